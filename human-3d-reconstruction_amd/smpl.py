@@ -1,0 +1,67 @@
+"""SMPL pose/shape -> linear-blend-skinning mesh stage (north_star).
+
+There is NO SMPL code, model file or test in the reference snapshot, and the real
+SMPL model is licence-gated, so this stage follows the published formulation (Loper et al.
+2015; axis-angle convention of the public `smplx` package) and ships a *synthetic* model of
+the true tensor shapes for benchmarking.  A real model drops in through `SMPLModel.from_npz`.
+Parity for this stage is "unpinned by the reference" (DESIGN.md).
+
+Device compute: csrc/smpl.hip via `h3d_smpl_*` (include/h3d.h).
+"""
+import numpy as np
+
+from . import synth
+
+NUM_VERTS = 6890
+NUM_JOINTS = 24
+NUM_BETAS = 10
+NUM_POSE_FEAT = 207
+PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
+                    20, 21], dtype=np.int32)
+
+
+class SMPLModel:
+    """Host container of the SMPL tensors (float32 numpy) + lazily-built device pack."""
+
+    def __init__(self, v_template, shapedirs, posedirs, J_regressor, weights, parents=PARENTS):
+        self.v_template = np.ascontiguousarray(v_template, np.float32)      # [V,3]
+        self.shapedirs = np.ascontiguousarray(shapedirs, np.float32)        # [V,3,10]
+        self.posedirs = np.ascontiguousarray(posedirs, np.float32)          # [V,3,207]
+        self.J_regressor = np.ascontiguousarray(J_regressor, np.float32)    # [24,V]
+        self.weights = np.ascontiguousarray(weights, np.float32)            # [V,24]
+        self.parents = np.ascontiguousarray(parents, np.int32)
+        V = self.v_template.shape[0]
+        assert self.shapedirs.shape == (V, 3, NUM_BETAS)
+        assert self.posedirs.shape == (V, 3, NUM_POSE_FEAT)
+        assert self.J_regressor.shape == (NUM_JOINTS, V)
+        assert self.weights.shape == (V, NUM_JOINTS)
+        self._dev = None
+
+    @classmethod
+    def synthetic(cls, seed=0, num_verts=NUM_VERTS):
+        """Seeded model with the true shapes: body-sized template, small blend shapes,
+        row-stochastic joint regressor, 4-sparse skinning weights (as the real model has)."""
+        V = num_verts
+        v = synth.uniform("smpl.v_template", (V, 3), -1.0, 1.0, seed) * np.array([0.45, 0.9, 0.15], np.float32)
+        S = synth.uniform("smpl.shapedirs", (V, 3, NUM_BETAS), -0.03, 0.03, seed)
+        P = synth.uniform("smpl.posedirs", (V, 3, NUM_POSE_FEAT), -0.01, 0.01, seed)
+        Jr = synth.uniform01("smpl.J_regressor", (NUM_JOINTS, V), seed)
+        Jr = np.where(Jr > 0.97, Jr, 0.0)
+        Jr = (Jr / Jr.sum(1, keepdims=True)).astype(np.float32)
+        u = synth.uniform01("smpl.weights", (V, NUM_JOINTS), seed)
+        kth = np.sort(u, axis=1)[:, -4][:, None]
+        W = np.where(u >= kth, u, 0.0)
+        W = (W / W.sum(1, keepdims=True)).astype(np.float32)
+        return cls(v, S, P, Jr, W)
+
+    @classmethod
+    def from_npz(cls, path):
+        d = np.load(path, allow_pickle=False)
+        parents = d["parents"] if "parents" in d else PARENTS
+        return cls(d["v_template"], d["shapedirs"], d["posedirs"], d["J_regressor"], d["weights"],
+                   parents)
+
+    def numpy_dict(self):
+        return {"v_template": self.v_template, "shapedirs": self.shapedirs,
+                "posedirs": self.posedirs, "J_regressor": self.J_regressor,
+                "weights": self.weights, "parents": self.parents}

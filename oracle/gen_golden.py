@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE -- golden-vector generator.  Runs ONLY in the build container:
+imports the reference's own Python code from /root/reference (read-only) and records its
+OUTPUTS on deterministic synthetic inputs (h3d_amd.synth) into tests/golden/*.npz.
+No reference source text is copied; the fixtures hold numbers only.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+What is recorded
+  dla34_plain.npz      reference `dla_net(heads, not_use_dcn=True)` (models/model.py:501-516) --
+                       the only variant the reference can run on a CPU -- on synthetic weights,
+                       input [2,3,96,128]; outputs = the six multi_pose heads.
+  dla34_shapes.json    the reference model's state_dict {key: shape} table.
+  decode_*.npz         reference `_nms/_topk/_topk_channel/multi_pose_decode/ctdet_decode`
+                       (models/decode.py) outputs on synthetic post-sigmoid heads.
+  sigmoid.npz          reference `_sigmoid` (models/utils.py:8-10) on a logit ramp.
+"""
+import json
+import os
+import sys
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/src/lib"
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import h3d_amd  # noqa: E402,F401
+from h3d_amd import synth  # noqa: E402
+
+from models import decode as ref_decode  # noqa: E402  (reference)
+from models import model as ref_model  # noqa: E402    (reference)
+from models import utils as ref_utils  # noqa: E402    (reference)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
+
+DECODE_CASES = {
+    # name: (B, H, W, K, seed, use_reg, use_hm_hp, use_hp_offset)
+    "decode_128x128_k100": (2, 128, 128, 100, 0, True, True, True),
+    "decode_48x64_k100": (3, 48, 64, 100, 1, True, True, True),
+    "decode_16x24_k100_tied": (2, 16, 24, 100, 2, True, True, True),
+    "decode_64x64_k40": (1, 64, 64, 40, 3, True, True, True),
+    "decode_32x32_noreg": (2, 32, 32, 50, 4, False, True, False),
+    "decode_32x32_nohp": (1, 32, 32, 50, 5, True, False, False),
+}
+
+
+def gen_dla():
+    torch.manual_seed(0)
+    m = ref_model.dla_net(HEADS, not_use_dcn=True).eval()
+    shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+    with open(os.path.join(OUT, "dla34_shapes.json"), "w") as f:
+        json.dump(shapes, f, indent=0, sort_keys=True)
+    sd = synth.synth_state_dict(shapes, seed=0)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    x = synth.synth_images(2, 96, 128, seed=317)
+    with torch.no_grad():
+        out = m(torch.from_numpy(x))[0]
+    np.savez_compressed(os.path.join(OUT, "dla34_plain.npz"),
+                        **{k: v.numpy() for k, v in out.items()})
+    print("dla34_plain:", {k: tuple(v.shape) for k, v in out.items()},
+          "hm range", float(out["hm"].min()), float(out["hm"].max()))
+
+
+def gen_decode():
+    for name, (B, H, W, K, seed, use_reg, use_hm_hp, use_off) in DECODE_CASES.items():
+        h = {k: torch.from_numpy(v) for k, v in synth.synth_heads(B, H, W, 17, seed).items()}
+        rec = {}
+        heat = ref_decode._nms(h["hm"])
+        s, inds, clses, ys, xs = ref_decode._topk(heat, K=K)
+        rec.update(topk_scores=s.numpy(), topk_inds=inds.numpy(), topk_clses=clses.numpy(),
+                   topk_ys=ys.numpy(), topk_xs=xs.numpy())
+        rec["nms_hm_nonzero"] = np.array([(heat[b] != 0).sum().item() for b in range(B)])
+        if use_hm_hp:
+            hs, hi, hy, hx = ref_decode._topk_channel(ref_decode._nms(h["hm_hp"]), K=K)
+            rec.update(hp_scores=hs.numpy(), hp_inds=hi.numpy(), hp_ys=hy.numpy(), hp_xs=hx.numpy())
+        dets = ref_decode.multi_pose_decode(
+            h["hm"].clone(), h["wh"].clone(), h["hps"].clone(),
+            reg=h["reg"].clone() if use_reg else None,
+            hm_hp=h["hm_hp"].clone() if use_hm_hp else None,
+            hp_offset=h["hp_offset"].clone() if use_off else None, K=K)
+        rec["dets"] = dets.numpy()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+        print(name, "dets", tuple(dets.shape), "survivors", rec["nms_hm_nonzero"])
+
+    # ctdet (two-stage top-k with 80 classes)
+    B, C, H, W, K = 2, 80, 32, 32, 100
+    u = synth.uniform("ctdet_hm", (B, C, H, W), 0.0, 1.0, 7)
+    hm = np.clip((u * u) * (u * u) * np.float32(0.9), np.float32(1e-4), np.float32(1 - 1e-4)).astype(np.float32)
+    wh = synth.uniform("ctdet_wh", (B, 2, H, W), 2.0, 20.0, 7)
+    reg = synth.uniform("ctdet_reg", (B, 2, H, W), 0.0, 1.0, 7)
+    heat = ref_decode._nms(torch.from_numpy(hm))
+    s, inds, clses, ys, xs = ref_decode._topk(heat, K=K)
+    dets = ref_decode.ctdet_decode(torch.from_numpy(hm), torch.from_numpy(wh),
+                                   reg=torch.from_numpy(reg), K=K)
+    np.savez_compressed(os.path.join(OUT, "ctdet_32x32_c80.npz"), dets=dets.numpy(),
+                        topk_scores=s.numpy(), topk_inds=inds.numpy(), topk_clses=clses.numpy(),
+                        topk_ys=ys.numpy(), topk_xs=xs.numpy())
+    print("ctdet", tuple(dets.shape))
+
+
+def gen_sigmoid():
+    x = np.concatenate([np.linspace(-20, 20, 4001, dtype=np.float32),
+                        synth.normalish("sig", (4096,), -2.19, 3.0, 0)])
+    y = ref_utils._sigmoid(torch.from_numpy(x.copy()))
+    np.savez_compressed(os.path.join(OUT, "sigmoid.npz"), x=x, y=y.numpy())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_sigmoid()
+    gen_decode()
+    gen_dla()
+    print("golden vectors written to", OUT)

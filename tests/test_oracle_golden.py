@@ -1,0 +1,111 @@
+"""CPU: the oracle restatements (oracle/dla.py, oracle/decode.py) against golden vectors that
+are OUTPUTS OF THE REFERENCE'S OWN CODE (tests/golden/*.npz, made by oracle/gen_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import h3d_amd  # noqa: F401
+from h3d_amd import synth
+from oracle import decode as odec
+from oracle import dla as odla
+
+HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
+
+CASES = {
+    "decode_128x128_k100": (2, 128, 128, 100, 0, True, True, True),
+    "decode_48x64_k100": (3, 48, 64, 100, 1, True, True, True),
+    "decode_16x24_k100_tied": (2, 16, 24, 100, 2, True, True, True),
+    "decode_64x64_k40": (1, 64, 64, 40, 3, True, True, True),
+    "decode_32x32_noreg": (2, 32, 32, 50, 4, False, True, False),
+    "decode_32x32_nohp": (1, 32, 32, 50, 5, True, False, False),
+}
+
+
+def test_sigmoid_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sigmoid.npz"))
+    y = odec.sigmoid_clamp(g["x"])
+    # numpy exp vs torch's vectorised sigmoid may differ by an ulp; the clamp plateaus are exact
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=1.2e-7)
+    assert (y[g["y"] == np.float32(1e-4)] == np.float32(1e-4)).all()
+
+
+def test_state_dict_shape_table_matches_reference(golden_dir):
+    ref = json.load(open(os.path.join(golden_dir, "dla34_shapes.json")))
+    ours = odla.state_dict_shapes(HEADS, use_dcn=False)
+    assert set(ours) == set(ref)
+    for k in ref:
+        assert tuple(ours[k]) == tuple(ref[k]), k
+
+
+def test_dla34_plain_forward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "dla34_plain.npz"))
+    shapes = odla.state_dict_shapes(HEADS, use_dcn=False)
+    sd = synth.synth_state_dict(shapes, seed=0)
+    net = odla.DLAOracle(sd, HEADS, use_dcn=False)
+    x = torch.from_numpy(synth.synth_images(2, 96, 128, seed=317))
+    with torch.no_grad():
+        out = net(x)[0]
+    for k in HEADS:
+        np.testing.assert_allclose(out[k].numpy(), g[k], rtol=1e-5, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_multi_pose_decode_matches_reference(golden_dir, name):
+    B, H, W, K, seed, use_reg, use_hp, use_off = CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    h = synth.synth_heads(B, H, W, 17, seed)
+    dets, aux = odec.multi_pose_decode(
+        h["hm"], h["wh"], h["hps"], reg=h["reg"] if use_reg else None,
+        hm_hp=h["hm_hp"] if use_hp else None, hp_offset=h["hp_offset"] if use_off else None,
+        K=K, return_aux=True)
+    # scores are identical as multisets everywhere; indices are bit-exact on the strict prefix
+    np.testing.assert_array_equal(aux["scores"], g["topk_scores"])
+    for b in range(B):
+        p = odec.strict_prefix(g["topk_scores"][b], K)
+        assert p >= min(K, int(g["nms_hm_nonzero"][b])) - 1 or p == K
+        np.testing.assert_array_equal(aux["inds"][b, :p], g["topk_inds"][b, :p])
+        np.testing.assert_array_equal(aux["ys"][b, :p], g["topk_ys"][b, :p])
+        np.testing.assert_array_equal(aux["xs"][b, :p], g["topk_xs"][b, :p])
+        np.testing.assert_array_equal(aux["clses"][b, :p], g["topk_clses"][b, :p])
+        if use_hp:
+            np.testing.assert_array_equal(aux["hm_score"][b], g["hp_scores"][b])
+            hp_strict = True
+            for j in range(17):
+                q = odec.strict_prefix(g["hp_scores"][b, j], K)
+                np.testing.assert_array_equal(aux["hm_inds"][b, j, :q], g["hp_inds"][b, j, :q])
+                hp_strict &= (q == K)
+        else:
+            hp_strict = True
+        # detections: rows in the strict prefix; keypoint columns additionally need every
+        # joint's candidate list to be tie-free (ties only ever involve sub-threshold 1e-4 / 0
+        # scores, which the 0.1 threshold masks out, so in practice all rows agree)
+        np.testing.assert_array_equal(dets[b, :p, :5], g["dets"][b, :p, :5])
+        np.testing.assert_array_equal(dets[b, :p, 39], g["dets"][b, :p, 39])
+        np.testing.assert_array_equal(dets[b, :p, 5:39], g["dets"][b, :p, 5:39])
+
+
+def test_strict_prefix_covers_all_real_peaks(golden_dir):
+    g = np.load(os.path.join(golden_dir, "decode_128x128_k100.npz"))
+    for b in range(2):
+        assert odec.strict_prefix(g["topk_scores"][b], 100) == 100
+
+
+def test_ctdet_decode_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ctdet_32x32_c80.npz"))
+    B, C, H, W, K = 2, 80, 32, 32, 100
+    u = synth.uniform("ctdet_hm", (B, C, H, W), 0.0, 1.0, 7)
+    hm = np.clip((u * u) * (u * u) * np.float32(0.9), np.float32(1e-4), np.float32(1 - 1e-4)).astype(np.float32)
+    wh = synth.uniform("ctdet_wh", (B, 2, H, W), 2.0, 20.0, 7)
+    reg = synth.uniform("ctdet_reg", (B, 2, H, W), 0.0, 1.0, 7)
+    s, inds, clses, ys, xs = odec.topk(odec.nms(hm), K)
+    np.testing.assert_array_equal(s, g["topk_scores"])
+    for b in range(B):
+        p = odec.strict_prefix(g["topk_scores"][b], K)
+        assert p == K
+        np.testing.assert_array_equal(inds[b], g["topk_inds"][b])
+        np.testing.assert_array_equal(clses[b], g["topk_clses"][b])
+    dets = odec.ctdet_decode(hm, wh, reg=reg, K=K)
+    np.testing.assert_array_equal(dets, g["dets"])

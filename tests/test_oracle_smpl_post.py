@@ -1,0 +1,76 @@
+"""CPU: analytic known answers for the restatements that have NO importable reference
+(SMPL: no reference code at all -> parity unpinned; post-process: reference needs cv2)."""
+import numpy as np
+
+import h3d_amd  # noqa: F401
+from h3d_amd import smpl as psmpl
+from oracle import post_process as opost
+from oracle import smpl as osmpl
+
+
+def _model():
+    return psmpl.SMPLModel.synthetic(seed=0).numpy_dict()
+
+
+def test_rodrigues_properties():
+    th = np.array([[0, 0, 0], [0.3, -0.2, 0.9], [np.pi / 2, 0, 0], [0, 0, -3.0]])
+    R = osmpl.rodrigues(th)
+    np.testing.assert_allclose(R[0], np.eye(3), atol=1e-7)
+    for r in R:
+        np.testing.assert_allclose(r @ r.T, np.eye(3), atol=1e-12)
+        assert abs(np.linalg.det(r) - 1) < 1e-12
+    np.testing.assert_allclose(R[2], [[1, 0, 0], [0, 0, -1], [0, 1, 0]], atol=1e-7)
+
+
+def test_zero_pose_is_shape_blend_only():
+    m = _model()
+    betas = np.linspace(-1, 1, 20).reshape(2, 10)
+    v, j = osmpl.lbs(betas, np.zeros((2, 72)), m)
+    v_s = m["v_template"][None] + np.einsum("vck,pk->pvc", m["shapedirs"], betas)
+    np.testing.assert_allclose(v, v_s, atol=1e-6)
+    np.testing.assert_allclose(j, np.einsum("jv,pvc->pjc", m["J_regressor"], v_s), atol=1e-6)
+
+
+def test_single_joint_rotation_moves_only_descendants():
+    m = _model()
+    th = np.zeros((1, 24, 3))
+    th[0, 18] = [0, 0, np.pi / 2]          # left elbow: descendants 20, 22
+    v0, _ = osmpl.lbs(np.zeros((1, 10)), np.zeros((1, 72)), m)
+    mm = dict(m)
+    mm["posedirs"] = np.zeros_like(m["posedirs"])      # isolate the skinning effect
+    v1, _ = osmpl.lbs(np.zeros((1, 10)), th.reshape(1, 72), mm)
+    moved = np.abs(v1 - v0).max(axis=(0, 2)) > 1e-9
+    desc = np.zeros(24, bool)
+    desc[[18, 20, 22]] = True
+    has_desc_weight = (m["weights"][:, desc].sum(1) > 0)
+    assert (moved <= has_desc_weight).all()
+    assert moved.sum() > 0
+
+
+def test_global_rotation_rotates_about_root():
+    m = _model()
+    th = np.zeros((1, 72))
+    th[0, :3] = [0, np.pi / 2, 0]
+    mm = dict(m)
+    mm["posedirs"] = np.zeros_like(m["posedirs"])
+    v0, j0 = osmpl.lbs(np.zeros((1, 10)), np.zeros((1, 72)), mm)
+    v1, j1 = osmpl.lbs(np.zeros((1, 10)), th, mm)
+    R = osmpl.rodrigues(th[0, :3])
+    np.testing.assert_allclose(v1[0], (v0[0] - j0[0, 0]) @ R.T + j0[0, 0], atol=1e-6)
+
+
+def test_post_process_is_scale_and_shift_for_centred_crop():
+    # c = image centre, s = max(h,w): x_img = (x_out - w_out/2) * s / w_out + c_x
+    dets = np.zeros((1, 5, 40), np.float32)
+    rng = np.random.RandomState(0)
+    dets[0, :, :4] = rng.uniform(0, 128, (5, 4))
+    dets[0, :, 4] = rng.uniform(0, 1, 5)
+    dets[0, :, 5:39] = rng.uniform(0, 128, (5, 34))
+    c = np.array([[320.0, 240.0]], np.float32)
+    s = np.array([640.0], np.float32)
+    out = opost.multi_pose_post_process(dets.copy(), c, s, 128, 128)[0]
+    exp_box = (dets[0, :, :4].reshape(-1, 2) - 64.0) * 5.0 + c[0]
+    np.testing.assert_allclose(out[:, :4], exp_box.reshape(-1, 4), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(out[:, 4], dets[0, :, 4])
+    exp_pts = (dets[0, :, 5:39].reshape(-1, 2) - 64.0) * 5.0 + c[0]
+    np.testing.assert_allclose(out[:, 5:], exp_pts.reshape(-1, 34), rtol=1e-5, atol=1e-3)
