@@ -1,0 +1,121 @@
+// Shared device/host helpers for libh3d_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/h3d.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- error plumbing -------------------------------------------------------------------------
+void h3d_set_error(const char *fmt, ...);
+#define H3D_FAIL(code, ...)        \
+    do {                           \
+        h3d_set_error(__VA_ARGS__); \
+        return (code);             \
+    } while (0)
+#define H3D_CHECK_LAUNCH(name)                                                          \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) H3D_FAIL(H3D_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- element traits: the same kernel source runs in f32 ("parity mode", exact fmaf chain on
+//      v_mfma_f32_32x32x2_f32) and bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+//      A fragment = 8 consecutive K elements of one row/column per lane:
+//        lane l: row/col = l & 31, K offset = 8 * (l >> 5)   (both operands use the same map,
+//        so for f32 the 8 k=2 MFMAs simply walk the 8 elements; K order is permuted
+//        identically on A and B).
+template <typename T> struct ET;
+
+template <> struct ET<float> {
+    static constexpr int BYTES = 4;
+    struct frag { f32x4 lo, hi; };
+    static __device__ __forceinline__ frag lds_frag(const char *p)
+    {
+        frag f;
+        f.lo = *reinterpret_cast<const f32x4 *>(p);
+        f.hi = *reinterpret_cast<const f32x4 *>(p + 16);
+        return f;
+    }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[0], b.lo[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[1], b.lo[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[2], b.lo[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[3], b.lo[3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[0], b.hi[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[1], b.hi[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[2], b.hi[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[3], b.hi[3], acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(float v) { return v; }
+    static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+
+template <> struct ET<bf16_t> {
+    static constexpr int BYTES = 2;
+    struct frag { u32x4 v; };
+    static __device__ __forceinline__ frag lds_frag(const char *p)
+    {
+        frag f;
+        f.v = *reinterpret_cast<const u32x4 *>(p);
+        return f;
+    }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v),
+                                                      __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(bf16_t v)
+    {
+        return __uint_as_float(((uint32_t)v) << 16);
+    }
+    static __device__ __forceinline__ bf16_t from_f32(float f)
+    {
+        __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+        return __builtin_bit_cast(uint16_t, b);
+    }
+};
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    return (uint32_t)ET<bf16_t>::from_f32(lo) | ((uint32_t)ET<bf16_t>::from_f32(hi) << 16);
+}
+
+// store 4 consecutive channels held as floats
+template <typename T> __device__ __forceinline__ void store4(T *p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float *p, float a, float b, float c, float d)
+{
+    f32x4 v = {a, b, c, d};
+    *reinterpret_cast<f32x4 *>(p) = v;
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float a, float b, float c, float d)
+{
+    u32x2 v = {pack_bf16x2(a, b), pack_bf16x2(c, d)};
+    *reinterpret_cast<u32x2 *>(p) = v;
+}
+template <typename T> __device__ __forceinline__ void load4(const T *p, float *o);
+template <> __device__ __forceinline__ void load4<float>(const float *p, float *o)
+{
+    f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t *p, float *o)
+{
+    u32x2 v = *reinterpret_cast<const u32x2 *>(p);
+    o[0] = __uint_as_float(v[0] << 16);
+    o[1] = __uint_as_float(v[0] & 0xffff0000u);
+    o[2] = __uint_as_float(v[1] << 16);
+    o[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

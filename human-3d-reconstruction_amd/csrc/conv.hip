@@ -1,0 +1,538 @@
+// Dense convolution stack of DLA-34 on gfx950: implicit-GEMM on MFMA with the input halo tile
+// staged once in LDS and re-read by all kh*kw taps (no im2col buffer, no per-tap re-fetch).
+//
+// Replaces the cuDNN calls behind nn.Conv2d / BatchNorm2d / ReLU / residual add of
+// /root/reference/src/lib/models/model.py:32-61 (BasicBlock), 148-166 (Root), 200-207 (project),
+// 274-284 (conv levels), 451-460 (heads).  BatchNorm (eval) is folded into weights/bias by the
+// host packer; bias, residual add and ReLU are the epilogue.
+//
+// GEMM orientation: M = output channels (A operand = weights), N = pixels (B operand = halo
+// tile), so an accumulator lane owns ONE pixel and 4-channel runs -> NHWC stores of 8/16 B per
+// lane and fully coalesced NCHW rows for the head outputs.
+//
+// Block = 256 threads = 4 waves; output tile = TH x 16 pixels of one image x (32*MT) channels.
+// wave w owns tile rows [w*TH/4, (w+1)*TH/4): NT = TH/8 N-tiles of 32 pixels (2 rows x 16).
+// LDS image of the halo: pixel stride SB = CK*sizeof(T)+16 bytes (odd multiple of 16 B), row
+// stride RB = multiple of 256 B, which makes every ds_read_b128 fragment read conflict-free for
+// stride-1 convs (bank = (addr/4)%64, 16-lane groups {0-3,12-15,20-27},{4-11,16-19,28-31}).
+#include "common.h"
+#include "epilogue.h"
+
+struct ConvArgs {
+    const char *in;
+    const char *w;
+    const float *bias;
+    const char *res;
+    char *out;
+    int B, H, W, Cin, in_cs;
+    int Ho, Wo, Cout, out_cs, res_cs;
+    int relu, out_mode;
+    int tiles_x, tiles_y;
+};
+
+template <typename T, int KS, int STRIDE, int MT, int CK, int TH>
+struct ConvCfg {
+    static constexpr int TW = 16;
+    static constexpr int ES = sizeof(T);
+    static constexpr int PAD = KS / 2;
+    static constexpr int IN_H = (TH - 1) * STRIDE + KS;
+    static constexpr int IN_W = (TW - 1) * STRIDE + KS;
+    static constexpr int SB = CK * ES + 16;
+    static constexpr int RB = ((IN_W * SB + 255) / 256) * 256;
+    static constexpr int WB = KS * KS * CK * ES + 16;
+    static constexpr int BN = 32 * MT;
+    static constexpr int NT = TH / 8;
+    static constexpr int VPP = CK * ES / 16;  // 16-byte vectors per pixel per chunk
+    static constexpr int LDS_IN = IN_H * RB;
+    static constexpr int LDS_W = BN * WB;
+    static constexpr int LDS = LDS_IN + LDS_W;
+};
+
+template <typename T, int KS, int STRIDE, int MT, int CK, int TH>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a)
+{
+    using C = ConvCfg<T, KS, STRIDE, MT, CK, TH>;
+    using E = ET<T>;
+    constexpr int ES = C::ES;
+    __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+    char *s_in = smem;
+    char *s_w = smem + C::LDS_IN;
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * C::TW;
+    const int cout0 = blockIdx.y * C::BN;
+
+    f32x16 acc[MT][C::NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    // per-lane LDS byte offsets of the B (pixel) fragments at tap (0,0), k = 0
+    int boff[C::NT];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n) {
+        const int py = wv * (2 * C::NT) + n * 2 + (r >> 4), px = r & 15;
+        boff[n] = (py * STRIDE) * C::RB + (px * STRIDE) * C::SB + 8 * h * ES;
+    }
+    const int aoff = r * C::WB + 8 * h * ES;
+
+    const size_t in_img = (size_t)b * a.H * a.W;
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        if (c0) __syncthreads();
+        // ---- stage the input halo chunk [IN_H][IN_W][CK] (zero outside the image) -------------
+        for (int i = tid; i < C::IN_H * C::IN_W * C::VPP; i += 256) {
+            const int v = i % C::VPP, pix = i / C::VPP;
+            const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
+            const int gy = oy0 * STRIDE - C::PAD + iy, gx = ox0 * STRIDE - C::PAD + ix;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                val = *reinterpret_cast<const u32x4 *>(
+                    a.in + ((in_img + (size_t)gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
+            *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = val;
+        }
+        // ---- stage the weight chunk [BN][KS*KS][CK] --------------------------------------------
+        constexpr int WV = KS * KS * C::VPP;
+        for (int i = tid; i < C::BN * WV; i += 256) {
+            const int row = i / WV, q = i - row * WV;
+            const int tap = q / C::VPP, v = q - tap * C::VPP;
+            const u32x4 val = *reinterpret_cast<const u32x4 *>(
+                a.w + (((size_t)(cout0 + row) * (KS * KS) + tap) * a.Cin + c0) * ES + v * 16);
+            *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * ES + v * 16) = val;
+        }
+        __syncthreads();
+        // ---- contraction over this chunk: taps x CK/16 k-steps -------------------------------------
+#pragma unroll
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int dy = tap / KS, dx = tap - dy * KS;
+#pragma unroll
+            for (int kk = 0; kk < CK / 16; ++kk) {
+                typename E::frag fa[MT], fb[C::NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    fa[m] = E::lds_frag(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * ES);
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n)
+                    fb[n] = E::lds_frag(s_in + boff[n] + dy * C::RB + dx * C::SB + kk * 16 * ES);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
+            }
+        }
+    }
+
+    EpiArgs e;
+    e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = a.Cout;
+    e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
+    tile_epilogue<T, MT, C::NT>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+}
+
+template <typename T, int KS, int STRIDE, int MT, int CK, int TH>
+static int launch_conv_cfg(const ConvArgs &a0, hipStream_t st)
+{
+    using C = ConvCfg<T, KS, STRIDE, MT, CK, TH>;
+    static_assert(C::LDS <= 160 * 1024, "LDS budget");
+    ConvArgs a = a0;
+    a.tiles_x = cdiv(a.Wo, C::TW);
+    a.tiles_y = cdiv(a.Ho, TH);
+    dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
+    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH>), grid, dim3(256), 0, st, a);
+    H3D_CHECK_LAUNCH("conv_kernel");
+    return H3D_OK;
+}
+
+template <typename T> static int launch_conv_t(const h3d_op &op, const ConvArgs &a, hipStream_t st);
+
+template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipStream_t st)
+{
+    const int cin = op.Cin, co = op.Cout;
+    if (op.ksize == 3 && op.stride == 1) {
+        if (cin % 32 == 0) {
+            if (co <= 32) return launch_conv_cfg<bf16_t, 3, 1, 1, 32, 16>(a, st);
+            if (co <= 64) return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 16>(a, st);
+            return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 16>(a, st);
+        }
+        if (co <= 32) return launch_conv_cfg<bf16_t, 3, 1, 1, 16, 16>(a, st);
+        if (co <= 64) return launch_conv_cfg<bf16_t, 3, 1, 2, 16, 16>(a, st);
+        return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 16>(a, st);
+    }
+    if (op.ksize == 3 && op.stride == 2) {
+        if (co <= 32) return launch_conv_cfg<bf16_t, 3, 2, 1, 16, 8>(a, st);
+        if (co <= 64) return launch_conv_cfg<bf16_t, 3, 2, 2, 16, 8>(a, st);
+        return launch_conv_cfg<bf16_t, 3, 2, 4, 16, 8>(a, st);
+    }
+    if (op.ksize == 1 && op.stride == 1) {
+        if (cin % 64 == 0) {
+            if (co <= 32) return launch_conv_cfg<bf16_t, 1, 1, 1, 64, 16>(a, st);
+            if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 16>(a, st);
+            return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 16>(a, st);
+        }
+        if (co <= 32) return launch_conv_cfg<bf16_t, 1, 1, 1, 16, 16>(a, st);
+        if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 16, 16>(a, st);
+        return launch_conv_cfg<bf16_t, 1, 1, 4, 16, 16>(a, st);
+    }
+    H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv: ksize=%d stride=%d not covered (k in {1,3}, stride in {1,2})",
+             op.ksize, op.stride);
+}
+
+template <> int launch_conv_t<float>(const h3d_op &op, const ConvArgs &a, hipStream_t st)
+{
+    const int co = op.Cout;
+    if (op.ksize == 3 && op.stride == 1) {
+        if (co <= 32) return launch_conv_cfg<float, 3, 1, 1, 16, 16>(a, st);
+        return launch_conv_cfg<float, 3, 1, 2, 16, 16>(a, st);
+    }
+    if (op.ksize == 3 && op.stride == 2) {
+        if (co <= 32) return launch_conv_cfg<float, 3, 2, 1, 16, 8>(a, st);
+        return launch_conv_cfg<float, 3, 2, 2, 16, 8>(a, st);
+    }
+    if (op.ksize == 1 && op.stride == 1) {
+        if (co <= 32) return launch_conv_cfg<float, 1, 1, 1, 16, 16>(a, st);
+        return launch_conv_cfg<float, 1, 1, 2, 16, 16>(a, st);
+    }
+    H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv: ksize=%d stride=%d not covered (k in {1,3}, stride in {1,2})",
+             op.ksize, op.stride);
+}
+
+int h3d_launch_conv(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "conv: null pointer");
+    const int es = op.dtype == H3D_BF16 ? 2 : 4;
+    if (op.Cin % 16 || op.in_cs % (16 / es) || op.Cin > op.in_cs)
+        H3D_FAIL(H3D_ERR_SHAPE, "conv: Cin=%d (stride %d) must be a multiple of 16", op.Cin, op.in_cs);
+    const int pad = op.ksize / 2;
+    const int ho = (op.H + 2 * pad - op.ksize) / op.stride + 1;
+    const int wo = (op.W + 2 * pad - op.ksize) / op.stride + 1;
+    if (ho != op.Ho || wo != op.Wo)
+        H3D_FAIL(H3D_ERR_SHAPE, "conv: output %dx%d does not match (H+2p-k)/s+1 = %dx%d", op.Ho, op.Wo, ho, wo);
+    if (op.wrows < ((op.Cout + 127) / 128) * 128)
+        H3D_FAIL(H3D_ERR_SHAPE, "conv: packed weight rows %d < Cout %d padded to 128", op.wrows, op.Cout);
+    if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
+        H3D_FAIL(H3D_ERR_SHAPE, "conv: out channel stride %d must be a multiple of 4 and >= Cout %d", op.out_cs, op.Cout);
+    if (op.in2 && (op.in2_cs % 4)) H3D_FAIL(H3D_ERR_SHAPE, "conv: residual channel stride %d", op.in2_cs);
+    ConvArgs a;
+    a.in = (const char *)op.in; a.w = (const char *)op.w; a.bias = op.bias;
+    a.res = (const char *)op.in2; a.out = (char *)op.out;
+    a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
+    a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.out_cs = op.out_cs; a.res_cs = op.in2_cs;
+    a.relu = op.relu; a.out_mode = op.out_mode; a.tiles_x = a.tiles_y = 0;
+    if (op.dtype == H3D_BF16) return launch_conv_t<bf16_t>(op, a, st);
+    if (op.dtype == H3D_F32) return launch_conv_t<float>(op, a, st);
+    H3D_FAIL(H3D_ERR_DTYPE, "conv: dtype %d", op.dtype);
+}
+
+// =================================================================================================
+// Stem: base_layer = Conv2d(3, C0=16, 7x7, s1, p3, bias=False) + BN + ReLU (model.py:231-235),
+// reading the NCHW fp32 image batch and writing NHWC T.  v1: direct FMA, weights via scalar loads.
+// w: fp32 [16][3][7][7] (BN folded), bias fp32 [16].
+template <typename T>
+__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                   const float *__restrict__ bias, T *__restrict__ out,
+                                                   int B, int H, int W, int out_cs, int tiles_x, int tiles_y)
+{
+    constexpr int TS = 16, HS = TS + 6;
+    __shared__ float s[3][HS][HS + 1];
+    const int tiles = tiles_x * tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int oy0 = ty * TS, ox0 = tx * TS;
+    for (int i = threadIdx.x; i < 3 * HS * HS; i += 256) {
+        const int c = i / (HS * HS), rem = i - c * HS * HS;
+        const int iy = rem / HS, ix = rem - iy * HS;
+        const int gy = oy0 - 3 + iy, gx = ox0 - 3 + ix;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = img[(((size_t)b * 3 + c) * H + gy) * W + gx];
+        s[c][iy][ix] = v;
+    }
+    __syncthreads();
+    const int py = threadIdx.x >> 4, px = threadIdx.x & 15;
+    float acc[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) acc[o] = bias[o];
+    for (int c = 0; c < 3; ++c)
+        for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 7; ++dx) {
+                const float x = s[c][py + dy][px + dx];
+#pragma unroll
+                for (int o = 0; o < 16; ++o) acc[o] = fmaf(w[((o * 3 + c) * 7 + dy) * 7 + dx], x, acc[o]);
+            }
+    const int oy = oy0 + py, ox = ox0 + px;
+    if (oy < H && ox < W) {
+        T *op = out + (((size_t)b * H + oy) * W + ox) * out_cs;
+#pragma unroll
+        for (int o = 0; o < 16; o += 4)
+            store4<T>(op + o, fmaxf(acc[o], 0.f), fmaxf(acc[o + 1], 0.f), fmaxf(acc[o + 2], 0.f),
+                      fmaxf(acc[o + 3], 0.f));
+    }
+}
+
+int h3d_launch_stem(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "stem: null pointer");
+    if (op.Cin != 3 || op.Cout != 16 || op.ksize != 7 || op.Ho != op.H || op.Wo != op.W || op.out_cs % 4)
+        H3D_FAIL(H3D_ERR_SHAPE, "stem: expects 7x7 3->16 stride 1 (got k=%d %d->%d)", op.ksize, op.Cin, op.Cout);
+    const int tx = cdiv(op.W, 16), ty = cdiv(op.H, 16);
+    dim3 grid(op.B * tx * ty);
+    if (op.dtype == H3D_BF16)
+        hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, st, (const float *)op.in, (const float *)op.w,
+                           op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.out_cs, tx, ty);
+    else if (op.dtype == H3D_F32)
+        hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, st, (const float *)op.in, (const float *)op.w,
+                           op.bias, (float *)op.out, op.B, op.H, op.W, op.out_cs, tx, ty);
+    else
+        H3D_FAIL(H3D_ERR_DTYPE, "stem: dtype %d", op.dtype);
+    H3D_CHECK_LAUNCH("stem_kernel");
+    return H3D_OK;
+}
+
+// =================================================================================================
+// Elementwise NHWC kernels (HBM-bound; 16 B per lane)
+template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T>
+__device__ __forceinline__ void unpack16(const u32x4 &v, float *o)
+{
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(v[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(v[i] << 16);
+            o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ u32x4 pack16(const float *o)
+{
+    u32x4 v;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(o[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
+    }
+    return v;
+}
+
+// 2x2/2 max pool (floor semantics of nn.MaxPool2d(2, stride=2), model.py:201)
+template <typename T>
+__global__ void maxpool_kernel(const T *__restrict__ in, T *__restrict__ out, int B, int H, int W, int C,
+                               int in_cs, int Ho, int Wo, int out_cs)
+{
+    constexpr int N = Vec16<T>::N;
+    const int vpc = C / N;
+    const size_t total = (size_t)B * Ho * Wo * vpc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = i % vpc;
+        const size_t p = i / vpc;
+        const int ox = p % Wo;
+        const size_t q = p / Wo;
+        const int oy = q % Ho, b = q / Ho;
+        float m[N], x[N];
+        const T *base = in + (((size_t)b * H + oy * 2) * W + ox * 2) * in_cs + v * N;
+        unpack16<T>(*reinterpret_cast<const u32x4 *>(base), m);
+        unpack16<T>(*reinterpret_cast<const u32x4 *>(base + in_cs), x);
+#pragma unroll
+        for (int k = 0; k < N; ++k) m[k] = fmaxf(m[k], x[k]);
+        unpack16<T>(*reinterpret_cast<const u32x4 *>(base + (size_t)W * in_cs), x);
+#pragma unroll
+        for (int k = 0; k < N; ++k) m[k] = fmaxf(m[k], x[k]);
+        unpack16<T>(*reinterpret_cast<const u32x4 *>(base + (size_t)W * in_cs + in_cs), x);
+#pragma unroll
+        for (int k = 0; k < N; ++k) m[k] = fmaxf(m[k], x[k]);
+        *reinterpret_cast<u32x4 *>(out + p * out_cs + v * N) = pack16<T>(m);
+    }
+}
+
+// Depthwise ConvTranspose2d(C, C, k=2f, stride=f, padding=f/2, groups=C, bias=False) + skip add
+// (IDAUp.forward: layers[i] = up(proj(layers[i])); node(layers[i] + layers[i-1]), model.py:384-390).
+// out[oy][ox][c] = skip + sum over (i,j) with (oy + p - i) % f == 0: w[c][i][j] * in[(oy+p-i)/f][(ox+p-j)/f][c]
+// -> exactly two i and two j per output pixel.  w: fp32 [k*k][C] (tap-major so channel vectors load).
+template <typename T>
+__global__ void upadd_kernel(const T *__restrict__ in, const T *__restrict__ skip, const float *__restrict__ w,
+                             T *__restrict__ out, int B, int H, int W, int C, int in_cs, int skip_cs, int Ho,
+                             int Wo, int out_cs, int f)
+{
+    constexpr int N = Vec16<T>::N;
+    const int vpc = C / N, k = 2 * f, p = f / 2;
+    const size_t total = (size_t)B * Ho * Wo * vpc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = i % vpc;
+        const size_t pix = i / vpc;
+        const int ox = pix % Wo;
+        const size_t q = pix / Wo;
+        const int oy = q % Ho, b = q / Ho;
+        float acc[N], x[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = 0.f;
+        const int ry = (oy + p) % f, rx = (ox + p) % f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ki = ry + a * f;
+            const int iy = (oy + p - ki) / f;  // exact: (oy+p-ki) is a multiple of f (may be negative)
+            if (oy + p - ki < 0 || iy >= H) continue;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const int kj = rx + c2 * f;
+                const int ix = (ox + p - kj) / f;
+                if (ox + p - kj < 0 || ix >= W) continue;
+                unpack16<T>(*reinterpret_cast<const u32x4 *>(in + (((size_t)b * H + iy) * W + ix) * in_cs + v * N), x);
+                const float *wp = w + (size_t)(ki * k + kj) * C + v * N;
+#pragma unroll
+                for (int n = 0; n < N; ++n) acc[n] = fmaf(wp[n], x[n], acc[n]);
+            }
+        }
+        unpack16<T>(*reinterpret_cast<const u32x4 *>(skip + pix * skip_cs + v * N), x);
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] += x[n];
+        *reinterpret_cast<u32x4 *>(out + pix * out_cs + v * N) = pack16<T>(acc);
+    }
+}
+
+template <typename T>
+__global__ void copy_kernel(const T *__restrict__ in, T *__restrict__ out, size_t npix, int C, int in_cs, int out_cs)
+{
+    constexpr int N = Vec16<T>::N;
+    const int vpc = C / N;
+    const size_t total = npix * vpc;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int v = i % vpc;
+        const size_t p = i / vpc;
+        *reinterpret_cast<u32x4 *>(out + p * out_cs + v * N) = *reinterpret_cast<const u32x4 *>(in + p * in_cs + v * N);
+    }
+}
+
+static inline int ew_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 2048 * 8 ? 2048 * 8 : (g ? g : 1)); }
+
+int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.out) H3D_FAIL(H3D_ERR_ARG, "elementwise: null pointer");
+    const int es = op.dtype == H3D_BF16 ? 2 : (op.dtype == H3D_F32 ? 4 : 0);
+    if (!es) H3D_FAIL(H3D_ERR_DTYPE, "elementwise: dtype %d", op.dtype);
+    const int n = 16 / es;
+    if (op.Cin % n || op.in_cs % n || op.out_cs % n || op.Cin != op.Cout)
+        H3D_FAIL(H3D_ERR_SHAPE, "elementwise: channels %d/%d strides %d/%d must be multiples of %d", op.Cin, op.Cout,
+                 op.in_cs, op.out_cs, n);
+    const size_t total = (size_t)op.B * op.Ho * op.Wo * (op.Cin / n);
+    dim3 grid(ew_grid(total)), blk(256);
+    if (op.kind == H3D_OP_MAXPOOL) {
+        if (op.Ho != op.H / 2 || op.Wo != op.W / 2) H3D_FAIL(H3D_ERR_SHAPE, "maxpool: output must be floor(H/2) x floor(W/2)");
+        if (es == 2)
+            hipLaunchKernelGGL(maxpool_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t *)op.in, (bf16_t *)op.out, op.B, op.H,
+                               op.W, op.Cin, op.in_cs, op.Ho, op.Wo, op.out_cs);
+        else
+            hipLaunchKernelGGL(maxpool_kernel<float>, grid, blk, 0, st, (const float *)op.in, (float *)op.out, op.B, op.H,
+                               op.W, op.Cin, op.in_cs, op.Ho, op.Wo, op.out_cs);
+        H3D_CHECK_LAUNCH("maxpool_kernel");
+    } else if (op.kind == H3D_OP_UPADD) {
+        const int f = op.stride;
+        if (!op.in2 || !op.w) H3D_FAIL(H3D_ERR_ARG, "upadd: null pointer");
+        if (op.ksize != 2 * f || op.Ho != op.H * f || op.Wo != op.W * f || op.in2_cs % n)
+            H3D_FAIL(H3D_ERR_SHAPE, "upadd: expects k=2f, out = f*in (k=%d f=%d)", op.ksize, f);
+        if (es == 2)
+            hipLaunchKernelGGL(upadd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t *)op.in, (const bf16_t *)op.in2,
+                               (const float *)op.w, (bf16_t *)op.out, op.B, op.H, op.W, op.Cin, op.in_cs, op.in2_cs, op.Ho,
+                               op.Wo, op.out_cs, f);
+        else
+            hipLaunchKernelGGL(upadd_kernel<float>, grid, blk, 0, st, (const float *)op.in, (const float *)op.in2,
+                               (const float *)op.w, (float *)op.out, op.B, op.H, op.W, op.Cin, op.in_cs, op.in2_cs, op.Ho,
+                               op.Wo, op.out_cs, f);
+        H3D_CHECK_LAUNCH("upadd_kernel");
+    } else {
+        if (op.Ho != op.H || op.Wo != op.W) H3D_FAIL(H3D_ERR_SHAPE, "copy: shape");
+        const size_t npix = (size_t)op.B * op.H * op.W;
+        if (es == 2)
+            hipLaunchKernelGGL(copy_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t *)op.in, (bf16_t *)op.out, npix, op.Cin,
+                               op.in_cs, op.out_cs);
+        else
+            hipLaunchKernelGGL(copy_kernel<float>, grid, blk, 0, st, (const float *)op.in, (float *)op.out, npix, op.Cin,
+                               op.in_cs, op.out_cs);
+        H3D_CHECK_LAUNCH("copy_kernel");
+    }
+    return H3D_OK;
+}
+
+// =================================================================================================
+// Layout converters at the host boundary (reference tensors are NCHW fp32)
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float *__restrict__ src, T *__restrict__ dst, int B, int C, int HW, int dst_cs)
+{
+    // tile 32 pixels x 32 channels through LDS so both sides are coalesced
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, p = p0 + tx;
+        tile[k][tx] = (c < C && p < HW) ? src[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int p = p0 + k, c = c0 + tx;
+        if (p < HW && c < C) dst[((size_t)b * HW + p) * dst_cs + c] = ET<T>::from_f32(tile[tx][k]);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T *__restrict__ src, float *__restrict__ dst, int B, int C, int HW, int src_cs)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int p = p0 + k, c = c0 + tx;
+        tile[k][tx] = (p < HW && c < C) ? ET<T>::to_f32(src[((size_t)b * HW + p) * src_cs + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, p = p0 + tx;
+        if (c < C && p < HW) dst[((size_t)b * C + c) * HW + p] = tile[tx][k];
+    }
+}
+
+extern "C" int h3d_nchw_f32_to_nhwc(const float *src, void *dst, int dtype, int B, int C, int H, int W, int dst_cs,
+                                    void *stream)
+{
+    if (!src || !dst) H3D_FAIL(H3D_ERR_ARG, "nchw_to_nhwc: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || dst_cs < C) H3D_FAIL(H3D_ERR_SHAPE, "nchw_to_nhwc: bad shape");
+    dim3 grid(cdiv(H * W, 32), cdiv(C, 32), B);
+    if (dtype == H3D_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t *)dst, B, C,
+                           H * W, dst_cs);
+    else if (dtype == H3D_F32)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float *)dst, B, C,
+                           H * W, dst_cs);
+    else
+        H3D_FAIL(H3D_ERR_DTYPE, "nchw_to_nhwc: dtype %d", dtype);
+    H3D_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return H3D_OK;
+}
+
+extern "C" int h3d_nhwc_to_nchw_f32(const void *src, int dtype, float *dst, int B, int C, int H, int W, int src_cs,
+                                    void *stream)
+{
+    if (!src || !dst) H3D_FAIL(H3D_ERR_ARG, "nhwc_to_nchw: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || src_cs < C) H3D_FAIL(H3D_ERR_SHAPE, "nhwc_to_nchw: bad shape");
+    dim3 grid(cdiv(H * W, 32), cdiv(C, 32), B);
+    if (dtype == H3D_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)src, dst,
+                           B, C, H * W, src_cs);
+    else if (dtype == H3D_F32)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, dst, B,
+                           C, H * W, src_cs);
+    else
+        H3D_FAIL(H3D_ERR_DTYPE, "nhwc_to_nchw: dtype %d", dtype);
+    H3D_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return H3D_OK;
+}

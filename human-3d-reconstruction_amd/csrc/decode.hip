@@ -1,0 +1,489 @@
+// CenterNet heat-map decode on gfx950 (reference: /root/reference/src/lib/models/decode.py,
+// utils.py).  Bit-exact with the reference's CPU results on identical fp32 inputs: every float
+// operation below is a single IEEE op in the reference's order (this file is compiled with
+// -ffp-contract=off), and index selection is an exact integer radix select.
+//
+//   nms_topk_kernel      _sigmoid (utils.py:8-10, optional) + _nms (decode.py:6-13) +
+//                        per-map top-K (decode.py:18/29) -- one workgroup per (b, c) map;
+//                        map keys live in LDS, 4x8-bit radix select for the K-th key, ordered
+//                        compaction of ties (lowest index first), bitonic sort of the K survivors.
+//   topk_merge_kernel    stage 2 of _topk (decode.py:34-39)
+//   gather_feat_kernel   _transpose_and_gather_feat (utils.py:23-27) without the NHWC transpose
+//   pose_assemble_kernel multi_pose_decode body (decode.py:86-161)
+//   ctdet_assemble_kernel ctdet_decode body (decode.py:52-75)
+//   post_process_kernel  multi_pose_post_process (utils/post_process.py:41-52)
+#include "common.h"
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint32_t fkey(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// descending bitonic sort of N (power of two) 64-bit keys in LDS, all `nthreads` threads call
+__device__ void bitonic_desc(u64 *s, int N, int tid, int nthreads)
+{
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < N; i += nthreads) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 x = s[i], y = s[ixj];
+                    const bool desc_blk = ((i & k) == 0);
+                    if (desc_blk ? (x < y) : (x > y)) { s[i] = y; s[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ float sigmoid_clamp(float x)
+{
+    // clamp(sigmoid(x), 1e-4, 1-1e-4); expf (not __expf) keeps full fp32 accuracy
+    float y = 1.0f / (1.0f + expf(-x));
+    return fminf(fmaxf(y, 1e-4f), 1.0f - 1e-4f);
+}
+
+constexpr int NMS_THREADS = 256;
+constexpr int NMS_MAXK = 1024;
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__restrict__ heat, int C, int H, int W, int K,
+                                                               int flags, float *__restrict__ o_score,
+                                                               int64_t *__restrict__ o_ind, float *__restrict__ o_y,
+                                                               float *__restrict__ o_x)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_key[];  // [HW] then candidates
+    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_sel[2];  // [0] = chosen bin, [1] = remaining need
+    __shared__ uint32_t s_cnt;
+    const int tid = threadIdx.x;
+    const int HW = H * W;
+    const float *map = heat + (size_t)blockIdx.x * HW;
+    u64 *s_cand = reinterpret_cast<u64 *>(s_key + ((HW + 1) & ~1));
+
+    // ---- sigmoid + 3x3 NMS -> order-preserving keys ----------------------------------------------
+    for (int i = tid; i < HW; i += NMS_THREADS) {
+        const int y = i / W, x = i - y * W;
+        const float v = map[i];
+        float m = v;
+        if (!(flags & 2))
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                m = fmaxf(m, map[yy * W + xx]);
+            }
+        }
+        float sv = v, sm = m;
+        if (flags & 1) { sv = sigmoid_clamp(v); sm = sigmoid_clamp(m); }
+        // heat * keep (keep in {0,1}); +0.0f folds -0 into +0 so equal values share one key
+        const float val = ((sm == sv) ? sv : sv * 0.0f) + 0.0f;
+        s_key[i] = fkey(val);
+    }
+    __syncthreads();
+
+    // ---- radix select: key of the K-th largest element ------------------------------------------
+    uint32_t prefix = 0, pmask = 0, need = (uint32_t)K;
+    for (int pass = 3; pass >= 0; --pass) {
+        s_hist[tid] = 0;
+        __syncthreads();
+        const int sh = pass * 8;
+        for (int i = tid; i < HW; i += NMS_THREADS) {
+            const uint32_t k = s_key[i];
+            if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        // inclusive suffix sum over bins (Hillis-Steele, 8 steps)
+        uint32_t v = s_hist[tid];
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t add = (tid + off < 256) ? s_hist[tid + off] : 0u;
+            __syncthreads();
+            v += add;
+            s_hist[tid] = v;
+            __syncthreads();
+        }
+        const uint32_t above = (tid + 1 < 256) ? s_hist[tid + 1] : 0u;  // elements in bins > tid
+        if (v >= need && above < need) { s_sel[0] = (uint32_t)tid; s_sel[1] = need - above; }
+        __syncthreads();
+        prefix |= s_sel[0] << sh;
+        pmask |= 0xffu << sh;
+        need = s_sel[1];
+        __syncthreads();
+    }
+    const uint32_t kth = prefix;            // exact key of the K-th largest
+    const uint32_t n_gt = (uint32_t)K - need;  // elements strictly greater; take `need` equal ones
+
+    // ---- compaction: all keys > kth (any order), then `need` keys == kth in index order ----------
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < HW; i += NMS_THREADS) {
+        const uint32_t k = s_key[i];
+        if (k > kth) {
+            const uint32_t pos = atomicAdd(&s_cnt, 1u);
+            s_cand[pos] = ((u64)k << 32) | (u64)(0xffffffffu - (uint32_t)i);
+        }
+    }
+    const int chunk = (HW + NMS_THREADS - 1) / NMS_THREADS;
+    const int lo = tid * chunk, hi = min(lo + chunk, HW);
+    uint32_t eq = 0;
+    for (int i = lo; i < hi; ++i) eq += (s_key[i] == kth);
+    s_hist[tid] = eq;
+    __syncthreads();
+    uint32_t incl = eq;  // inclusive prefix sum over threads
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t add = (tid >= off) ? s_hist[tid - off] : 0u;
+        __syncthreads();
+        incl += add;
+        s_hist[tid] = incl;
+        __syncthreads();
+    }
+    uint32_t rank = incl - eq;
+    for (int i = lo; i < hi && rank < need; ++i)
+        if (s_key[i] == kth) {
+            s_cand[n_gt + rank] = ((u64)kth << 32) | (u64)(0xffffffffu - (uint32_t)i);
+            ++rank;
+        }
+    int N = 1;
+    while (N < K) N <<= 1;
+    for (int i = K + tid; i < N; i += NMS_THREADS) s_cand[i] = 0ull;
+    __syncthreads();
+    bitonic_desc(s_cand, N, tid, NMS_THREADS);
+
+    for (int j = tid; j < K; j += NMS_THREADS) {
+        const u64 c = s_cand[j];
+        const uint32_t idx = 0xffffffffu - (uint32_t)(c & 0xffffffffull);
+        const size_t o = (size_t)blockIdx.x * K + j;
+        o_score[o] = fkey_inv((uint32_t)(c >> 32));
+        o_ind[o] = (int64_t)idx;
+        o_y[o] = (float)(int)(idx / (uint32_t)W);
+        o_x[o] = (float)(int)(idx % (uint32_t)W);
+    }
+}
+
+extern "C" int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K, int flags, float *scores,
+                            int64_t *inds, float *ys, float *xs, void *stream)
+{
+    if (!heat || !scores || !inds || !ys || !xs) H3D_FAIL(H3D_ERR_ARG, "nms_topk: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) H3D_FAIL(H3D_ERR_SHAPE, "nms_topk: bad shape");
+    const long HW = (long)H * W;
+    if (K <= 0 || K > HW) H3D_FAIL(H3D_ERR_SHAPE, "nms_topk: selected index k out of range (K=%d, H*W=%ld)", K, HW);
+    if (K > NMS_MAXK || HW > 36864)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "nms_topk: K=%d (max %d), H*W=%ld (max 36864)", K, NMS_MAXK, HW);
+    int N = 1;
+    while (N < K) N <<= 1;
+    const size_t lds = (size_t)((HW + 1) & ~1L) * 4 + (size_t)N * 8;
+    static thread_local size_t max_set = 0;
+    if (lds > 64 * 1024 && lds > max_set) {
+        if (hipFuncSetAttribute((const void *)nms_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            H3D_FAIL(H3D_ERR_LAUNCH, "nms_topk: cannot reserve %zu bytes of LDS", lds);
+        max_set = lds;
+    }
+    hipLaunchKernelGGL(nms_topk_kernel, dim3(B * C), dim3(NMS_THREADS), lds, (hipStream_t)stream, heat, C, H, W, K,
+                       flags, scores, inds, ys, xs);
+    H3D_CHECK_LAUNCH("nms_topk_kernel");
+    return H3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone _nms (decode.py:6-13) and _sigmoid (utils.py:8-10) for API completeness
+__global__ void nms_kernel(const float *__restrict__ heat, int H, int W, float *__restrict__ out, size_t total)
+{
+    const int HW = H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t mapi = i / HW;
+        const int p = (int)(i - mapi * HW);
+        const int y = p / W, x = p - y * W;
+        const float *map = heat + mapi * HW;
+        const float v = map[p];
+        float m = v;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                m = fmaxf(m, map[yy * W + xx]);
+            }
+        }
+        out[i] = (m == v) ? v : v * 0.0f;
+    }
+}
+
+extern "C" int h3d_nms(const float *heat, int B, int C, int H, int W, float *out, void *stream)
+{
+    if (!heat || !out) H3D_FAIL(H3D_ERR_ARG, "nms: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) H3D_FAIL(H3D_ERR_SHAPE, "nms: bad shape");
+    const size_t total = (size_t)B * C * H * W;
+    const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(nms_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, heat, H, W, out, total);
+    H3D_CHECK_LAUNCH("nms_kernel");
+    return H3D_OK;
+}
+
+__global__ void sigmoid_clamp_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = sigmoid_clamp(in[i]);
+}
+
+extern "C" int h3d_sigmoid_clamp(const float *in, float *out, size_t n, void *stream)
+{
+    if (!in || !out) H3D_FAIL(H3D_ERR_ARG, "sigmoid_clamp: null pointer");
+    if (n == 0) return H3D_OK;
+    const int grid = (int)((n + 255) / 256 > 16384 ? 16384 : (n + 255) / 256);
+    hipLaunchKernelGGL(sigmoid_clamp_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    H3D_CHECK_LAUNCH("sigmoid_clamp_kernel");
+    return H3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ scores, const int64_t *__restrict__ inds,
+                                                         const float *__restrict__ ys, const float *__restrict__ xs, int C,
+                                                         int K, int N, float *__restrict__ o_score, int64_t *__restrict__ o_ind,
+                                                         int32_t *__restrict__ o_cls, float *__restrict__ o_y,
+                                                         float *__restrict__ o_x)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 s_m[];
+    const int b = blockIdx.x, tid = threadIdx.x, CK = C * K;
+    const size_t base = (size_t)b * CK;
+    for (int i = tid; i < N; i += 256)
+        s_m[i] = (i < CK) ? (((u64)fkey(scores[base + i] + 0.0f) << 32) | (u64)(0xffffffffu - (uint32_t)i)) : 0ull;
+    __syncthreads();
+    bitonic_desc(s_m, N, tid, 256);
+    for (int j = tid; j < K; j += 256) {
+        const u64 c = s_m[j];
+        const uint32_t pos = 0xffffffffu - (uint32_t)(c & 0xffffffffull);
+        const size_t o = (size_t)b * K + j;
+        o_score[o] = scores[base + pos];
+        o_cls[o] = (int32_t)(pos / (uint32_t)K);
+        o_ind[o] = inds[base + pos];
+        o_y[o] = ys[base + pos];
+        o_x[o] = xs[base + pos];
+    }
+}
+
+extern "C" int h3d_topk_merge(const float *scores, const int64_t *inds, const float *ys, const float *xs, int B, int C,
+                              int K, float *o_score, int64_t *o_ind, int32_t *o_cls, float *o_y, float *o_x, void *stream)
+{
+    if (!scores || !inds || !ys || !xs || !o_score || !o_ind || !o_cls || !o_y || !o_x)
+        H3D_FAIL(H3D_ERR_ARG, "topk_merge: null pointer");
+    if (B <= 0 || C <= 0 || K <= 0) H3D_FAIL(H3D_ERR_SHAPE, "topk_merge: bad shape");
+    if ((long)C * K > 8192) H3D_FAIL(H3D_ERR_UNSUPPORTED, "topk_merge: C*K=%ld > 8192", (long)C * K);
+    int N = 1;
+    while (N < C * K) N <<= 1;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(256), (size_t)N * 8, (hipStream_t)stream, scores, inds, ys, xs, C, K,
+                       N, o_score, o_ind, o_cls, o_y, o_x);
+    H3D_CHECK_LAUNCH("topk_merge_kernel");
+    return H3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_feat_kernel(const float *__restrict__ feat, const int64_t *__restrict__ ind, int C, int HW, int N,
+                                   long sb, long sc, long sp, float *__restrict__ out, size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i % C;
+        const size_t bn = i / C;
+        const size_t b = bn / N;
+        const int64_t p = ind[bn];
+        out[i] = (p >= 0 && p < HW) ? feat[b * sb + c * sc + p * sp] : 0.f;
+    }
+}
+
+extern "C" int h3d_gather_feat(const float *feat, const int64_t *ind, int B, int C, int HW, int N, int channels_last,
+                               float *out, void *stream)
+{
+    if (!feat || !ind || !out) H3D_FAIL(H3D_ERR_ARG, "gather_feat: null pointer");
+    if (B <= 0 || C <= 0 || HW <= 0 || N <= 0) H3D_FAIL(H3D_ERR_SHAPE, "gather_feat: bad shape");
+    const size_t total = (size_t)B * N * C;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    const long sb = (long)C * HW, sc = channels_last ? 1 : HW, sp = channels_last ? C : 1;
+    hipLaunchKernelGGL(gather_feat_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, feat, ind, C, HW, N, sb, sc, sp,
+                       out, total);
+    H3D_CHECK_LAUNCH("gather_feat_kernel");
+    return H3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One workgroup per image.  LDS: regressed keypoints [K][2J], boxes [K][4], joint candidates 3x[K].
+__global__ __launch_bounds__(256) void pose_assemble_kernel(
+    const float *__restrict__ c_score, const int64_t *__restrict__ c_ind, const int32_t *__restrict__ c_cls,
+    const float *__restrict__ c_y, const float *__restrict__ c_x, const float *__restrict__ hp_score,
+    const int64_t *__restrict__ hp_ind, const float *__restrict__ hp_y, const float *__restrict__ hp_x,
+    const float *__restrict__ wh, const float *__restrict__ hps, const float *__restrict__ reg,
+    const float *__restrict__ hp_offset, int J, int HW, int K, float *__restrict__ dets)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_f[];
+    float *s_kp = s_f;               // [K][2J]
+    float *s_box = s_kp + K * 2 * J; // [K][4]
+    float *s_hx = s_box + K * 4;     // [K]
+    float *s_hy = s_hx + K;
+    float *s_hs = s_hy + K;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int D = 5 + 2 * J + 1;
+    const float thresh = 0.1f;
+
+    for (int k = tid; k < K; k += 256) {
+        const size_t o = (size_t)b * K + k;
+        const int64_t ind = c_ind[o];
+        const float xs = c_x[o], ys = c_y[o];
+        for (int j = 0; j < J; ++j) {
+            s_kp[k * 2 * J + 2 * j] = hps[((size_t)b * 2 * J + 2 * j) * HW + ind] + xs;
+            s_kp[k * 2 * J + 2 * j + 1] = hps[((size_t)b * 2 * J + 2 * j + 1) * HW + ind] + ys;
+        }
+        float cx, cy;
+        if (reg) { cx = xs + reg[((size_t)b * 2) * HW + ind]; cy = ys + reg[((size_t)b * 2 + 1) * HW + ind]; }
+        else { cx = xs + 0.5f; cy = ys + 0.5f; }
+        const float w = wh[((size_t)b * 2) * HW + ind], hgt = wh[((size_t)b * 2 + 1) * HW + ind];
+        const float l = cx - w / 2.f, t = cy - hgt / 2.f, r = cx + w / 2.f, bt = cy + hgt / 2.f;
+        s_box[k * 4] = l; s_box[k * 4 + 1] = t; s_box[k * 4 + 2] = r; s_box[k * 4 + 3] = bt;
+        float *d = dets + o * D;
+        d[0] = l; d[1] = t; d[2] = r; d[3] = bt;
+        d[4] = c_score[o];
+        d[5 + 2 * J] = (float)c_cls[o];
+    }
+    __syncthreads();
+    if (!hp_score) {
+        for (int i = tid; i < K * 2 * J; i += 256) {
+            const int k = i / (2 * J), q = i - k * 2 * J;
+            dets[((size_t)b * K + k) * D + 5 + q] = s_kp[i];
+        }
+        return;
+    }
+    for (int j = 0; j < J; ++j) {
+        for (int c = tid; c < K; c += 256) {
+            const size_t o = ((size_t)b * J + j) * K + c;
+            float hs = hp_score[o], hx = hp_x[o], hy = hp_y[o];
+            if (hp_offset) {
+                const int64_t ind = hp_ind[o];
+                hx = hx + hp_offset[((size_t)b * 2) * HW + ind];
+                hy = hy + hp_offset[((size_t)b * 2 + 1) * HW + ind];
+            } else { hx = hx + 0.5f; hy = hy + 0.5f; }
+            const bool m = hs > thresh;
+            s_hs[c] = m ? hs : -1.0f;
+            s_hx[c] = m ? hx : -10000.0f;
+            s_hy[c] = m ? hy : -10000.0f;
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += 256) {
+            const float rx = s_kp[k * 2 * J + 2 * j], ry = s_kp[k * 2 * J + 2 * j + 1];
+            float best = 0.f;
+            int bi = -1;
+            for (int c = 0; c < K; ++c) {
+                const float dx = rx - s_hx[c], dy = ry - s_hy[c];
+                const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+                if (bi < 0 || d < best) { best = d; bi = c; }
+            }
+            const float sx = s_hx[bi], sy = s_hy[bi], ss = s_hs[bi];
+            const float l = s_box[k * 4], t = s_box[k * 4 + 1], r = s_box[k * 4 + 2], bt = s_box[k * 4 + 3];
+            const bool bad = (sx < l) || (sx > r) || (sy < t) || (sy > bt) || (ss < thresh) ||
+                             (best > __fmul_rn(fmaxf(bt - t, r - l), 0.3f));
+            float *d = dets + ((size_t)b * K + k) * D + 5 + 2 * j;
+            d[0] = bad ? rx : sx;
+            d[1] = bad ? ry : sy;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int h3d_multi_pose_assemble(const float *c_score, const int64_t *c_ind, const int32_t *c_cls, const float *c_y,
+                                       const float *c_x, const float *hp_score, const int64_t *hp_ind, const float *hp_y,
+                                       const float *hp_x, const float *wh, const float *hps, const float *reg,
+                                       const float *hp_offset, int B, int J, int H, int W, int K, float *dets, void *stream)
+{
+    if (!c_score || !c_ind || !c_cls || !c_y || !c_x || !wh || !hps || !dets)
+        H3D_FAIL(H3D_ERR_ARG, "multi_pose_assemble: null pointer");
+    if (hp_score && (!hp_ind || !hp_y || !hp_x)) H3D_FAIL(H3D_ERR_ARG, "multi_pose_assemble: partial joint top-k");
+    if (B <= 0 || J <= 0 || H <= 0 || W <= 0 || K <= 0) H3D_FAIL(H3D_ERR_SHAPE, "multi_pose_assemble: bad shape");
+    const size_t lds = ((size_t)K * 2 * J + (size_t)K * 4 + (size_t)K * 3) * sizeof(float);
+    if (lds > 64 * 1024) H3D_FAIL(H3D_ERR_UNSUPPORTED, "multi_pose_assemble: K*J too large (%d x %d)", K, J);
+    hipLaunchKernelGGL(pose_assemble_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, c_score, c_ind, c_cls, c_y, c_x,
+                       hp_score, hp_ind, hp_y, hp_x, wh, hps, reg, hp_offset, J, H * W, K, dets);
+    H3D_CHECK_LAUNCH("pose_assemble_kernel");
+    return H3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void ctdet_assemble_kernel(const float *__restrict__ c_score, const int64_t *__restrict__ c_ind,
+                                      const int32_t *__restrict__ c_cls, const float *__restrict__ c_y,
+                                      const float *__restrict__ c_x, const float *__restrict__ wh,
+                                      const float *__restrict__ reg, int C, int HW, int K, int cat_spec_wh, int total,
+                                      float *__restrict__ dets)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int b = o / K;
+    const int64_t ind = c_ind[o];
+    const float xs = c_x[o], ys = c_y[o];
+    float cx, cy;
+    if (reg) { cx = xs + reg[((size_t)b * 2) * HW + ind]; cy = ys + reg[((size_t)b * 2 + 1) * HW + ind]; }
+    else { cx = xs + 0.5f; cy = ys + 0.5f; }
+    const int cls = c_cls[o];
+    const int whc = cat_spec_wh ? 2 * C : 2;
+    const int w0 = cat_spec_wh ? 2 * cls : 0;
+    const float w = wh[((size_t)b * whc + w0) * HW + ind], hgt = wh[((size_t)b * whc + w0 + 1) * HW + ind];
+    float *d = dets + (size_t)o * 6;
+    d[0] = cx - w / 2.f; d[1] = cy - hgt / 2.f; d[2] = cx + w / 2.f; d[3] = cy + hgt / 2.f;
+    d[4] = c_score[o];
+    d[5] = (float)cls;
+}
+
+extern "C" int h3d_ctdet_assemble(const float *c_score, const int64_t *c_ind, const int32_t *c_cls, const float *c_y,
+                                  const float *c_x, const float *wh, const float *reg, int B, int C, int H, int W, int K,
+                                  int cat_spec_wh, float *dets, void *stream)
+{
+    if (!c_score || !c_ind || !c_cls || !c_y || !c_x || !wh || !dets) H3D_FAIL(H3D_ERR_ARG, "ctdet_assemble: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) H3D_FAIL(H3D_ERR_SHAPE, "ctdet_assemble: bad shape");
+    const int total = B * K;
+    hipLaunchKernelGGL(ctdet_assemble_kernel, dim3(cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream, c_score, c_ind,
+                       c_cls, c_y, c_x, wh, reg, C, H * W, K, cat_spec_wh, total, dets);
+    H3D_CHECK_LAUNCH("ctdet_assemble_kernel");
+    return H3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse crop affine with rot = 0 (utils/image.py:27-68 with inv=1): the three-point transform
+// reduces to  p_img = c + (p_out - [w/2, h/2]) * (s / w_out)  (s = scale[0] = the source width).
+__global__ void post_process_kernel(const float *__restrict__ dets, const float *__restrict__ c, const float *__restrict__ s,
+                                    int K, int J, int out_h, int out_w, int total, float *__restrict__ out)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int b = o / K;
+    const int D = 5 + 2 * J + 1, DO = 5 + 2 * J;
+    const float *d = dets + (size_t)o * D;
+    float *q = out + (size_t)o * DO;
+    const double sc = (double)s[b] / (double)out_w;
+    const double cx = c[b * 2], cy = c[b * 2 + 1];
+    const double hx = 0.5 * out_w, hy = 0.5 * out_h;
+    for (int i = 0; i < 2; ++i) {
+        q[2 * i] = (float)(cx + ((double)d[2 * i] - hx) * sc);
+        q[2 * i + 1] = (float)(cy + ((double)d[2 * i + 1] - hy) * sc);
+    }
+    q[4] = d[4];
+    for (int j = 0; j < J; ++j) {
+        q[5 + 2 * j] = (float)(cx + ((double)d[5 + 2 * j] - hx) * sc);
+        q[5 + 2 * j + 1] = (float)(cy + ((double)d[5 + 2 * j + 1] - hy) * sc);
+    }
+}
+
+extern "C" int h3d_multi_pose_post_process(const float *dets, const float *c, const float *s, int B, int K, int J,
+                                           int out_h, int out_w, float *out, void *stream)
+{
+    if (!dets || !c || !s || !out) H3D_FAIL(H3D_ERR_ARG, "post_process: null pointer");
+    if (B <= 0 || K <= 0 || J <= 0 || out_h <= 0 || out_w <= 0) H3D_FAIL(H3D_ERR_SHAPE, "post_process: bad shape");
+    const int total = B * K;
+    hipLaunchKernelGGL(post_process_kernel, dim3(cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream, dets, c, s, K, J,
+                       out_h, out_w, total, out);
+    H3D_CHECK_LAUNCH("post_process_kernel");
+    return H3D_OK;
+}

@@ -1,0 +1,111 @@
+"""Host mirror of the reference's models/DCNv2/dcn_v2.py (forward path): `dcn_v2_forward`
+(the `_ext` entry point, DCNv2/src/dcn_v2.h:9-39), `dcn_v2_conv`, `DCNv2`, `DCN` with the same
+constructor arguments and state_dict keys (weight, bias, conv_offset_mask.{weight,bias}).
+
+Backward (dcn_v2_backward) and PS-ROI pooling are out of scope:
+inference only -- calling with autograd enabled on tensors that require grad raises."""
+import math
+
+import torch
+from torch import nn
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+
+
+def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w,
+                   pad_h, pad_w, dilation_h, dilation_w, deformable_group):
+    """Positional twin of `_ext.dcn_v2_forward` (dcn_v2.py:25-31 call site). fp32 contiguous
+    NCHW CUDA tensors; returns a new [B,Cout,Ho,Wo] tensor."""
+    _lib.require_cuda(input, weight, bias, offset, mask)
+    for t in (input, weight, bias, offset, mask):
+        if t.dtype != torch.float32:
+            raise RuntimeError("dcn_v2_forward: expected float32 tensors (reference uses .data<float>())")
+    input, weight, bias, offset, mask = [t.contiguous() for t in (input, weight, bias, offset, mask)]
+    B, C, H, W = input.shape
+    Cout, Ck, kh_, kw_ = weight.shape
+    if kh_ != kernel_h or kw_ != kernel_w:
+        raise RuntimeError("Input shape and kernel shape wont match: (%d x %d vs %d x %d)."
+                           % (kernel_h, kernel_w, kh_, kw_))
+    if C != Ck:
+        raise RuntimeError("Input shape and kernel channels wont match: (%d vs %d)." % (C, Ck))
+    Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) // stride_h + 1
+    Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) // stride_w + 1
+    if tuple(offset.shape) != (B, 2 * deformable_group * kernel_h * kernel_w, Ho, Wo):
+        raise RuntimeError("offset shape %s does not match [B, 2*dg*kh*kw, Ho, Wo] = %s"
+                           % (tuple(offset.shape), (B, 2 * deformable_group * kernel_h * kernel_w, Ho, Wo)))
+    if tuple(mask.shape) != (B, deformable_group * kernel_h * kernel_w, Ho, Wo):
+        raise RuntimeError("mask shape %s does not match [B, dg*kh*kw, Ho, Wo]" % (tuple(mask.shape),))
+    if bias.numel() != Cout:
+        raise RuntimeError("bias has %d elements, expected %d" % (bias.numel(), Cout))
+    out = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = _lib.lib().h3d_dcn_v2_forward(
+            _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(out),
+            B, C, H, W, Cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+            deformable_group, _lib.stream_ptr())
+    _lib.check(rc, "dcn_v2_forward")
+    return out
+
+
+def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+    """`_DCNv2.apply` argument order (dcn_v2.py:18-33), forward only."""
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (input, offset, mask, weight, bias)):
+        raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): "
+                           "call under torch.no_grad()")
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    kh, kw = weight.shape[2:4]
+    return dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_groups)
+
+
+class DCNv2(nn.Module):
+    """Parameters + forward(input, offset, mask) (dcn_v2.py:57-94)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = _pair(kernel_size), _pair(stride)
+        self.padding, self.dilation = _pair(padding), _pair(dilation)
+        self.deformable_groups = deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1.0 / math.sqrt(self.in_channels * self.kernel_size[0] * self.kernel_size[1])
+        with torch.no_grad():
+            self.weight.uniform_(-stdv, stdv)
+            self.bias.zero_()
+
+    def forward(self, input, offset, mask):
+        k = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
+        assert 2 * k == offset.shape[1]
+        assert k == mask.shape[1]
+        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.deformable_groups)
+
+
+class DCN(DCNv2):
+    """DCNv2 + its own offset/mask conv (dcn_v2.py:97-128): zero-initialised
+    `conv_offset_mask`, offset = first 2/3 of its output, mask = sigmoid(last 1/3)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, deformable_groups)
+        ch = self.deformable_groups * 3 * self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset_mask = nn.Conv2d(self.in_channels, ch, kernel_size=self.kernel_size, stride=self.stride,
+                                          padding=self.padding, bias=True)
+        with torch.no_grad():
+            self.conv_offset_mask.weight.zero_()
+            self.conv_offset_mask.bias.zero_()
+
+    def forward(self, input):
+        # the small offset/mask conv of a stand-alone DCN goes through torch here; inside the
+        # DLA-34 engine (engine.py) it is the HIP conv kernel writing NHWC fp32 offsets directly
+        out = self.conv_offset_mask(input)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        mask = torch.sigmoid(mask)
+        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                           self.dilation, self.deformable_groups)

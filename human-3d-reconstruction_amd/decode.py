@@ -1,0 +1,112 @@
+"""Host mirror of the reference's models/decode.py: same function names, arguments and return
+values; all arithmetic runs in csrc/decode.hip.
+
+Tie rule: where the reference's torch.topk leaves the order of equal scores unspecified, this
+implementation orders them lowest flat index first ('Top-k ties')."""
+import torch
+
+from . import _lib
+from .utils import _f32c
+
+NMS_SIGMOID, NMS_SKIP = 1, 2
+
+
+def _nms(heat, kernel=3):
+    """heat * (max_pool2d(heat, 3, 1, 1) == heat)  (reference decode.py:6-13)."""
+    if kernel != 3:
+        raise RuntimeError("_nms: only the 3x3 kernel of the reference call sites is implemented")
+    heat = _f32c(heat)
+    B, C, H, W = heat.shape
+    out = torch.empty_like(heat)
+    _lib.check(_lib.lib().h3d_nms(_lib.ptr(heat), B, C, H, W, _lib.ptr(out), _lib.stream_ptr()), "_nms")
+    return out
+
+
+def _map_topk(scores, K, flags):
+    scores = _f32c(scores)
+    B, C, H, W = scores.shape
+    dev = scores.device
+    s = torch.empty(B, C, K, dtype=torch.float32, device=dev)
+    i = torch.empty(B, C, K, dtype=torch.int64, device=dev)
+    y = torch.empty(B, C, K, dtype=torch.float32, device=dev)
+    x = torch.empty(B, C, K, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().h3d_nms_topk(_lib.ptr(scores), B, C, H, W, K, flags, _lib.ptr(s), _lib.ptr(i),
+                                       _lib.ptr(y), _lib.ptr(x), _lib.stream_ptr()), "topk")
+    return s, i, y, x
+
+
+def _merge(s, i, y, x, K):
+    B, C, _ = s.shape
+    dev = s.device
+    o_s = torch.empty(B, K, dtype=torch.float32, device=dev)
+    o_i = torch.empty(B, K, dtype=torch.int64, device=dev)
+    o_c = torch.empty(B, K, dtype=torch.int32, device=dev)
+    o_y = torch.empty(B, K, dtype=torch.float32, device=dev)
+    o_x = torch.empty(B, K, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().h3d_topk_merge(_lib.ptr(s), _lib.ptr(i), _lib.ptr(y), _lib.ptr(x), B, C, K,
+                                         _lib.ptr(o_s), _lib.ptr(o_i), _lib.ptr(o_c), _lib.ptr(o_y),
+                                         _lib.ptr(o_x), _lib.stream_ptr()), "_topk")
+    return o_s, o_i, o_c, o_y, o_x
+
+
+def _topk_channel(scores, K=40):
+    """Per-channel top-K of an (already NMS-ed) score map (reference decode.py:15-24):
+    returns (topk_scores, topk_inds, topk_ys, topk_xs), each [B,C,K]."""
+    return _map_topk(scores, K, NMS_SKIP)
+
+
+def _topk(scores, K=40):
+    """Two-stage top-K (reference decode.py:26-41): returns
+    (topk_score [B,K], topk_inds [B,K] int64, topk_clses [B,K] int32, topk_ys, topk_xs)."""
+    return _merge(*_map_topk(scores, K, NMS_SKIP), K)
+
+
+def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100):
+    """reference decode.py:44-75 -> detections [B,K,6]."""
+    heat, wh = _f32c(heat), _f32c(wh)
+    reg = None if reg is None else _f32c(reg)
+    B, C, H, W = heat.shape
+    s, i, c, y, x = _merge(*_map_topk(heat, K, 0), K)
+    dets = torch.empty(B, K, 6, dtype=torch.float32, device=heat.device)
+    _lib.check(_lib.lib().h3d_ctdet_assemble(_lib.ptr(s), _lib.ptr(i), _lib.ptr(c), _lib.ptr(y), _lib.ptr(x),
+                                             _lib.ptr(wh), _lib.ptr(reg), B, C, H, W, K, int(bool(cat_spec_wh)),
+                                             _lib.ptr(dets), _lib.stream_ptr()), "ctdet_decode")
+    return dets
+
+
+def _multi_pose(heat, wh, kps, reg, hm_hp, hp_offset, K, logits, return_aux=False):
+    heat, wh, kps = _f32c(heat), _f32c(wh), _f32c(kps)
+    reg = None if reg is None else _f32c(reg)
+    hm_hp = None if hm_hp is None else _f32c(hm_hp)
+    hp_offset = None if hp_offset is None else _f32c(hp_offset)
+    B, C, H, W = heat.shape
+    J = kps.shape[1] // 2
+    flags = NMS_SIGMOID if logits else 0
+    s, i, c, y, x = _merge(*_map_topk(heat, K, flags), K)
+    if hm_hp is not None:
+        hs, hi, hy, hx = _map_topk(hm_hp, K, flags)
+    else:
+        hs = hi = hy = hx = None
+        hp_offset = None
+    dets = torch.empty(B, K, 5 + 2 * J + 1, dtype=torch.float32, device=heat.device)
+    _lib.check(_lib.lib().h3d_multi_pose_assemble(
+        _lib.ptr(s), _lib.ptr(i), _lib.ptr(c), _lib.ptr(y), _lib.ptr(x),
+        _lib.ptr(hs), _lib.ptr(hi), _lib.ptr(hy), _lib.ptr(hx),
+        _lib.ptr(wh), _lib.ptr(kps), _lib.ptr(reg), _lib.ptr(hp_offset),
+        B, J, H, W, K, _lib.ptr(dets), _lib.stream_ptr()), "multi_pose_decode")
+    if return_aux:
+        return dets, {"scores": s, "inds": i, "clses": c, "ys": y, "xs": x, "hm_score": hs, "hm_inds": hi}
+    return dets
+
+
+def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100):
+    """reference decode.py:77-163: `heat`/`hm_hp` are post-`_sigmoid` maps -> detections
+    [B,K,40] = [bbox(4), score, 17x(x,y), class]."""
+    return _multi_pose(heat, wh, kps, reg, hm_hp, hp_offset, K, logits=False)
+
+
+def multi_pose_decode_logits(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100, return_aux=False):
+    """Fused form used by the detector: `heat`/`hm_hp` are the raw head outputs; the in-place
+    `_sigmoid` the reference's loss module applies before decode (trains/trainer.py:93,127) is
+    folded into the NMS kernel."""
+    return _multi_pose(heat, wh, kps, reg, hm_hp, hp_offset, K, logits=True, return_aux=return_aux)

@@ -1,0 +1,130 @@
+"""multi_pose detector: the inference call order of the reference's
+`HMRTrainer.run_epoch('val')` -> `save_result` (trains/trainer.py:253-261, 456-469), i.e.
+
+    output = model(images)[0]
+    output['hm'], output['hm_hp'] = _sigmoid(...)           (loss module side effect, :93,:127)
+    dets = multi_pose_decode(hm, wh, hps, reg, hm_hp, hp_offset, K)          [B,K,40]
+    dets_out = multi_pose_post_process(dets, c, s, out_h, out_w)             (optional)
+
+plus the north_star's SMPL stage: per-detection pose/shape read from two extra heads at the
+detection centres -> 6890-vertex LBS mesh.  One process per GPU; `gather_detections` is the
+single RCCL collective of the sharded path.
+"""
+import torch
+
+from . import _lib, decode, smpl as _smpl
+from .model import dla_net
+from .utils import _transpose_and_gather_feat
+
+MULTI_POSE_HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}   # opts.py:248-258
+SMPL_HEADS = {"pose": 72, "shape": 10}
+
+
+class Opt:
+    """The option names the path consumes (reference opts.py; defaults of the multi_pose task)."""
+
+    def __init__(self, **kw):
+        self.task = "multi_pose"
+        self.arch = "dla_34"
+        self.head_conv = 256
+        self.down_ratio = 4
+        self.K = 100
+        self.not_use_dcn = False
+        self.input_h = self.input_w = 512
+        self.reg_offset = True
+        self.hm_hp = True
+        self.reg_hp_offset = True
+        self.smpl = False             # north_star extension: pose/shape heads + LBS
+        self.smpl_people = None       # meshes per image (None = K)
+        self.dtype = "bf16"
+        for k, v in kw.items():
+            setattr(self, k, v)
+        self.output_h, self.output_w = self.input_h // self.down_ratio, self.input_w // self.down_ratio
+        heads = {"hm": 1, "wh": 2, "hps": 34}
+        if self.reg_offset:
+            heads["reg"] = 2
+        if self.hm_hp:
+            heads["hm_hp"] = 17
+        if self.reg_hp_offset:
+            heads["hp_offset"] = 2
+        if self.smpl:
+            heads.update(SMPL_HEADS)
+        self.heads = heads
+
+
+class MultiPoseDetector:
+    def __init__(self, opt, state_dict=None, smpl_model=None, device="cuda"):
+        if opt.task != "multi_pose":
+            raise ValueError("task not defined!")          # trains/trainer.py:472
+        self.opt = opt
+        self.device = torch.device(device)
+        self.model = dla_net(opt.heads, 34, opt.head_conv, opt.down_ratio, opt.not_use_dcn, dtype=opt.dtype)
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict, strict=True)
+        self.model.to(self.device).eval()
+        self.smpl_model = smpl_model
+        if opt.smpl and smpl_model is None:
+            self.smpl_model = _smpl.SMPLModel.synthetic()
+
+    @torch.no_grad()
+    def run(self, images, meta=None):
+        """images [B,3,H,W] fp32 on the device -> dict(dets [B,K,40], inds [B,K], optional
+        verts [B,N,6890,3] / joints, optional results [B,K,39] in image px when meta={'c','s'})."""
+        opt = self.opt
+        out = self.model(images)[0]
+        dets, aux = decode.multi_pose_decode_logits(
+            out["hm"], out["wh"], out["hps"], reg=out.get("reg") if opt.reg_offset else None,
+            hm_hp=out.get("hm_hp") if opt.hm_hp else None,
+            hp_offset=out.get("hp_offset") if opt.reg_hp_offset else None, K=opt.K, return_aux=True)
+        res = {"dets": dets, "inds": aux["inds"], "heads": out}
+        if opt.smpl:
+            n = opt.smpl_people or opt.K
+            inds = aux["inds"][:, :n].contiguous()
+            B = inds.shape[0]
+            thetas = _transpose_and_gather_feat(out["pose"], inds).view(B * n, 72)
+            betas = _transpose_and_gather_feat(out["shape"], inds).view(B * n, 10)
+            verts, joints = _smpl.lbs(self.smpl_model, betas, thetas, return_joints=True)
+            res["verts"] = verts.view(B, n, -1, 3)
+            res["joints"] = joints.view(B, n, 24, 3)
+        if meta is not None:
+            res["results"] = multi_pose_post_process(dets, meta["c"], meta["s"], out["hm"].shape[2],
+                                                     out["hm"].shape[3])
+        return res
+
+
+def multi_pose_post_process(dets, c, s, h, w):
+    """reference utils/post_process.py:41-52 on the device: dets [B,K,40], c [B,2], s [B] ->
+    [B,K,39] (bbox, score, 17 keypoints in original-image pixels)."""
+    _lib.require_cuda(dets)
+    dets = dets.contiguous().float()
+    B, K, D = dets.shape
+    J = (D - 6) // 2
+    c = torch.as_tensor(c, dtype=torch.float32, device=dets.device).contiguous().view(B, 2)
+    s = torch.as_tensor(s, dtype=torch.float32, device=dets.device).contiguous().view(-1)
+    if s.numel() == 2 * B:                                  # per-axis scale: the reference uses scale[0]
+        s = s.view(B, 2)[:, 0].contiguous()
+    out = torch.empty(B, K, 5 + 2 * J, dtype=torch.float32, device=dets.device)
+    _lib.check(_lib.lib().h3d_multi_pose_post_process(_lib.ptr(dets), _lib.ptr(c), _lib.ptr(s), B, K, J, int(h), int(w),
+                                                      _lib.ptr(out), _lib.stream_ptr()), "multi_pose_post_process")
+    return out
+
+
+def gather_detections(dets, group=None):
+    """All ranks' [B_local,K,40] -> [world*B_local,K,40] with ONE all-gather (RCCL over xGMI when
+    the backend is nccl; gloo in the CPU tests).  Nothing else crosses ranks: images are
+    independent, weights are replicated (the reference's DataParallel scatter, trainer.py:176)."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dets
+    world = dist.get_world_size(group)
+    out = torch.empty((world * dets.shape[0],) + tuple(dets.shape[1:]), dtype=dets.dtype, device=dets.device)
+    dist.all_gather_into_tensor(out, dets.contiguous(), group=group)
+    return out
+
+
+def shard_batch(n_images, rank, world):
+    """Contiguous image range of `rank` (B/world contiguous images per rank;
+    remainders go to the lowest ranks)."""
+    base, rem = divmod(n_images, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

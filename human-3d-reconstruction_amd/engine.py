@@ -1,0 +1,315 @@
+"""Launch-plan builder and executor for the DLA-34 (+DCNv2) multi_pose network.
+
+Host-side counterpart of the reference's `DLASeg.forward` (models/model.py:475-489): instead of
+walking nn.Modules per call, the network is lowered ONCE per (batch, height, width, dtype) into
+an array of `h3d_op` descriptors (include/h3d.h) over pre-allocated NHWC buffers and pre-packed
+weights; a forward is a single `h3d_run_ops` call on the current stream.
+
+Lowering decisions (DESIGN.md 'Data layout'):
+  * activations NHWC (channels-last) bf16 (throughput) or fp32 (parity mode);
+  * eval-mode BatchNorm folded into the preceding conv / DCN weights and bias;
+  * Root's torch.cat (model.py:160) is free: producers write into channel slices of one buffer;
+  * residual add + ReLU are conv epilogues; IDAUp's depthwise deconv + skip add is one kernel;
+  * conv_offset_mask (dcn_v2.py:119-122) writes NHWC fp32 offsets/mask-logits consumed in place
+    by the DCN kernel (no chunk/cat/sigmoid passes);
+  * the `project` conv of the two-level trees (level3/level4) is dead in the reference
+    (model.py:212 recomputes the residual inside tree1) and is not lowered;
+  * head outputs are written directly as contiguous NCHW fp32, the reference's head layout.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, arch
+from ._lib import H3dOp
+
+_TORCH_DT = {"bf16": torch.bfloat16, "f32": torch.float32}
+_H3D_DT = {"bf16": _lib.H3D_BF16, "f32": _lib.H3D_F32}
+
+
+def _t(v):
+    return v.detach().float().cpu() if torch.is_tensor(v) else torch.from_numpy(np.asarray(v)).float()
+
+
+class View:
+    """A [B,H,W,C] tensor living at channel offset `coff` of an NHWC buffer of channel stride `cs`."""
+    __slots__ = ("buf", "H", "W", "C", "cs", "coff", "es")
+
+    def __init__(self, buf, H, W, C, cs, coff, es):
+        self.buf, self.H, self.W, self.C, self.cs, self.coff, self.es = buf, H, W, C, cs, coff, es
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.coff * self.es
+
+    def slice(self, c0, c):
+        assert c0 + c <= self.C
+        return View(self.buf, self.H, self.W, c, self.cs, self.coff + c0, self.es)
+
+
+class PackedWeights:
+    """BN-folded, re-laid-out weights on the device (built once per state_dict/dtype)."""
+
+    def __init__(self, state_dict, heads, use_dcn, dtype, device, head_conv=256):
+        self.heads, self.use_dcn, self.dtype, self.device = dict(heads), use_dcn, dtype, device
+        self.head_conv = head_conv
+        self.sd = {k: _t(v) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+        missing = [k for k in arch.state_dict_shapes(heads, use_dcn, head_conv)
+                   if not k.endswith("num_batches_tracked") and k not in self.sd]
+        if missing:
+            raise KeyError("state_dict is missing %d keys, e.g. %s" % (len(missing), missing[:3]))
+        self.t = {}
+
+    def _fold(self, w, b, bn):
+        """conv(+bias) followed by eval BatchNorm `bn` -> (w', b')."""
+        if b is None:
+            b = torch.zeros(w.shape[0])
+        if bn is None:
+            return w, b
+        sd = self.sd
+        scale = sd[bn + ".weight"].double() / torch.sqrt(sd[bn + ".running_var"].double() + arch.BN_EPS)
+        w2 = (w.double() * scale.view(-1, 1, 1, 1)).float()
+        b2 = ((b.double() - sd[bn + ".running_mean"].double()) * scale + sd[bn + ".bias"].double()).float()
+        return w2, b2
+
+    def conv(self, wkey, bkey=None, bn=None, pad_cout_to=None):
+        """-> (packed weights [rows][kh*kw][Cin], bias fp32 [rows], Cout, Cin, k)."""
+        key = ("conv", wkey, bn, pad_cout_to)
+        if key not in self.t:
+            w, b = self._fold(self.sd[wkey], self.sd[bkey] if bkey else None, bn)
+            co, ci, kh, kw = w.shape
+            cout = pad_cout_to or co
+            rows = ((cout + 127) // 128) * 128
+            wp = torch.zeros(rows, kh * kw, ci)
+            wp[:co] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+            bp = torch.zeros(rows)
+            bp[:co] = b
+            self.t[key] = (wp.to(_TORCH_DT[self.dtype]).contiguous().to(self.device),
+                           bp.contiguous().to(self.device), cout, ci, kh, rows)
+        return self.t[key]
+
+    def stem(self):
+        key = ("stem",)
+        if key not in self.t:
+            w, b = self._fold(self.sd["base.base_layer.0.weight"], None, "base.base_layer.1")
+            self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
+        return self.t[key]
+
+    def up(self, wkey):
+        key = ("up", wkey)
+        if key not in self.t:
+            w = self.sd[wkey]                               # [C,1,k,k]
+            c, _, k, _ = w.shape
+            self.t[key] = (w.reshape(c, k * k).t().contiguous().to(self.device), k)   # [k*k][C] fp32
+        return self.t[key]
+
+
+class Plan:
+    """Op array + the buffers it points into, for one (B,H,W)."""
+
+    def __init__(self, pw, B, H, W):
+        if H % 32 or W % 32:
+            raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
+                               "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
+        self.pw, self.B, self.H, self.W = pw, B, H, W
+        self.dtype = pw.dtype
+        self.es = 2 if pw.dtype == "bf16" else 4
+        self.ops = []
+        self.keep = []          # tensors the ops point into
+        self.images = torch.empty(B, 3, H, W, dtype=torch.float32, device=pw.device)
+        self.outputs = {}
+        self._lower()
+        self.op_array = (H3dOp * len(self.ops))(*self.ops)
+
+    # -- buffer / op helpers --------------------------------------------------------------------
+    def _alloc(self, H, W, C, dtype=None):
+        td = _TORCH_DT[self.dtype] if dtype is None else dtype
+        buf = torch.empty(self.B, H, W, C, dtype=td, device=self.pw.device)
+        self.keep.append(buf)
+        return View(buf, H, W, C, C, 0, buf.element_size())
+
+    def _op(self, kind, **kw):
+        op = H3dOp()
+        op.kind, op.dtype, op.B = kind, _H3D_DT[self.dtype], self.B
+        for k, v in kw.items():
+            setattr(op, k, v)
+        self.ops.append(op)
+
+    def conv(self, x, wkey, out=None, bkey=None, bn=None, stride=1, relu=True, res=None, out_mode=_lib.OUT_NHWC,
+             pad_cout_to=None, out_tensor=None):
+        wp, bp, cout, cin, k, rows = self.pw.conv(wkey, bkey, bn, pad_cout_to)
+        assert cin == x.C, (wkey, cin, x.C)
+        Ho = (x.H + 2 * (k // 2) - k) // stride + 1
+        Wo = (x.W + 2 * (k // 2) - k) // stride + 1
+        if out_mode == _lib.OUT_NHWC:
+            if out is None:
+                out = self._alloc(Ho, Wo, cout)
+            assert (out.H, out.W, out.C) == (Ho, Wo, cout), (wkey, out.H, out.W, out.C, Ho, Wo, cout)
+            optr, ocs = out.ptr, out.cs
+        elif out_mode == _lib.OUT_NHWC_F32:
+            out = self._alloc(Ho, Wo, cout, torch.float32)
+            optr, ocs = out.ptr, out.cs
+        else:
+            optr, ocs = out_tensor.data_ptr(), cout
+        self._op(_lib.OP_CONV, in_=x.ptr, in2=res.ptr if res is not None else None, w=wp.data_ptr(),
+                 bias=bp.data_ptr(), out=optr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs,
+                 in2_cs=res.cs if res is not None else 0, Ho=Ho, Wo=Wo, Cout=cout, out_cs=ocs, ksize=k,
+                 stride=stride, relu=int(relu), out_mode=out_mode, wrows=rows)
+        return out
+
+    def dcn(self, x, om, wkey, bkey, bn, out=None):
+        wp, bp, cout, cin, k, rows = self.pw.conv(wkey, bkey, bn)
+        assert cin == x.C and k == 3
+        if out is None:
+            out = self._alloc(x.H, x.W, cout)
+        self._op(_lib.OP_DCN, in_=x.ptr, in2=om.ptr, w=wp.data_ptr(), bias=bp.data_ptr(), out=out.ptr, H=x.H,
+                 W=x.W, Cin=cin, in_cs=x.cs, in2_cs=om.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
+                 stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
+        return out
+
+    def pool(self, x, out=None):
+        if out is None:
+            out = self._alloc(x.H // 2, x.W // 2, x.C)
+        self._op(_lib.OP_MAXPOOL, in_=x.ptr, out=out.ptr, H=x.H, W=x.W, Cin=x.C, in_cs=x.cs, Ho=out.H, Wo=out.W,
+                 Cout=x.C, out_cs=out.cs, ksize=2, stride=2)
+        return out
+
+    def upadd(self, x, skip, wkey):
+        w, k = self.pw.up(wkey)
+        f = k // 2
+        out = self._alloc(x.H * f, x.W * f, x.C)
+        assert (skip.H, skip.W, skip.C) == (out.H, out.W, out.C), wkey
+        self._op(_lib.OP_UPADD, in_=x.ptr, in2=skip.ptr, w=w.data_ptr(), out=out.ptr, H=x.H, W=x.W, Cin=x.C,
+                 in_cs=x.cs, in2_cs=skip.cs, Ho=out.H, Wo=out.W, Cout=x.C, out_cs=out.cs, ksize=k, stride=f)
+        return out
+
+    # -- network ---------------------------------------------------------------------------------
+    def _block(self, x, p, stride, residual, out):
+        """BasicBlock (model.py:46-60): conv-bn-relu, conv-bn, +residual, relu."""
+        t = self.conv(x, p + ".conv1.weight", bn=p + ".bn1", stride=stride)
+        return self.conv(t, p + ".conv2.weight", bn=p + ".bn2", res=residual, out=out)
+
+    def _tree1(self, x, p, cin, cout, stride, level_root, out, cat=None):
+        """One-level Tree (model.py:209-218).  `cat` = pre-allocated Root input whose trailing
+        slices (children) the caller has filled; layout [x2 | x1 | children...]."""
+        Ho, Wo = x.H // stride, x.W // stride
+        if cat is None:
+            cat = self._alloc(Ho, Wo, 2 * cout + (cin if level_root else 0))
+        s_x2, s_x1 = cat.slice(0, cout), cat.slice(cout, cout)
+        if stride > 1:
+            bottom = self.pool(x, cat.slice(2 * cout, cin) if level_root else None)
+        else:
+            bottom = x
+        if cin != cout:
+            residual = self.conv(bottom, p + ".project.0.weight", bn=p + ".project.1", relu=False)
+        else:
+            residual = bottom
+        self._block(x, p + ".tree1", stride, residual, s_x1)
+        self._block(s_x1, p + ".tree2", 1, s_x1, s_x2)
+        return self.conv(cat, p + ".root.conv.weight", bn=p + ".root.bn", out=out)
+
+    def _tree2(self, x, p, cin, cout, out):
+        """Two-level Tree with level_root (level3/level4; model.py:209-222): Root input of the inner
+        tree2 = [x2 | x1 | bottom | tree1 output]."""
+        Ho, Wo = x.H // 2, x.W // 2
+        cat = self._alloc(Ho, Wo, 2 * cout + cin + cout)
+        self.pool(x, cat.slice(2 * cout, cin))
+        x1 = self._tree1(x, p + ".tree1", cin, cout, 2, False, cat.slice(2 * cout + cin, cout))
+        return self._tree1(x1, p + ".tree2", cout, cout, 1, False, out, cat=cat)
+
+    def _deform(self, x, p, out=None):
+        """DeformConv (model.py:346-362): DCN or plain 3x3 conv, then BN + ReLU (folded)."""
+        if self.pw.use_dcn:
+            om = self.conv(x, p + ".conv.conv_offset_mask.weight", bkey=p + ".conv.conv_offset_mask.bias",
+                           relu=False, out_mode=_lib.OUT_NHWC_F32, pad_cout_to=32)
+            return self.dcn(x, om, p + ".conv.weight", p + ".conv.bias", p + ".actf.0", out)
+        return self.conv(x, p + ".conv.weight", bkey=p + ".conv.bias", bn=p + ".actf.0", out=out)
+
+    def _ida(self, layers, p, startp, endp):
+        """IDAUp.forward (model.py:384-390) on the python list `layers` (mutated like the reference)."""
+        for i in range(startp + 1, endp):
+            k = i - startp
+            y = self._deform(layers[i], "%s.proj_%d" % (p, k))
+            y = self.upadd(y, layers[i - 1], "%s.up_%d.weight" % (p, k))
+            layers[i] = self._deform(y, "%s.node_%d" % (p, k))
+
+    def _lower(self):
+        B, H, W = self.B, self.H, self.W
+        C = arch.CHANNELS
+        w, b = self.pw.stem()
+        x = self._alloc(H, W, C[0])
+        self._op(_lib.OP_STEM, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=x.ptr, H=H, W=W,
+                 Cin=3, in_cs=3, Ho=H, Wo=W, Cout=C[0], out_cs=x.cs, ksize=7, stride=1, relu=1)
+        y0 = self.conv(x, "base.level0.0.weight", bn="base.level0.1")
+        y1 = self.conv(y0, "base.level1.0.weight", bn="base.level1.1", stride=2)
+        y2 = self._tree1(y1, "base.level2", C[1], C[2], 2, False, None)
+        y3 = self._tree2(y2, "base.level3", C[2], C[3], None)
+        y4 = self._tree2(y3, "base.level4", C[3], C[4], None)
+        y5 = self._tree1(y4, "base.level5", C[4], C[5], 2, True, None)
+        layers = [y0, y1, y2, y3, y4, y5]
+        # DLAUp.forward (model.py:409-415)
+        outs = [layers[-1]]
+        for i in range(3):
+            self._ida(layers, "dla_up.ida_%d" % i, len(layers) - i - 2, len(layers))
+            outs.insert(0, layers[-1])
+        # DLASeg.forward (model.py:480-483): ida_up over the three finest maps
+        ys = [outs[0], outs[1], outs[2]]
+        self._ida(ys, "ida_up", 0, 3)
+        feat = ys[-1]
+        self.feat = feat
+        Ho, Wo = feat.H, feat.W
+        for head, c in self.pw.heads.items():
+            o = torch.empty(B, c, Ho, Wo, dtype=torch.float32, device=self.pw.device)
+            self.outputs[head] = o
+            if self.pw.head_conv > 0:
+                t = self.conv(feat, head + ".0.weight", bkey=head + ".0.bias")
+                self.conv(t, head + ".2.weight", bkey=head + ".2.bias", relu=False,
+                          out_mode=_lib.OUT_NCHW_F32, out_tensor=o)
+            else:
+                self.conv(feat, head + ".weight", bkey=head + ".bias", relu=False,
+                          out_mode=_lib.OUT_NCHW_F32, out_tensor=o)
+
+    def run(self):
+        rc = _lib.lib().h3d_run_ops(self.op_array, len(self.ops), _lib.stream_ptr())
+        _lib.check(rc, "h3d_run_ops")
+        return self.outputs
+
+
+class DLAEngine:
+    """state_dict -> packed weights -> cached plans.  `forward(images)` returns the head dict
+    (fresh views of the plan's output buffers; they are overwritten by the next forward of the
+    same shape, like any static-graph runtime -- clone to keep)."""
+
+    def __init__(self, state_dict, heads, use_dcn, dtype="bf16", device="cuda", head_conv=256):
+        if dtype not in _TORCH_DT:
+            raise ValueError("dtype must be 'bf16' or 'f32'")
+        _lib.lib()                                     # fail loudly now if the HIP library is missing
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Not implemented on the CPU")
+        self.pw = PackedWeights(state_dict, heads, use_dcn, dtype, self.device, head_conv)
+        self.plans = {}
+
+    def plan(self, B, H, W):
+        key = (B, H, W)
+        if key not in self.plans:
+            with torch.cuda.device(self.device):
+                self.plans[key] = Plan(self.pw, B, H, W)
+        return self.plans[key]
+
+    def forward(self, images):
+        _lib.require_cuda(images)
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise RuntimeError("expected images [B,3,H,W], got %s" % (tuple(images.shape),))
+        B, _, H, W = images.shape
+        plan = self.plan(B, H, W)
+        with torch.cuda.device(self.device):
+            if images.dtype == torch.float32 and images.is_contiguous():
+                plan.op_array[0].in_ = images.data_ptr()       # read the caller's batch in place
+            else:
+                plan.images.copy_(images)
+                plan.op_array[0].in_ = plan.images.data_ptr()
+            return plan.run()
+
+    __call__ = forward

@@ -1,0 +1,132 @@
+"""Host mirror of the reference's model factory `dla_net` (models/model.py:501-516).
+
+`dla_net(heads, num_layers=34, head_conv=256, down_ratio=4, not_use_dcn=False)` returns an
+nn.Module whose parameters/buffers carry the reference's state_dict names (so
+`load_state_dict(torch.load(ckpt)['state_dict'])` works, trains/trainer.py:475-509) and whose
+`forward(x)` returns `[{head: [B,C,H/4,W/4] fp32}]` like `DLASeg.forward` (model.py:475-489).
+The forward itself is the HIP engine (engine.py): the module tree only holds parameters.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import arch
+from .engine import DLAEngine
+
+
+class _Holder(nn.Module):
+    """Anonymous node of the parameter tree (names come from the dotted state_dict keys)."""
+
+
+def _init_tensor(key, shape, heads):
+    """Default initialisation of the reference modules (nn.Conv2d/BatchNorm2d defaults,
+    DCNv2.reset_parameters dcn_v2.py:75-81, init_offset dcn_v2.py:114-116, fill_up_weights
+    model.py:334-343, head biases model.py:461-464)."""
+    leaf = key.rsplit(".", 1)[-1]
+    parts = key.split(".")
+    if leaf == "num_batches_tracked":
+        return torch.zeros((), dtype=torch.long)
+    if leaf == "running_mean":
+        return torch.zeros(shape)
+    if leaf == "running_var":
+        return torch.ones(shape)
+    if "conv_offset_mask" in parts:
+        return torch.zeros(shape)
+    if len(shape) == 1:
+        if leaf == "weight":
+            return torch.ones(shape)                       # BN gamma
+        if parts[0] in heads:                              # head conv biases
+            if "hm" in parts[0]:
+                if parts[-2] == "2" or len(parts) == 2:
+                    return torch.full(shape, -2.19)
+                return None                                # default conv bias init, set by caller
+            return torch.zeros(shape)                      # fill_fc_weights
+        if len(parts) >= 2 and parts[-2] == "conv" and "proj_" not in key and "node_" not in key:
+            return torch.zeros(shape)
+        return None if parts[-2] == "conv" else torch.zeros(shape)   # BN beta = 0; conv bias by caller
+    if len(shape) == 4 and parts[-2].startswith("up_"):
+        k = shape[2]
+        f = math.ceil(k / 2)
+        c = (2 * f - 1 - f % 2) / (2.0 * f)
+        w = torch.zeros(shape)
+        for i in range(k):
+            for j in range(k):
+                w[:, 0, i, j] = (1 - math.fabs(i / f - c)) * (1 - math.fabs(j / f - c))
+        return w
+    return None
+
+
+class DLASeg(nn.Module):
+    def __init__(self, heads, head_conv=256, use_dcn=True, dtype="bf16"):
+        super().__init__()
+        self.heads = dict(heads)
+        self.head_conv = head_conv
+        self.use_dcn = use_dcn
+        self.compute_dtype = dtype
+        self._engine = None
+        shapes = arch.state_dict_shapes(self.heads, use_dcn, head_conv)
+        pending_bias = {}
+        for key, shape in shapes.items():
+            t = _init_tensor(key, shape, self.heads)
+            parts = key.split(".")
+            if t is None and len(shape) == 4:
+                fan_in = shape[1] * shape[2] * shape[3]
+                bound = 1.0 / math.sqrt(fan_in)            # kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in))
+                t = torch.empty(shape).uniform_(-bound, bound)
+                pending_bias[".".join(parts[:-1])] = bound
+            elif t is None:
+                bound = pending_bias.get(".".join(parts[:-1]), 0.0)
+                if self.use_dcn and parts[-2] == "conv" and ("proj_" in key or "node_" in key):
+                    t = torch.zeros(shape)                 # DCNv2.reset_parameters: bias = 0
+                else:
+                    t = torch.empty(shape).uniform_(-bound, bound)
+            mod = self
+            for name in parts[:-1]:
+                if name not in mod._modules:
+                    mod.add_module(name, _Holder())
+                mod = mod._modules[name]
+            if parts[-1] in ("running_mean", "running_var", "num_batches_tracked"):
+                mod.register_buffer(parts[-1], t)
+            else:
+                mod.register_parameter(parts[-1], nn.Parameter(t))
+        self.eval()
+
+    # any change to the parameters invalidates the packed device weights
+    def load_state_dict(self, *a, **kw):
+        self._engine = None
+        return super().load_state_dict(*a, **kw)
+
+    def _apply(self, fn, *a, **kw):
+        self._engine = None
+        return super()._apply(fn, *a, **kw)
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = dtype
+        self._engine = None
+        return self
+
+    def engine(self, device):
+        if self._engine is None or self._engine.device != torch.device(device):
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._engine = DLAEngine(sd, self.heads, self.use_dcn, self.compute_dtype, device, self.head_conv)
+        return self._engine
+
+    def forward(self, x):
+        if self.training:
+            raise RuntimeError("h3d_amd.DLASeg is inference-only (BatchNorm is folded): call .eval()")
+        if not x.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        with torch.no_grad():
+            return [dict(self.engine(x.device)(x))]
+
+
+def dla_net(heads, num_layers=34, head_conv=256, down_ratio=4, not_use_dcn=False, dtype="bf16"):
+    """Same signature as the reference factory (model.py:501-516) plus `dtype`
+    ('bf16' throughput mode, 'f32' parity mode)."""
+    if num_layers != 34:
+        raise ValueError("only dla34 exists in the reference (model.py:309-315)")
+    if down_ratio != 4:
+        raise ValueError("down_ratio %d: the multi_pose path uses 4 (opts.py)" % down_ratio)
+    print("==> Use DeformConv." if not not_use_dcn else "==> Do not use DeformConv.")
+    return DLASeg(heads, head_conv=head_conv, use_dcn=not not_use_dcn, dtype=dtype)

@@ -65,3 +65,58 @@ class SMPLModel:
         return {"v_template": self.v_template, "shapedirs": self.shapedirs,
                 "posedirs": self.posedirs, "J_regressor": self.J_regressor,
                 "weights": self.weights, "parents": self.parents}
+
+
+# ----------------------------------------------------------------------------------------------
+# device side (csrc/smpl.hip through the C ABI)
+def _device_pack(model, device, nnz=None):
+    """Layouts the kernels want (include/h3d.h section 4): K-major blend shapes, the joint
+    regressor pre-contracted with template/shapedirs (float64 on the host), sparse LBS weights."""
+    import torch
+    V = model.v_template.shape[0]
+    W = model.weights
+    if nnz is None:
+        nnz = int(max(1, (W != 0).sum(1).max()))
+    order = np.argsort(-W, axis=1, kind="stable")[:, :nnz].astype(np.int32)
+    wsel = np.take_along_axis(W, order.astype(np.int64), axis=1).astype(np.float32)
+    Jr = model.J_regressor.astype(np.float64)
+    j_template = (Jr @ model.v_template.astype(np.float64)).astype(np.float32)                 # [24,3]
+    j_dirs = np.einsum("jv,vck->jck", Jr, model.shapedirs.astype(np.float64)).astype(np.float32)  # [24,3,10]
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return {
+        "V": V, "nnz": nnz,
+        "v_template": to(model.v_template.reshape(-1)),
+        "shapedirsT": to(model.shapedirs.reshape(V * 3, NUM_BETAS).T),
+        "posedirsT": to(model.posedirs.reshape(V * 3, NUM_POSE_FEAT).T),
+        "j_template": to(j_template.reshape(-1)),
+        "j_shapedirs": to(j_dirs.reshape(NUM_JOINTS * 3, NUM_BETAS)),
+        "parents": to(model.parents.astype(np.int32)),
+        "lbs_idx": to(order), "lbs_w": to(wsel),
+    }
+
+
+def lbs(model, betas, thetas, return_joints=False):
+    """betas [P,10], thetas [P,72] (CUDA fp32) -> vertices [P,V,3] (and posed joints [P,24,3])."""
+    import torch
+    from . import _lib
+    _lib.require_cuda(betas, thetas)
+    dev = betas.device
+    if model._dev is None or model._dev["v_template"].device != dev:
+        model._dev = _device_pack(model, dev)
+    d = model._dev
+    betas = betas.contiguous().float()
+    thetas = thetas.contiguous().float().view(betas.shape[0], 72)
+    P = betas.shape[0]
+    pf = torch.empty(P, NUM_POSE_FEAT, dtype=torch.float32, device=dev)
+    A = torch.empty(P, NUM_JOINTS, 12, dtype=torch.float32, device=dev)
+    joints = torch.empty(P, NUM_JOINTS, 3, dtype=torch.float32, device=dev)
+    verts = torch.empty(P, d["V"], 3, dtype=torch.float32, device=dev)
+    L, st = _lib.lib(), _lib.stream_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(L.h3d_smpl_pose(_lib.ptr(betas), _lib.ptr(thetas), _lib.ptr(d["j_template"]),
+                                   _lib.ptr(d["j_shapedirs"]), _lib.ptr(d["parents"]), P, _lib.ptr(pf),
+                                   _lib.ptr(A), _lib.ptr(joints), st), "smpl_pose")
+        _lib.check(L.h3d_smpl_verts(_lib.ptr(betas), _lib.ptr(pf), _lib.ptr(A), _lib.ptr(d["v_template"]),
+                                    _lib.ptr(d["shapedirsT"]), _lib.ptr(d["posedirsT"]), _lib.ptr(d["lbs_idx"]),
+                                    _lib.ptr(d["lbs_w"]), d["nnz"], P, d["V"], _lib.ptr(verts), st), "smpl_verts")
+    return (verts, joints) if return_joints else verts

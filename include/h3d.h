@@ -1,0 +1,190 @@
+/*
+ * h3d.h -- C ABI of libh3d_hip.so: the MI355X (gfx950) implementation of the multi_pose
+ * inference hot path of Aaron20127/human-3d-reconstruction.
+ *
+ * Plain C: raw DEVICE pointers, sizes, an explicit hipStream_t (passed as void*), int error
+ * codes.  No torch types.  Every entry point is asynchronous on `stream`, allocates nothing,
+ * keeps no global state and is re-entrant (the reference launches on the current stream and
+ * keeps a global THCState, DCNv2/src/cuda/dcn_v2_cuda.cu:12,108 -- we take the stream instead).
+ *
+ * Citations (file:line) are relative to /root/reference/src/lib/models/.
+ */
+#ifndef H3D_H
+#define H3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (the reference raises C++ exceptions via AT_ASSERTM / AT_ERROR,
+ *      DCNv2/src/cuda/dcn_v2_cuda.cu:61-85; kernel launch failures are only printf-ed there,
+ *      dcn_v2_im2col_cuda.cu:346-350 -- here they are returned) */
+#define H3D_OK 0
+#define H3D_ERR_SHAPE (-1)       /* "Input shape and kernel shape wont match" class of errors   */
+#define H3D_ERR_DTYPE (-2)       /* unsupported element type                                     */
+#define H3D_ERR_LAUNCH (-3)      /* hipGetLastError() != hipSuccess after a launch              */
+#define H3D_ERR_UNSUPPORTED (-4) /* valid request outside what the kernels cover (message set)  */
+#define H3D_ERR_ARG (-5)         /* null pointer / bad enum                                      */
+
+#define H3D_F32 0
+#define H3D_BF16 1
+
+/* Last error text of the calling thread (thread_local), for the Python shim's RuntimeError. */
+const char *h3d_last_error(void);
+/* ABI version of this header; the loader checks it. */
+int h3d_abi_version(void);
+#define H3D_ABI_VERSION 1
+
+/* =====================================================================================
+ * 1. Operator boundary: replaces pybind module `_ext` (DCNv2/src/vision.cpp:4-9), function
+ *    `dcn_v2_forward` (DCNv2/src/dcn_v2.h:9-39 -> dcn_v2_cuda_forward, dcn_v2_cuda.cu:43-173).
+ *    Same operands, same positional meaning; layouts as the reference: contiguous NCHW fp32.
+ *      input  [B,C,H,W]   weight [Cout,C,kh,kw]   bias [Cout]
+ *      offset [B,2*dg*kh*kw,Ho,Wo]  (channel 2t = dh, 2t+1 = dw of tap t, im2col.cu:170-171)
+ *      mask   [B,dg*kh*kw,Ho,Wo]
+ *      output [B,Cout,Ho,Wo], Ho=(H+2ph-(dh(kh-1)+1))/sh+1 (dcn_v2_cuda.cu:87-88)
+ *    The caller allocates `output` (the reference callee allocates it, dcn_v2_cuda.cu:92).
+ *    No scratch: the `columns`/`ones` buffers and pointer tables of the reference
+ *    (dcn_v2_cuda.cu:90-103) do not exist -- sampling feeds the contraction through LDS.
+ * ===================================================================================== */
+int h3d_dcn_v2_forward(const float *input, const float *weight, const float *bias,
+                       const float *offset, const float *mask, float *output,
+                       int B, int C, int H, int W, int Cout,
+                       int kernel_h, int kernel_w, int stride_h, int stride_w,
+                       int pad_h, int pad_w, int dilation_h, int dilation_w,
+                       int deformable_group, void *stream);
+
+/* =====================================================================================
+ * 2. Network ops (DLA-34 + DLAUp/IDAUp + heads, model.py:32-61,148-222,286-292,346-415,475-489)
+ *    on the internal layout: activations NHWC (channels-last) of element type f32 or bf16,
+ *    addressed as (pointer, channel stride) so a tensor can live inside a wider concat buffer
+ *    (Root's torch.cat, model.py:160, costs nothing).  Weights are pre-packed by the host:
+ *      conv   : [rows = Cout padded to 128][kh*kw][Cin] elements, BatchNorm folded in,
+ *               bias fp32[rows]
+ *    One descriptor per launch; h3d_run_ops walks an array of them (the forward "plan").
+ * ===================================================================================== */
+enum {
+    H3D_OP_STEM = 1,    /* base_layer 7x7 3->C0 conv+BN+ReLU from NCHW fp32 images (model.py:231-235) */
+    H3D_OP_CONV = 2,    /* kxk (k=1|3, stride 1|2, pad k/2) conv + bias [+residual] [+ReLU]            */
+    H3D_OP_DCN = 3,     /* modulated deformable 3x3 s1 p1 d1 dg1 conv + bias [+ReLU] (model.py:346-362) */
+    H3D_OP_MAXPOOL = 4, /* 2x2 stride-2 max pool (Tree.downsample, model.py:200-201)                   */
+    H3D_OP_UPADD = 5,   /* depthwise ConvTranspose2d(k=2f,s=f,p=f/2) + skip add (IDAUp, model.py:375-390) */
+    H3D_OP_COPY = 6     /* strided NHWC copy (y[i] = x[i].clone(), model.py:480-482)                   */
+};
+enum { H3D_OUT_NHWC = 0, H3D_OUT_NCHW_F32 = 1, H3D_OUT_NHWC_F32 = 2 };
+
+typedef struct h3d_op {
+    int32_t kind;       /* H3D_OP_*                                                        */
+    int32_t dtype;      /* H3D_F32 | H3D_BF16: activation + weight element type           */
+    const void *in;     /* input activations (STEM: NCHW fp32 images)                      */
+    const void *in2;    /* CONV: residual (or NULL); UPADD: skip tensor; DCN: offset/mask  */
+    const void *w;      /* packed weights (UPADD: fp32 [C][k*k])                           */
+    const float *bias;  /* fp32 [rows] (NULL for POOL/UPADD/COPY)                          */
+    void *out;
+    int32_t B, H, W;    /* input batch / height / width                                    */
+    int32_t Cin, in_cs; /* input channels, input channel stride (elements per pixel)       */
+    int32_t in2_cs;     /* channel stride of in2 (DCN: floats per pixel of offset/mask, >=27) */
+    int32_t Ho, Wo;     /* output height / width                                           */
+    int32_t Cout, out_cs;
+    int32_t ksize;      /* CONV: 1|3; STEM: 7; UPADD: 2f                                   */
+    int32_t stride;     /* CONV: 1|2; UPADD: f                                             */
+    int32_t relu;       /* 1: ReLU epilogue                                                */
+    int32_t out_mode;   /* H3D_OUT_*                                                       */
+    int32_t wrows;      /* rows of the packed weight buffer (>= Cout, multiple of 128)     */
+    int32_t reserved;
+} h3d_op;
+
+/* Launch ops[0..n) in order on `stream`.  Returns H3D_OK or the first error (index in the
+ * message). */
+int h3d_run_ops(const h3d_op *ops, int n, void *stream);
+
+/* Layout helpers (host interface keeps the reference's NCHW fp32 tensors at the boundary). */
+int h3d_nchw_f32_to_nhwc(const float *src, void *dst, int dtype, int B, int C, int H, int W,
+                         int dst_cs, void *stream);
+int h3d_nhwc_to_nchw_f32(const void *src, int dtype, float *dst, int B, int C, int H, int W,
+                         int src_cs, void *stream);
+
+/* =====================================================================================
+ * 3. Heat-map decode (decode.py, utils.py).  All tensors contiguous NCHW fp32 as the
+ *    reference's heads (model.py:485-489).  Index outputs are int64 like torch.topk's.
+ *    Tie rule: equal scores -> lowest flat index first (torch leaves it unspecified).
+ * ===================================================================================== */
+
+/* _sigmoid (utils.py:8-10) optionally, then _nms (decode.py:6-13) and the per-channel top-K of
+ * _topk_channel / stage 1 of _topk (decode.py:15-24, 26-33) in one pass per (b, c) map.
+ *   heat [B,C,H,W]; with H3D_NMS_SIGMOID heat holds logits and scores are
+ *   clamp(sigmoid(x), 1e-4, 1-1e-4).  Requires K <= min(H*W, 1024), H*W <= 36864.
+ *   out: scores [B,C,K] f32 (descending), inds [B,C,K] i64 (flat y*W+x), ys/xs [B,C,K] f32. */
+#define H3D_NMS_SIGMOID 1 /* heat holds logits: apply _sigmoid first            */
+#define H3D_NMS_SKIP 2    /* heat is already NMS-ed (plain _topk/_topk_channel) */
+int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K, int flags,
+                 float *scores, int64_t *inds, float *ys, float *xs, void *stream);
+
+/* stand-alone _nms (decode.py:6-13): out = heat * (maxpool3x3(heat) == heat), [B,C,H,W] */
+int h3d_nms(const float *heat, int B, int C, int H, int W, float *out, void *stream);
+/* stand-alone _sigmoid (utils.py:8-10): out = clamp(sigmoid(in), 1e-4, 1-1e-4); in == out allowed */
+int h3d_sigmoid_clamp(const float *in, float *out, size_t n, void *stream);
+
+/* Stage 2 of _topk (decode.py:34-39): top-K over the C*K stage-1 candidates of each image.
+ *   in : scores/inds/ys/xs [B,C,K];  out: score [B,K], ind [B,K] i64, cls [B,K] i32, y/x [B,K].
+ *   Requires C*K <= 8192. */
+int h3d_topk_merge(const float *scores, const int64_t *inds, const float *ys, const float *xs,
+                   int B, int C, int K, float *o_score, int64_t *o_ind, int32_t *o_cls,
+                   float *o_y, float *o_x, void *stream);
+
+/* _transpose_and_gather_feat (utils.py:23-27): feat [B,C,H,W] (channels_last=0), ind [B,N]
+ * -> out [B,N,C], without the NHWC transpose; _gather_feat (utils.py:12-21) itself is the
+ * channels_last=1 case: feat [B,HW,C]. */
+int h3d_gather_feat(const float *feat, const int64_t *ind, int B, int C, int HW, int N,
+                    int channels_last, float *out, void *stream);
+
+/* multi_pose_decode after the two top-k's (decode.py:86-161): gathers, boxes, keypoint
+ * matching, assembly of dets [B,K,5+2J+1].  reg / hp_* may be NULL exactly as in the
+ * reference signature (reg=None, hm_hp=None, hp_offset=None).
+ *   centre top-k  : c_score/c_ind/c_cls/c_y/c_x [B,K]
+ *   joint  top-k  : hp_score/hp_ind/hp_y/hp_x [B,J,K] (NULL when hm_hp is None)
+ *   wh [B,2,H,W], hps [B,2J,H,W], reg [B,2,H,W]|NULL, hp_offset [B,2,H,W]|NULL */
+int h3d_multi_pose_assemble(const float *c_score, const int64_t *c_ind, const int32_t *c_cls,
+                            const float *c_y, const float *c_x,
+                            const float *hp_score, const int64_t *hp_ind, const float *hp_y,
+                            const float *hp_x,
+                            const float *wh, const float *hps, const float *reg,
+                            const float *hp_offset,
+                            int B, int J, int H, int W, int K, float *dets, void *stream);
+
+/* ctdet_decode after _topk (decode.py:52-75): dets [B,K,6]. wh [B,2 or 2C,H,W]. */
+int h3d_ctdet_assemble(const float *c_score, const int64_t *c_ind, const int32_t *c_cls,
+                       const float *c_y, const float *c_x, const float *wh, const float *reg,
+                       int B, int C, int H, int W, int K, int cat_spec_wh, float *dets,
+                       void *stream);
+
+/* multi_pose_post_process (utils/post_process.py:41-52 + utils/image.py:19-68, inv affine with
+ * rot = 0): dets [B,K,40] (output-res px) + c [B,2], s [B] -> out [B,K,39] image px. */
+int h3d_multi_pose_post_process(const float *dets, const float *c, const float *s, int B, int K,
+                                int J, int out_h, int out_w, float *out, void *stream);
+
+/* =====================================================================================
+ * 4. SMPL pose/shape -> LBS mesh (north_star; no reference code: published formulation).
+ *    Model tensors are packed by the host (h3d_amd/smpl.py: SMPLModel.device_pack):
+ *      v_template [V*3], shapedirsT [10][V*3], posedirsT [207][V*3], j_template [24*3],
+ *      j_shapedirs [24*3][10], parents i32[24], lbs_idx i32[V][nnz], lbs_w f32[V][nnz]
+ * ===================================================================================== */
+/* per person: Rodrigues (24), pose feature (207), joints, kinematic chain.
+ *   betas [P,10], thetas [P,72] -> pose_feat [P,207], A [P,24,12] (3x4 skinning transforms),
+ *   joints [P,24,3] (posed joint positions) */
+int h3d_smpl_pose(const float *betas, const float *thetas, const float *j_template,
+                  const float *j_shapedirs, const int32_t *parents, int P,
+                  float *pose_feat, float *A, float *joints, void *stream);
+/* blend shapes + LBS: verts [P,V,3] */
+int h3d_smpl_verts(const float *betas, const float *pose_feat, const float *A,
+                   const float *v_template, const float *shapedirsT, const float *posedirsT,
+                   const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int V,
+                   float *verts, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H3D_H */

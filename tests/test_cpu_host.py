@@ -1,0 +1,95 @@
+"""CPU (-m "not gpu"): host logic, the C-ABI library's exports, sharding + the world_size-2 gloo
+path of the one collective.  No compute calls (there is no GPU here and no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import h3d_amd  # noqa: F401
+from h3d_amd import _lib, arch, detector, model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "h3d.h")).read()
+    declared = set(re.findall(r"\b(h3d_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared - {"h3d_last_error", "h3d_abi_version"} == set(_lib.SIGNATURES)
+    assert L.h3d_abi_version() == _lib.ABI_VERSION
+
+
+def test_op_struct_matches_header_layout():
+    # 2 int32, 5 pointers, 16 int32 -> 8 + 40 + 64 = 112 bytes on LP64
+    assert ctypes.sizeof(_lib.H3dOp) == 112
+    assert _lib.H3dOp.in_.offset == 8 and _lib.H3dOp.B.offset == 48
+
+
+def test_null_and_bad_arguments_return_error_codes_without_a_gpu():
+    L = _lib.lib()
+    rc = L.h3d_run_ops(None, 0, None)
+    assert rc == -5 and b"null plan" in L.h3d_last_error()
+    rc = L.h3d_nms_topk(None, 1, 1, 4, 4, 2, 0, None, None, None, None, None)
+    assert rc == -5
+    with pytest.raises(RuntimeError, match="argument error"):
+        _lib.check(rc, "nms_topk")
+
+
+def test_product_has_no_cpu_fallback():
+    m = model.dla_net(HEADS, not_use_dcn=True)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        m(torch.zeros(1, 3, 64, 64))
+    from h3d_amd import decode
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        decode.multi_pose_decode(torch.zeros(1, 1, 8, 8), torch.zeros(1, 2, 8, 8), torch.zeros(1, 34, 8, 8), K=4)
+    src = "".join(open(os.path.join(ROOT, "human-3d-reconstruction_amd", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "human-3d-reconstruction_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_flop_table_matches_survey():
+    # 80.48 / 75.83 GFLOP per image incl. two dead 1x1 `project` convs (0.134 GFLOP) we skip
+    assert abs(arch.conv_flops(HEADS, True) / 1e9 - (80.48 - 0.134)) < 0.02
+    assert abs(arch.conv_flops(HEADS, False) / 1e9 - (75.83 - 0.134)) < 0.02
+
+
+def test_default_init_follows_reference_rules():
+    torch.manual_seed(0)
+    m = model.dla_net(HEADS)
+    sd = m.state_dict()
+    assert float(sd["hm.2.bias"]) == pytest.approx(-2.19) and float(sd["hm_hp.2.bias"][3]) == pytest.approx(-2.19)
+    assert sd["wh.0.bias"].abs().max() == 0 and sd["reg.2.bias"].abs().max() == 0
+    assert sd["hm.0.bias"].abs().max() > 0
+    assert sd["dla_up.ida_0.proj_1.conv.conv_offset_mask.weight"].abs().max() == 0
+    assert sd["dla_up.ida_0.proj_1.conv.bias"].abs().max() == 0
+    w = sd["ida_up.up_2.weight"]
+    assert w.shape == (64, 1, 8, 8) and torch.equal(w[0], w[5])
+    assert float(w[0, 0, 3, 3]) == pytest.approx((1 - abs(3 / 4 - 0.875)) ** 2)
+    assert float(sd["base.level2.root.bn.running_var"][0]) == 1.0
+
+
+def test_shard_batch_partitions():
+    for n, world in [(64, 8), (10, 4), (3, 8), (128, 8)]:
+        spans = [detector.shard_batch(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_gather_detections_world2_gloo():
+    script = os.path.join(ROOT, "tests", "dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29531", script],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DIST_OK" in r.stdout

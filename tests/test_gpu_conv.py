@@ -1,0 +1,169 @@
+"""GPU parity: the MFMA conv / stem / pool / upsample-add / layout kernels against plain PyTorch
+fp32 (CPU) of the same op.  Tolerances: f32 mode 2e-5 relative to the output scale (exact fmaf
+chains, only summation order differs); bf16 mode inputs/weights are pre-rounded to bf16 so the
+only error is fp32 accumulation order + the final bf16 rounding (2^-8 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_helpers import DEV, TD, bf16_round, conv, from_nhwc, mk, nhwc, rnd, run
+from h3d_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(got, ref, dtype, what=""):
+    scale = max(1.0, float(ref.abs().max()))
+    tol = 3e-5 * scale if dtype == "f32" else 1.2e-2 * scale
+    err = float((got - ref).abs().max())
+    assert err <= tol, "%s: max err %.3g > %.3g" % (what, err, tol)
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, H, W, k, stride, relu, residual)
+    (2, 16, 16, 32, 32, 3, 1, True, False),     # level0 class (CK=16, MT=1)
+    (1, 16, 32, 40, 24, 3, 2, True, False),     # level1 class, partial tiles
+    (2, 32, 64, 24, 40, 3, 2, True, False),     # tree conv1 stride 2
+    (2, 64, 64, 16, 16, 3, 1, True, True),      # BasicBlock conv2 + residual
+    (1, 64, 64, 20, 36, 3, 1, False, False),    # partial tiles both ways
+    (1, 128, 128, 16, 32, 3, 1, True, True),    # MT=4 path
+    (1, 64, 256, 16, 16, 3, 1, True, False),    # head 3x3 (two cout chunks)
+    (1, 256, 512, 8, 8, 3, 2, True, False),     # level5 conv1
+    (2, 32, 64, 16, 16, 1, 1, False, False),    # project 1x1 (CK=16 path)
+    (1, 448, 128, 16, 16, 1, 1, True, False),   # root 1x1 over a concat
+    (1, 1280, 512, 4, 4, 1, 1, True, False),    # level5 root
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_torch(case, dtype):
+    B, Ci, Co, H, W, k, s, relu, use_res = case
+    x = rnd("x", (B, Ci, H, W))
+    w = rnd("w", (Co, Ci, k, k), -1.0, 1.0) * (1.5 / np.sqrt(Ci * k * k))
+    b = rnd("b", (Co,))
+    if dtype == "bf16":
+        x, w = bf16_round(x), bf16_round(w)
+    ref = F.conv2d(x.double(), w.double(), b.double(), s, k // 2)
+    res = None
+    if use_res:
+        res = rnd("r", tuple(ref.shape))
+        if dtype == "bf16":
+            res = bf16_round(res)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    got, _ = conv(x, w, b, dtype, stride=s, relu=relu, res=res)
+    _check(got, ref.float(), dtype, str(case))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_channel_strided_views(dtype):
+    # input read from / output written into slices of wider concat buffers; neighbours untouched
+    x = rnd("x", (2, 64, 16, 32))
+    w = rnd("w", (64, 64, 3, 3)) * 0.06
+    b = rnd("b", (64,))
+    if dtype == "bf16":
+        x, w = bf16_round(x), bf16_round(w)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1)).float()
+    got, untouched = conv(x, w, b, dtype, relu=True, in_pad=64, out_pad=128)
+    _check(got, ref, dtype)
+    assert untouched
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_conv_output_modes(dtype):
+    x = rnd("x", (2, 256, 16, 24))
+    w = rnd("w", (34, 256, 1, 1)) * 0.1
+    b = rnd("b", (34,))
+    if dtype == "bf16":
+        x, w = bf16_round(x), bf16_round(w)
+    ref = F.conv2d(x.double(), w.double(), b.double()).float()
+    got, _ = conv(x, w, b, dtype, out_mode=_lib.OUT_NCHW_F32)
+    tol = 3e-5 if dtype == "f32" else 2e-4           # fp32 output: no bf16 rounding at the end
+    assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    x = rnd("x", (1, 64, 16, 16))
+    w = rnd("w", (27, 64, 3, 3)) * 0.05
+    b = rnd("b", (27,))
+    if dtype == "bf16":
+        x, w = bf16_round(x), bf16_round(w)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1).float()
+    got, _ = conv(x, w, b, dtype, out_mode=_lib.OUT_NHWC_F32, pad_cout_to=32)
+    assert float((got[:, :27] - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert float(got[:, 27:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_stem(dtype):
+    x = rnd("img", (2, 3, 40, 56))
+    w = rnd("w", (16, 3, 7, 7)) * 0.1
+    b = rnd("b", (16,))
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 3)).float()
+    xi = x.contiguous().to(DEV)
+    wd, bd = w.contiguous().to(DEV), b.to(DEV)
+    out = torch.zeros(2, 40, 56, 16, dtype=TD[dtype], device=DEV)
+    run(mk(_lib.OP_STEM, dtype, in_=xi.data_ptr(), w=wd.data_ptr(), bias=bd.data_ptr(), out=out.data_ptr(), B=2, H=40,
+           W=56, Cin=3, in_cs=3, Ho=40, Wo=56, Cout=16, out_cs=16, ksize=7, stride=1, relu=1))
+    _check(from_nhwc(out, 16), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_maxpool_and_upadd_and_copy(dtype):
+    x = rnd("x", (2, 32, 18, 22))
+    if dtype == "bf16":
+        x = bf16_round(x)
+    xb, xp = nhwc(x, dtype, 48, 8)
+    out = torch.zeros(2, 9, 11, 32, dtype=TD[dtype], device=DEV)
+    run(mk(_lib.OP_MAXPOOL, dtype, in_=xp, out=out.data_ptr(), B=2, H=18, W=22, Cin=32, in_cs=48, Ho=9, Wo=11, Cout=32,
+           out_cs=32, ksize=2, stride=2))
+    assert torch.equal(from_nhwc(out, 32), F.max_pool2d(x, 2, 2))
+    for f in (2, 4):
+        k = 2 * f
+        C = 64
+        x = rnd("u", (2, C, 6, 10))
+        skip = rnd("s", (2, C, 6 * f, 10 * f))
+        w = rnd("w", (C, 1, k, k), 0.0, 1.0)
+        if dtype == "bf16":
+            x, skip = bf16_round(x), bf16_round(skip)
+        ref = (F.conv_transpose2d(x.double(), w.double(), None, stride=f, padding=f // 2, groups=C) + skip.double()).float()
+        xb, xp = nhwc(x, dtype)
+        sb, sp = nhwc(skip, dtype)
+        wd = w.reshape(C, k * k).t().contiguous().to(DEV)
+        out = torch.zeros(2, 6 * f, 10 * f, C, dtype=TD[dtype], device=DEV)
+        run(mk(_lib.OP_UPADD, dtype, in_=xp, in2=sp, w=wd.data_ptr(), out=out.data_ptr(), B=2, H=6, W=10, Cin=C, in_cs=C,
+               in2_cs=C, Ho=6 * f, Wo=10 * f, Cout=C, out_cs=C, ksize=k, stride=f))
+        _check(from_nhwc(out, C), ref, dtype, "upadd f=%d" % f)
+    x = rnd("c", (1, 16, 5, 7))
+    if dtype == "bf16":
+        x = bf16_round(x)
+    xb, xp = nhwc(x, dtype)
+    out = torch.zeros(1, 5, 7, 32, dtype=TD[dtype], device=DEV)
+    run(mk(_lib.OP_COPY, dtype, in_=xp, out=out.data_ptr() + 16 * out.element_size(), B=1, H=5, W=7, Cin=16, in_cs=16,
+           Ho=5, Wo=7, Cout=16, out_cs=32, ksize=1, stride=1))
+    assert torch.equal(from_nhwc(out, 16, 16), x)
+
+
+def test_layout_round_trip():
+    x = rnd("x", (2, 19, 7, 9)).to(DEV)
+    for dtype in ("f32", "bf16"):
+        mid = torch.zeros(2, 7, 9, 24, dtype=TD[dtype], device=DEV)
+        _lib.check(_lib.lib().h3d_nchw_f32_to_nhwc(_lib.ptr(x), _lib.ptr(mid), _lib.H3D_F32 if dtype == "f32" else _lib.H3D_BF16,
+                                                   2, 19, 7, 9, 24, _lib.stream_ptr()), "to_nhwc")
+        back = torch.zeros_like(x)
+        _lib.check(_lib.lib().h3d_nhwc_to_nchw_f32(_lib.ptr(mid), _lib.H3D_F32 if dtype == "f32" else _lib.H3D_BF16,
+                                                   _lib.ptr(back), 2, 19, 7, 9, 24, _lib.stream_ptr()), "to_nchw")
+        torch.cuda.synchronize()
+        exp = x if dtype == "f32" else x.to(torch.bfloat16).float()
+        assert torch.equal(back, exp)
+
+
+def test_error_codes_raise():
+    x = rnd("x", (1, 24, 8, 8))                    # Cin not a multiple of 16
+    w = rnd("w", (16, 24, 3, 3))
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        conv(x, w, None, "f32")
+    x = rnd("x", (1, 16, 8, 8))
+    w = rnd("w", (16, 16, 5, 5))
+    with pytest.raises(RuntimeError, match="not covered"):
+        conv(x, w, None, "bf16")

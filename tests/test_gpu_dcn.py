@@ -1,0 +1,128 @@
+"""GPU parity of the deformable-conv kernels against the oracle (oracle/dcn.py, pinned in
+tests/test_oracle_dcn.py): (1) the operator boundary `dcn_v2_forward` (NCHW fp32, general
+parameters), incl. the reference's own known-answer test DCNv2/test.py:32-67; (2) the network
+DCN op (NHWC, fused offset/mask layout) in f32 and bf16."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_helpers import DEV, TD, bf16_round, from_nhwc, mk, nhwc, pack_conv, rnd, run
+from h3d_amd import _lib, dcn_v2
+from oracle import dcn as odcn
+
+pytestmark = pytest.mark.gpu
+
+
+def _fwd(x, w, b, off, m, *a):
+    with torch.no_grad():
+        return dcn_v2.dcn_v2_forward(x.to(DEV), w.to(DEV), b.to(DEV), off.to(DEV), m.to(DEV), *a).cpu()
+
+
+def test_zero_offset_identity_reference_known_answer():
+    N, C, H, W = 2, 2, 4, 4
+    x = rnd("x", (N, C, H, W))
+    w = torch.zeros(C, C, 3, 3)
+    for p in range(C):
+        w[p, p, 1, 1] = 1.0
+    y = _fwd(x, w, torch.zeros(C), torch.zeros(N, 18, H, W), torch.full((N, 9, H, W), 0.5), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    assert (x - 2 * y).abs().max().item() < 1e-10
+
+
+def test_shape_smoke_dg2_reference_example():
+    # DCNv2/test.py:169-180: DCN(64, 64, 3x3, dg=2) on [2,64,128,128]
+    x = rnd("x", (2, 64, 128, 128))
+    w = rnd("w", (64, 64, 3, 3), -0.05, 0.05)
+    y = _fwd(x, w, torch.zeros(64), torch.zeros(2, 36, 128, 128), torch.ones(2, 18, 128, 128), 3, 3, 1, 1, 1, 1, 1, 1, 2)
+    assert y.shape == (2, 64, 128, 128)
+    ref = F.conv2d(x, w, None, 1, 1)
+    assert float((y - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [(1, 1, 1, 1), (2, 1, 1, 1), (1, 2, 2, 2), (1, 1, 1, 4)])
+def test_operator_random_vs_oracle(cfg):
+    s, p, d, dg = cfg
+    B, C, H, W, Co = 2, 8, 13, 11, 7
+    Ho = (H + 2 * p - (d * 2 + 1)) // s + 1
+    Wo = (W + 2 * p - (d * 2 + 1)) // s + 1
+    x = rnd("x", (B, C, H, W))
+    w = rnd("w", (Co, C, 3, 3), -0.3, 0.3)
+    b = rnd("b", (Co,))
+    off = rnd("off", (B, 18 * dg, Ho, Wo), -3.0, 3.0)
+    m = rnd("m", (B, 9 * dg, Ho, Wo), 0.0, 1.0)
+    y = _fwd(x, w, b, off, m, 3, 3, s, s, p, p, d, d, dg)
+    ref = odcn.dcn_v2_forward(x, w, b, off, m, 3, 3, s, s, p, p, d, d, dg, acc_dtype=torch.float64)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_operator_boundary_gate_and_far_offsets():
+    x = torch.ones(1, 1, 4, 4)
+    w = torch.zeros(1, 1, 3, 3)
+    w[0, 0, 1, 1] = 1.0
+    off = torch.zeros(1, 18, 4, 4)
+    off[0, 8, 0, :] = -0.5
+    y = _fwd(x, w, torch.zeros(1), off, torch.ones(1, 9, 4, 4), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    np.testing.assert_allclose(y[0, 0, 0].numpy(), np.full(4, 0.5, np.float32), atol=1e-7)
+    off[0, 8, 0, :] = -1.0
+    y = _fwd(x, w, torch.zeros(1), off, torch.ones(1, 9, 4, 4), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    np.testing.assert_allclose(y[0, 0, 0].numpy(), np.zeros(4, np.float32), atol=1e-7)
+    b = rnd("b", (3,))
+    y = _fwd(rnd("x", (1, 2, 5, 5)), rnd("w", (3, 2, 3, 3)), b, torch.full((1, 18, 5, 5), 100.0), torch.ones(1, 9, 5, 5),
+             3, 3, 1, 1, 1, 1, 1, 1, 1)
+    np.testing.assert_allclose(y.numpy(), b.view(1, 3, 1, 1).expand(1, 3, 5, 5).numpy(), atol=1e-7)
+
+
+def test_operator_errors_match_reference_messages():
+    x = rnd("x", (1, 4, 8, 8)).to(DEV)
+    w = rnd("w", (4, 4, 3, 3)).to(DEV)
+    b = torch.zeros(4, device=DEV)
+    off = torch.zeros(1, 18, 8, 8, device=DEV)
+    m = torch.ones(1, 9, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError, match="kernel shape wont match"):
+        dcn_v2.dcn_v2_forward(x, w, b, off, m, 5, 5, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="kernel channels wont match"):
+        dcn_v2.dcn_v2_forward(x, rnd("w2", (4, 3, 3, 3)).to(DEV), b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        dcn_v2.dcn_v2_forward(x.cpu(), w.cpu(), b.cpu(), off.cpu(), m.cpu(), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
+def test_dcn_module_fresh_is_half_conv():
+    torch.manual_seed(0)
+    mod = dcn_v2.DCN(16, 8, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV).eval()
+    x = rnd("x", (2, 16, 12, 12)).to(DEV)
+    with torch.no_grad():
+        y = mod(x).cpu()
+        ref = (0.5 * F.conv2d(x, mod.weight, None, 1, 1) + mod.bias.view(1, -1, 1, 1)).cpu()
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert set(mod.state_dict()) == {"weight", "bias", "conv_offset_mask.weight", "conv_offset_mask.bias"}
+
+
+NET_CASES = [(2, 64, 64, 16, 16), (1, 128, 64, 24, 40), (1, 256, 128, 16, 16), (1, 512, 256, 8, 8), (1, 32, 16, 20, 20)]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", NET_CASES)
+def test_network_dcn_op_vs_oracle(case, dtype):
+    B, Ci, Co, H, W = case
+    x = rnd("x", (B, Ci, H, W))
+    w = rnd("w", (Co, Ci, 3, 3)) * (1.5 / np.sqrt(Ci * 9))
+    b = rnd("b", (Co,))
+    om = rnd("om", (B, 27, H, W), -2.5, 2.5)          # raw conv_offset_mask output
+    om[:, :18, :2, :] *= 4.0                              # some samples far outside the image
+    if dtype == "bf16":
+        x, w = bf16_round(x), bf16_round(w)
+    offset, mask = om[:, :18].contiguous(), torch.sigmoid(om[:, 18:]).contiguous()
+    ref = F.relu(odcn.dcn_v2_forward(x, w, b, offset, mask, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64))
+    xb, xp = nhwc(x, dtype)
+    omb = torch.zeros(B, H, W, 32, dtype=torch.float32, device=DEV)
+    omb[..., :27] = om.permute(0, 2, 3, 1).to(DEV)
+    wp, bp, cout, rows = pack_conv(w, b, dtype)
+    out = torch.zeros(B, H, W, Co, dtype=TD[dtype], device=DEV)
+    run(mk(_lib.OP_DCN, dtype, in_=xp, in2=omb.data_ptr(), w=wp.data_ptr(), bias=bp.data_ptr(), out=out.data_ptr(), B=B,
+           H=H, W=W, Cin=Ci, in_cs=Ci, in2_cs=32, Ho=H, Wo=W, Cout=Co, out_cs=Co, ksize=3, stride=1, relu=1,
+           out_mode=_lib.OUT_NHWC, wrows=rows))
+    got = from_nhwc(out, Co)
+    scale = max(1.0, float(ref.abs().max()))
+    # bf16: the sampled operand is rounded to bf16 before the MFMA (2^-9 relative per term)
+    tol = 5e-5 * scale if dtype == "f32" else 2.5e-2 * scale
+    assert float((got - ref).abs().max()) <= tol

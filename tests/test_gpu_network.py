@@ -1,0 +1,127 @@
+"""GPU parity of the whole DLA-34 forward through the reference-named factory `dla_net`:
+  * plain-conv variant, f32 mode, against the golden vectors = the REFERENCE's own model output
+    (tests/golden/dla34_plain.npz) and against the oracle restatement;
+  * DCN variant, f32 mode, against the oracle (the reference cannot run DCN on a CPU);
+  * bf16 throughput mode against the f32 oracle with the bf16 tolerance stated here;
+  * end-to-end detector (model -> sigmoid -> decode -> SMPL) index agreement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import h3d_amd  # noqa: F401
+from h3d_amd import arch, model, synth
+from h3d_amd.detector import MultiPoseDetector, Opt
+from oracle import decode as odec
+from oracle import dla as odla
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
+F32_TOL = 2e-4      # abs, heads are O(1): f32 MFMA = exact fmaf chain, BN folding + summation order only
+BF16_TOL = 0.12     # abs: ~50 layers of bf16 activations/weights (2^-9 relative per rounding)
+
+
+def _net(use_dcn, dtype, heads=HEADS):
+    sd = synth.synth_state_dict(arch.state_dict_shapes(heads, use_dcn), seed=0)
+    m = model.dla_net(heads, not_use_dcn=not use_dcn, dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.to(DEV).eval(), sd
+
+
+def test_plain_f32_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "dla34_plain.npz"))
+    m, _ = _net(False, "f32")
+    x = torch.from_numpy(synth.synth_images(2, 96, 128, seed=317)).to(DEV)
+    out = m(x)[0]
+    assert set(out) == set(HEADS)
+    for k in HEADS:
+        got = out[k].cpu().numpy()
+        assert got.shape == g[k].shape
+        np.testing.assert_allclose(got, g[k], rtol=0, atol=F32_TOL, err_msg=k)
+
+
+def test_dcn_f32_matches_oracle():
+    m, sd = _net(True, "f32")
+    xs = synth.synth_images(2, 64, 96, seed=5)
+    out = m(torch.from_numpy(xs).to(DEV))[0]
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(torch.from_numpy(xs))[0]
+    for k in HEADS:
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=5e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("use_dcn", [False, True])
+def test_bf16_mode_within_stated_tolerance(use_dcn):
+    m, sd = _net(use_dcn, "bf16")
+    xs = synth.synth_images(2, 128, 128, seed=7)
+    out = m(torch.from_numpy(xs).to(DEV))[0]
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, HEADS, use_dcn=use_dcn)(torch.from_numpy(xs))[0]
+    worst = 0.0
+    for k in HEADS:
+        e = float(np.abs(out[k].cpu().numpy() - ref[k].numpy()).max())
+        worst = max(worst, e)
+        assert e < BF16_TOL, (k, e)
+    print("bf16 max abs head error (dcn=%s): %.4f" % (use_dcn, worst))
+
+
+def test_batch_position_invariance_and_determinism():
+    m, _ = _net(True, "bf16")
+    xs = torch.from_numpy(synth.synth_images(3, 64, 64, seed=3)).to(DEV)
+    a = {k: v.clone() for k, v in m(xs)[0].items()}
+    b = {k: v.clone() for k, v in m(xs)[0].items()}
+    one = {k: v.clone() for k, v in m(xs[1:2].contiguous())[0].items()}
+    for k in HEADS:
+        assert torch.equal(a[k], b[k])
+        assert torch.equal(a[k][1:2], one[k])
+
+
+def test_state_dict_keys_and_reference_checkpoint_format(tmp_path):
+    m = model.dla_net(HEADS, not_use_dcn=False)
+    keys = set(m.state_dict())
+    assert keys == set(arch.state_dict_shapes(HEADS, True))
+    # reference checkpoint format (trains/trainer.py:530-539): {'epoch', 'state_dict'}, 'module.' prefix
+    ck = {"epoch": 3, "state_dict": {"module." + k: v for k, v in m.state_dict().items()}}
+    path = os.path.join(tmp_path, "model_last.pth")
+    torch.save(ck, path)
+    from h3d_amd.checkpoint import load_model
+    m2 = model.dla_net(HEADS, not_use_dcn=False)
+    load_model(m2, path)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m.train()(torch.zeros(1, 3, 32, 32, device=DEV))
+    with pytest.raises(RuntimeError, match="CPU"):
+        m.eval()(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="multiples of 32"):
+        m.to(DEV).eval()(torch.zeros(1, 3, 48, 40, device=DEV))
+
+
+def test_detector_end_to_end_f32_indices_match_oracle():
+    opt = Opt(input_h=128, input_w=128, dtype="f32", K=50)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0)
+    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    xs = synth.synth_images(2, 128, 128, seed=317)
+    res = det.run(torch.from_numpy(xs).to(DEV), meta={"c": np.array([[64, 64], [64, 64]], np.float32),
+                                                      "s": np.array([128.0, 128.0], np.float32)})
+    heads = {k: v.cpu().numpy() for k, v in res["heads"].items()}
+    # decode of the GPU's own heads by the oracle: identical inputs -> bit-exact indices
+    from h3d_amd import utils
+    hm = utils._sigmoid(res["heads"]["hm"]).cpu().numpy()
+    hp = utils._sigmoid(res["heads"]["hm_hp"]).cpu().numpy()
+    ref, aux = odec.multi_pose_decode(hm, heads["wh"], heads["hps"], heads["reg"], hp, heads["hp_offset"], K=50,
+                                      return_aux=True)
+    np.testing.assert_array_equal(res["inds"].cpu().numpy(), aux["inds"])
+    np.testing.assert_array_equal(res["dets"].cpu().numpy(), ref)
+    # network heads vs the fp32 oracle network, then indices wherever the score gap allows
+    with torch.no_grad():
+        oref = odla.DLAOracle(sd, opt.heads, use_dcn=True)(torch.from_numpy(xs))[0]
+    ohm = odec.sigmoid_clamp(oref["hm"].numpy())
+    _, oaux = odec.multi_pose_decode(ohm, oref["wh"].numpy(), oref["hps"].numpy(), oref["reg"].numpy(),
+                                     odec.sigmoid_clamp(oref["hm_hp"].numpy()), oref["hp_offset"].numpy(), K=50,
+                                     return_aux=True)
+    agree = (res["inds"].cpu().numpy() == oaux["inds"]).mean()
+    assert agree > 0.9, agree
+    assert res["results"].shape == (2, 50, 39)
