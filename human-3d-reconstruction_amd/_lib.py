@@ -36,6 +36,8 @@ class H3dOp(ctypes.Structure):
 SIGNATURES = {
     "h3d_dcn_v2_forward": [c_vp] * 6 + [c_i] * 14 + [c_vp],
     "h3d_run_ops": [ctypes.POINTER(H3dOp), c_i, c_vp],
+    "h3d_run_ops_timed": [ctypes.POINTER(H3dOp), c_i, c_vp, c_vp],
+    "h3d_op_kernel_name": [ctypes.POINTER(H3dOp), ctypes.c_char_p, c_i],
     "h3d_nchw_f32_to_nhwc": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "h3d_nhwc_to_nchw_f32": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "h3d_nms_topk": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp],

@@ -17,6 +17,9 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 // ---- error plumbing -------------------------------------------------------------------------
 void h3d_set_error(const char *fmt, ...);
+// Records the kernel instantiation an op maps to; returns true when the caller must NOT launch
+// (h3d_op_kernel_name's dry run).  Names match the kernel symbols rocprofv3 reports.
+bool h3d_note_kernel(const char *fmt, ...);
 #define H3D_FAIL(code, ...)        \
     do {                           \
         h3d_set_error(__VA_ARGS__); \

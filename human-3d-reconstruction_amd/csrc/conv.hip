@@ -144,6 +144,9 @@ static int launch_conv_cfg(const ConvArgs &a0, hipStream_t st)
     a.tiles_x = cdiv(a.Wo, C::TW);
     a.tiles_y = cdiv(a.Ho, TH);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
+    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
+                        CK, TH))
+        return H3D_OK;
     hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH>), grid, dim3(256), 0, st, a);
     H3D_CHECK_LAUNCH("conv_kernel");
     return H3D_OK;
@@ -283,6 +286,7 @@ int h3d_launch_stem(const h3d_op &op, hipStream_t st)
         H3D_FAIL(H3D_ERR_SHAPE, "stem: expects 7x7 3->16 stride 1 (got k=%d %d->%d)", op.ksize, op.Cin, op.Cout);
     const int tx = cdiv(op.W, 16), ty = cdiv(op.H, 16);
     dim3 grid(op.B * tx * ty);
+    if (h3d_note_kernel("stem_kernel<%s>", op.dtype == H3D_BF16 ? "unsigned short" : "float")) return H3D_OK;
     if (op.dtype == H3D_BF16)
         hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, st, (const float *)op.in, (const float *)op.w,
                            op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.out_cs, tx, ty);
@@ -428,6 +432,9 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
                  op.in_cs, op.out_cs, n);
     const size_t total = (size_t)op.B * op.Ho * op.Wo * (op.Cin / n);
     dim3 grid(ew_grid(total)), blk(256);
+    if (h3d_note_kernel("%s<%s>", op.kind == H3D_OP_MAXPOOL ? "maxpool_kernel" : op.kind == H3D_OP_UPADD ? "upadd_kernel" : "copy_kernel",
+                        es == 2 ? "unsigned short" : "float"))
+        return H3D_OK;
     if (op.kind == H3D_OP_MAXPOOL) {
         if (op.Ho != op.H / 2 || op.Wo != op.W / 2) H3D_FAIL(H3D_ERR_SHAPE, "maxpool: output must be floor(H/2) x floor(W/2)");
         if (es == 2)

@@ -199,6 +199,7 @@ static int launch_dcn_cfg(const DcnArgs &a0, hipStream_t st)
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
+    if (h3d_note_kernel("dcn_kernel<%s, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK)) return H3D_OK;
     hipLaunchKernelGGL((dcn_kernel<T, MT, CK>), grid, dim3(256), 0, st, a);
     H3D_CHECK_LAUNCH("dcn_kernel");
     return H3D_OK;

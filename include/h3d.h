@@ -101,6 +101,13 @@ typedef struct h3d_op {
  * message). */
 int h3d_run_ops(const h3d_op *ops, int n, void *stream);
 
+/* Same, with a HIP event pair around every op: ms[i] = device time of ops[i] (bench.py's
+ * live roofline measurement; events are recorded on `stream`). Synchronises the stream. */
+int h3d_run_ops_timed(const h3d_op *ops, int n, void *stream, float *ms);
+/* Name of the kernel instantiation `op` dispatches to, as rocprofv3 prints it
+ * (e.g. "conv_kernel<unsigned short, 3, 1, 2, 32, 16>"); nothing is launched. */
+int h3d_op_kernel_name(const h3d_op *op, char *buf, int buflen);
+
 /* Layout helpers (host interface keeps the reference's NCHW fp32 tensors at the boundary). */
 int h3d_nchw_f32_to_nhwc(const float *src, void *dst, int dtype, int B, int C, int H, int W,
                          int dst_cs, void *stream);
