@@ -74,7 +74,11 @@ def cpu_baseline(opt, sd, seconds_budget=20.0):
     """Oracle (torch-CPU restatement, kind 'port') on a bounded sample of the same workload."""
     from oracle import decode as odec, dla as odla, smpl as osmpl
     from h3d_amd import smpl as psmpl
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))                          # the 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
     net = odla.DLAOracle(sd, opt.heads, use_dcn=not opt.not_use_dcn)
     model = psmpl.SMPLModel.synthetic().numpy_dict()
@@ -88,16 +92,19 @@ def cpu_baseline(opt, sd, seconds_budget=20.0):
                                            odec.sigmoid_clamp(o["hm_hp"]), o["hp_offset"], K=opt.K, return_aux=True)
         n = 4                                             # meshes per image in the CPU sample (fp64 numpy)
         idx = aux["inds"][:, :n]
-        th = np.stack([o["pose"][i][:, idx[i]].T for i in range(B)]).reshape(-1, 72)
-        be = np.stack([o["shape"][i][:, idx[i]].T for i in range(B)]).reshape(-1, 10)
+        th = np.stack([o["pose"][i].reshape(72, -1)[:, idx[i]].T for i in range(B)]).reshape(-1, 72)
+        be = np.stack([o["shape"][i].reshape(10, -1)[:, idx[i]].T for i in range(B)]).reshape(-1, 10)
         osmpl.lbs(be, th, model)
 
+    t0 = time.time()
     step()                                                # warm-up
+    print("[bench] cpu_baseline warm-up step %.1f s on %d threads" % (time.time() - t0, cores), file=sys.stderr, flush=True)
     t0 = time.time()
     iters = 0
     while iters < 2 or (time.time() - t0 < seconds_budget and iters < 12):
         step()
         iters += 1
+        print("[bench] cpu_baseline step %d: %.1f s elapsed" % (iters, time.time() - t0), file=sys.stderr, flush=True)
     dt = time.time() - t0
     return {"value": round(B * iters / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d steps of batch %d (512x512, DLA-34+DCNv2+heads fp32 via torch-CPU threads=%d, numpy decode, "
@@ -141,8 +148,13 @@ def main():
         res = det.run(images)
         return gather_detections(res["dets"]) if world > 1 else res["dets"]
 
+    t_setup = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        print("[bench] warm-up (%d steps incl. plan build + weight packing) %.1f s" % (args.warmup, time.perf_counter() - t_setup),
+              file=sys.stderr, flush=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -159,6 +171,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert out.shape == (world * args.batch, 100, 40)
+    if rank == 0:
+        print("[bench] %d GPU(s): %.1f images/s, %.3f ms/step" % (world, world * args.batch * args.steps / dt,
+                                                                 1e3 * dt / args.steps), file=sys.stderr, flush=True)
 
     if rank == 0:
         gflop_img = arch.conv_flops(opt.heads, True) / 1e9
@@ -189,9 +204,11 @@ def main():
                                 "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                                 "share_of_network_time": round(g["ms"] / total_ms, 3),
                                 "network_ms_per_step": round(total_ms, 3)}
+            print("[bench] roofline %s" % json.dumps(line["roofline"]), file=sys.stderr, flush=True)
             line["kernels"] = {k: {"ms": round(v["ms"], 3), "n": v["launches"],
                                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
+            print("[bench] kernels %s" % json.dumps(line["kernels"]), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(opt, sd)
         print(json.dumps(line))
