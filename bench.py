@@ -42,6 +42,9 @@ def op_flops(op):
         return 2.0 * px * op.Cout * op.Cin * op.ksize * op.ksize
     if op.kind == _lib.OP_UPADD:
         return 2.0 * px * op.Cout * 4
+    if op.kind == _lib.OP_HEADS:
+        d = ctypes.cast(op.in2, ctypes.POINTER(_lib.H3dHeadsDesc)).contents
+        return sum(2.0 * px * op.Cout * (op.Cin * 9 + d.head[i].C) for i in range(d.nheads))
     return 0.0
 
 

@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libh3d_hip.so")
 
 H3D_F32, H3D_BF16 = 0, 1
-OP_STEM, OP_CONV, OP_DCN, OP_MAXPOOL, OP_UPADD, OP_COPY = 1, 2, 3, 4, 5, 6
+OP_STEM, OP_CONV, OP_DCN, OP_MAXPOOL, OP_UPADD, OP_COPY, OP_HEADS = 1, 2, 3, 4, 5, 6, 7
+HEADS_MAX = 16
 OUT_NHWC, OUT_NCHW_F32, OUT_NHWC_F32 = 0, 1, 2
 ABI_VERSION = 1
 
@@ -30,6 +31,15 @@ class H3dOp(ctypes.Structure):
         ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32), ("relu", ctypes.c_int32),
         ("out_mode", ctypes.c_int32), ("wrows", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
+
+
+class _HeadEntry(ctypes.Structure):
+    _fields_ = [("w2", c_vp), ("b2", c_vp), ("out", c_vp), ("C", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+class H3dHeadsDesc(ctypes.Structure):
+    """Mirror of `struct h3d_heads_desc` (host-side descriptor behind H3D_OP_HEADS)."""
+    _fields_ = [("nheads", ctypes.c_int32), ("reserved", ctypes.c_int32), ("head", _HeadEntry * HEADS_MAX)]
 
 
 # name -> argtypes (restype is int unless noted); also the export list the CPU test checks

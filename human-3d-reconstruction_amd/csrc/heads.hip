@@ -13,6 +13,7 @@
 // the accumulator row order, which the host bakes into the packed 1x1 weights).
 // Outputs are written as contiguous NCHW fp32 rows (lane = pixel), the reference's head layout.
 #include "common.h"
+#include <type_traits>
 
 constexpr int HEADS_MAX = 16;
 constexpr int HC_IN = 64;     // channels of y (DLA-34 first_level = 2)
@@ -49,6 +50,53 @@ struct HeadsCfg {
     static constexpr int VPR = HC_IN * ES / 16;       // 16-byte vectors per 64-element row
     static constexpr int NSTG = (32 * HC_MT2 * VPR + 511) / 512;   // staging vectors per thread (W2 stage is the largest)
 };
+
+// Second contraction of a head: acc2[m2] += W2[rows of tile m2][slab K] . ReLU(acc + b1), then acc = 0.
+// The accumulator registers 8s..8s+7 of a 32x32 tile are K-step s of the B operand (lane = pixel);
+// the matching A fragment (K in accumulator-row order) sits at column m*32 + h*16 + s*8 of the
+// host-permuted W2 row.
+template <typename T, int NT, int M2>
+__device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][NT], const float *__restrict__ b1,
+                                      const char *s_w2, int w2b, int r, int h)
+{
+    using E = ET<T>;
+    constexpr int ES = sizeof(T);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+            typename E::frag fb[NT];
+            float bias[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = 8 * sb + j;
+                bias[j] = b1[m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    x[j] = fmaxf(acc[m][n][8 * sb + j] + bias[j], 0.f);
+                    acc[m][n][8 * sb + j] = 0.f;
+                }
+                if constexpr (ES == 4) {
+                    fb[n].lo = f32x4{x[0], x[1], x[2], x[3]};
+                    fb[n].hi = f32x4{x[4], x[5], x[6], x[7]};
+                } else {
+                    fb[n].v = u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]),
+                                    pack_bf16x2(x[6], x[7])};
+                }
+            }
+#pragma unroll
+            for (int m2 = 0; m2 < M2; ++m2) {
+                const typename E::frag fa = E::lds_frag(s_w2 + (m2 * 32 + r) * w2b + (m * 32 + h * 16 + sb * 8) * ES);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) E::mma(acc2[m2][n], fa, fb[n]);
+            }
+        }
+    }
+}
 
 template <typename T, int TH>
 __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
@@ -129,125 +177,94 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     commit(0);
     __syncthreads();
 
-    f32x16 acc[2][NT], acc2[HC_MT2][NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-#pragma unroll
-    for (int m = 0; m < HC_MT2; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc2[m][n][i] = 0.f;
-
     int boff[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) boff[n] = (wv * NT + n) * C::RB + r * C::SB + 8 * h * ES;
     const int aoff = r * C::WB + 8 * h * ES;
 
-    for (int s = 0; s < nstages; ++s) {
-        const int head = s / stages_per_head, q = s - head * stages_per_head;
-        const int slab = q / 10, k = q - slab * 10;
-        if (s + 1 < nstages) prefetch(s + 1);
-        if (k < 9) {
-            // ---- 3x3 tap k of this slab: acc[2][NT] += W1[64 x 64] . halo(tap)[64 x pixels] --------
-            const int dy = k / 3, dx = k - dy * 3;
-            const char *wr = s_ring + (k & 1) * C::LDS_RING + aoff;
+    // One head with M2 row tiles of 1x1 output.  Accumulators are local to this instantiation so
+    // no control-flow merge ever joins differently-updated accumulator sets (that costs copies
+    // and spills); `s` is the running stage index of the weight pipeline.
+    auto run_head = [&](auto m2_tag, int head, int &s) {
+        constexpr int M2 = decltype(m2_tag)::value;
+        f32x16 acc[2][NT], acc2[M2][NT];
 #pragma unroll
-            for (int kk = 0; kk < HC_IN / 16; ++kk) {
-                typename E::frag fa[2], fb[NT];
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int m = 0; m < 2; ++m) fa[m] = E::lds_frag(wr + m * 32 * C::WB + kk * 16 * ES);
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(s_in + boff[n] + dy * C::RB + dx * C::SB + kk * 16 * ES);
+                for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < M2; ++m)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
-            }
-        } else {
-            // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X -------------
-            const int C_head = a.C[head];
-            const float *b1 = a.b1 + head * a.head_conv + slab * HC_SLAB;
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                float bias[16];
+                for (int i = 0; i < 16; ++i) acc2[m][n][i] = 0.f;
+        for (int slab = 0; slab < slabs; ++slab) {
+            for (int k = 0; k < 9; ++k, ++s) {
+                // ---- 3x3 tap k of this slab: acc[2][NT] += W1[64 x 64] . halo(tap)[64 x pixels] ----
+                if (s + 1 < nstages) prefetch(s + 1);
+                const int dy = k / 3, dx = k - dy * 3;
+                const char *wr = s_ring + (k & 1) * C::LDS_RING + aoff;
+                const char *br = s_in + dy * C::RB + dx * C::SB;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) bias[i] = b1[m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+                for (int kk = 0; kk < HC_IN / 16; ++kk) {
+                    typename E::frag fa[2], fb[NT];
 #pragma unroll
-                for (int sb = 0; sb < 2; ++sb) {
-                    typename E::frag fb[NT];
+                    for (int m = 0; m < 2; ++m) fa[m] = E::lds_frag(wr + m * 32 * C::WB + kk * 16 * ES);
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        float x[8];
+                    for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) x[j] = fmaxf(acc[m][n][8 * sb + j] + bias[8 * sb + j], 0.f);
-                        if constexpr (ES == 4) {
-                            fb[n].lo = f32x4{x[0], x[1], x[2], x[3]};
-                            fb[n].hi = f32x4{x[4], x[5], x[6], x[7]};
-                        } else {
-                            fb[n].v = u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]),
-                                            pack_bf16x2(x[6], x[7])};
-                        }
-                    }
+                    for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int m2 = 0; m2 < HC_MT2; ++m2) {
-                        if (m2 * 32 < C_head) {
-                            const typename E::frag fa =
-                                E::lds_frag(s_w2 + (m2 * 32 + r) * C::W2B + (m * 32 + h * 16 + sb * 8) * ES);
-#pragma unroll
-                            for (int n = 0; n < NT; ++n) E::mma(acc2[m2][n], fa, fb[n]);
-                        }
-                    }
+                        for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
                 }
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+                if (s + 1 < nstages) commit(s + 1);
+                __syncthreads();
             }
-            if (slab == slabs - 1) {
-                // ---- head done: z = acc2 + b2 -> NCHW fp32 (lane = pixel: coalesced rows) ------------
-                const float *b2 = a.b2[head];
-                float *out = a.out[head];
+            // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 --------
+            if (s + 1 < nstages) prefetch(s + 1);
+            gemm2<T, NT, M2>(acc, acc2, a.b1 + head * a.head_conv + slab * HC_SLAB, s_w2, C::W2B, r, h);
+            if (s + 1 < nstages) commit(s + 1);
+            __syncthreads();
+            ++s;
+        }
+        // ---- head done: z = acc2 + b2 -> NCHW fp32 (lane = pixel: coalesced rows) --------------------
+        const int C_head = a.C[head];
+        const float *b2 = a.b2[head];
+        float *out = a.out[head];
+        const size_t cstride = (size_t)a.H * a.W;
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    const int oy = oy0 + wv * NT + n, ox = ox0 + r;
-                    const bool ok = (oy < a.H && ox < a.W);
+        for (int n = 0; n < NT; ++n) {
+            const int oy = oy0 + wv * NT + n, ox = ox0 + r;
+            if (oy < a.H && ox < a.W) {
+                float *op = out + (((size_t)b * C_head + 4 * h) * a.H + oy) * a.W + ox;
 #pragma unroll
-                    for (int m2 = 0; m2 < HC_MT2; ++m2) {
-                        if (m2 * 32 < C_head) {
+                for (int m2 = 0; m2 < M2; ++m2) {
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const int c = m2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                                if (ok && c < C_head)
-                                    out[(((size_t)b * C_head + c) * a.H + oy) * a.W + ox] = acc2[m2][n][i] + b2[c];
-                                acc2[m2][n][i] = 0.f;
-                            }
-                        }
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = m2 * 32 + 8 * g + 4 * h;
+                        float *p = op + (size_t)(m2 * 32 + 8 * g) * cstride;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (c + i < C_head) p[i * cstride] = acc2[m2][n][4 * g + i] + b2[c + i];
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
         }
-        if (s + 1 < nstages) commit(s + 1);
-        __syncthreads();
+    };
+
+    int s = 0;
+    for (int head = 0; head < a.nheads; ++head) {
+        const int mt2 = (a.C[head] + 31) >> 5;   // wave-uniform
+        if (mt2 == 1) run_head(std::integral_constant<int, 1>{}, head, s);
+        else if (mt2 == 2) run_head(std::integral_constant<int, 2>{}, head, s);
+        else run_head(std::integral_constant<int, 3>{}, head, s);
     }
 }
 
-// host descriptor behind h3d_op.in2 for H3D_OP_HEADS
-struct h3d_heads_desc {
-    int32_t nheads;
-    int32_t reserved;
-    struct {
-        const void *w2;
-        const float *b2;
-        float *out;
-        int32_t C;
-        int32_t pad;
-    } head[HEADS_MAX];
-};
+static_assert(HEADS_MAX == H3D_HEADS_MAX, "header/kernel mismatch");
 
 int h3d_launch_heads(const h3d_op &op, hipStream_t st)
 {

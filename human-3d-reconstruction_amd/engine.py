@@ -96,6 +96,31 @@ class PackedWeights:
             self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
         return self.t[key]
 
+    def heads(self):
+        """Fused-heads pack: 3x3 weights of all heads stacked [nheads*head_conv][9][64]; per head the
+        1x1 weights as [96 rows][head_conv] with K re-ordered to the MFMA accumulator row order
+        (csrc/heads.hip): within every 32-channel group, position h*16 + r holds channel
+        (r&3) + 8*(r>>2) + 4*h."""
+        key = ("heads",)
+        if key not in self.t:
+            hc = self.head_conv
+            td = _TORCH_DT[self.dtype]
+            w1, b1, per = [], [], []
+            perm = torch.tensor([g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h
+                                 for g in range(hc // 32) for h in range(2) for r in range(16)])
+            for head, c in self.heads.items():
+                w = self.sd[head + ".0.weight"]                      # [hc,64,3,3]
+                w1.append(w.permute(0, 2, 3, 1).reshape(hc, 9, w.shape[1]))
+                b1.append(self.sd[head + ".0.bias"])
+                w2 = torch.zeros(96, hc)
+                w2[:c] = self.sd[head + ".2.weight"].reshape(c, hc)[:, perm]
+                b2 = torch.zeros(96)
+                b2[:c] = self.sd[head + ".2.bias"]
+                per.append((head, c, w2.to(td).contiguous().to(self.device), b2.to(self.device)))
+            self.t[key] = (torch.cat(w1).to(td).contiguous().to(self.device),
+                           torch.cat(b1).float().contiguous().to(self.device), per)
+        return self.t[key]
+
     def up(self, wkey):
         key = ("up", wkey)
         if key not in self.t:
@@ -108,7 +133,8 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W):
+    def __init__(self, pw, B, H, W, fuse_heads=True):
+        self.fuse_heads = fuse_heads
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -259,6 +285,20 @@ class Plan:
         feat = ys[-1]
         self.feat = feat
         Ho, Wo = feat.H, feat.W
+        fused = (self.pw.head_conv > 0 and self.pw.head_conv % 64 == 0 and feat.C == 64 and
+                 len(self.pw.heads) <= _lib.HEADS_MAX and max(self.pw.heads.values()) <= 96 and self.fuse_heads)
+        if fused:
+            w1, b1, per = self.pw.heads()
+            desc = _lib.H3dHeadsDesc()
+            desc.nheads = len(per)
+            for i, (head, c, w2, b2) in enumerate(per):
+                o = torch.empty(B, c, Ho, Wo, dtype=torch.float32, device=self.pw.device)
+                self.outputs[head] = o
+                desc.head[i].w2, desc.head[i].b2, desc.head[i].out, desc.head[i].C = w2.data_ptr(), b2.data_ptr(), o.data_ptr(), c
+            self.keep.append(desc)
+            self._op(_lib.OP_HEADS, in_=feat.ptr, in2=ctypes.addressof(desc), w=w1.data_ptr(), bias=b1.data_ptr(),
+                     H=Ho, W=Wo, Cin=feat.C, in_cs=feat.cs, Ho=Ho, Wo=Wo, Cout=self.pw.head_conv, ksize=3, stride=1)
+            return
         for head, c in self.pw.heads.items():
             o = torch.empty(B, c, Ho, Wo, dtype=torch.float32, device=self.pw.device)
             self.outputs[head] = o
@@ -290,12 +330,13 @@ class DLAEngine:
             raise RuntimeError("Not implemented on the CPU")
         self.pw = PackedWeights(state_dict, heads, use_dcn, dtype, self.device, head_conv)
         self.plans = {}
+        self.fuse_heads = True          # False: one conv3x3 + conv1x1 launch pair per head (debug/ablation)
 
     def plan(self, B, H, W):
         key = (B, H, W)
         if key not in self.plans:
             with torch.cuda.device(self.device):
-                self.plans[key] = Plan(self.pw, B, H, W)
+                self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads)
         return self.plans[key]
 
     def forward(self, images):

@@ -72,8 +72,27 @@ enum {
     H3D_OP_DCN = 3,     /* modulated deformable 3x3 s1 p1 d1 dg1 conv + bias [+ReLU] (model.py:346-362) */
     H3D_OP_MAXPOOL = 4, /* 2x2 stride-2 max pool (Tree.downsample, model.py:200-201)                   */
     H3D_OP_UPADD = 5,   /* depthwise ConvTranspose2d(k=2f,s=f,p=f/2) + skip add (IDAUp, model.py:375-390) */
-    H3D_OP_COPY = 6     /* strided NHWC copy (y[i] = x[i].clone(), model.py:480-482)                   */
+    H3D_OP_COPY = 6,    /* strided NHWC copy (y[i] = x[i].clone(), model.py:480-482)                   */
+    H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
+                           (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */
 };
+
+/* H3D_OP_HEADS: op.in = y (NHWC, 64 ch), op.w = packed 3x3 weights of all heads
+ * [nheads*head_conv][9][64], op.bias = fp32 [nheads*head_conv], op.Cout = head_conv,
+ * op.in2 = host pointer to this descriptor.  w2: [96 rows][head_conv] elements with K in MFMA
+ * accumulator-row order (h3d_amd/engine.py: pack_head_1x1), b2: fp32 [96], out: NCHW fp32. */
+#define H3D_HEADS_MAX 16
+typedef struct h3d_heads_desc {
+    int32_t nheads;
+    int32_t reserved;
+    struct {
+        const void *w2;
+        const float *b2;
+        float *out;
+        int32_t C;
+        int32_t pad;
+    } head[H3D_HEADS_MAX];
+} h3d_heads_desc;
 enum { H3D_OUT_NHWC = 0, H3D_OUT_NCHW_F32 = 1, H3D_OUT_NHWC_F32 = 2 };
 
 typedef struct h3d_op {

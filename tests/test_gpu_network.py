@@ -125,3 +125,28 @@ def test_detector_end_to_end_f32_indices_match_oracle():
     agree = (res["inds"].cpu().numpy() == oaux["inds"]).mean()
     assert agree > 0.9, agree
     assert res["results"].shape == (2, 50, 39)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+def test_fused_heads_match_per_head_convs(dtype, tol):
+    # fused heads kernel (csrc/heads.hip) vs one conv3x3 + conv1x1 launch pair per head, incl. the
+    # 72- and 10-channel SMPL heads and a map whose width is not a multiple of the 32-pixel tile
+    heads = dict(HEADS, pose=72, shape=10)
+    m, sd = _net(True, dtype, heads)
+    xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=11)).to(DEV)
+    fused = {k: v.clone() for k, v in m(xs)[0].items()}
+    eng = m.engine(xs.device)
+    eng.fuse_heads = False
+    eng.plans.clear()
+    plain = {k: v.clone() for k, v in m(xs)[0].items()}
+    eng.fuse_heads = True
+    eng.plans.clear()
+    for k in heads:
+        assert fused[k].shape == (2, heads[k], 24, 40)
+        e = float((fused[k] - plain[k]).abs().max())
+        assert e <= tol, (k, e)
+    if dtype == "f32":
+        with torch.no_grad():
+            ref = odla.DLAOracle(sd, heads, use_dcn=True)(xs.cpu())[0]
+        for k in heads:
+            np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=5e-4, err_msg=k)
