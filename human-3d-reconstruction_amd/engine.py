@@ -96,7 +96,7 @@ class PackedWeights:
             self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
         return self.t[key]
 
-    def heads(self):
+    def fused_heads(self):
         """Fused-heads pack: 3x3 weights of all heads stacked [nheads*head_conv][9][64]; per head the
         1x1 weights as [96 rows][head_conv] with K re-ordered to the MFMA accumulator row order
         (csrc/heads.hip): within every 32-channel group, position h*16 + r holds channel
@@ -288,7 +288,7 @@ class Plan:
         fused = (self.pw.head_conv > 0 and self.pw.head_conv % 64 == 0 and feat.C == 64 and
                  len(self.pw.heads) <= _lib.HEADS_MAX and max(self.pw.heads.values()) <= 96 and self.fuse_heads)
         if fused:
-            w1, b1, per = self.pw.heads()
+            w1, b1, per = self.pw.fused_heads()
             desc = _lib.H3dHeadsDesc()
             desc.nheads = len(per)
             for i, (head, c, w2, b2) in enumerate(per):
