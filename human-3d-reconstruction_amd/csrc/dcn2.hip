@@ -1,0 +1,337 @@
+// Network-path modulated deformable convolution, second generation (replaces dcn.hip's
+// dcn_kernel in the plan; that one stays as the simple reference implementation for tests).
+//
+// Reference semantics: DCNv2/src/cuda/dcn_v2_im2col_cuda.cu:25-54 (bilinear, zero corners),
+// :125-195 (positions, (>-1,<H) gate, val*mask), dcn_v2_cuda.cu:124-164 (bias + W.columns).
+//
+// What changed against generation one (profiles/r01_v1: 97 TFLOP/s, VALU- and L1-gather-bound):
+//  * the input tile + a MARGIN-pixel apron is staged ONCE per channel chunk in LDS, zero outside
+//    the image, so the 36 corner reads per output pixel hit LDS (256 B/clk/CU) instead of the
+//    vector L1 (64 B/clk/CU); samples whose corners leave the apron take a per-lane global path;
+//  * in bf16 mode the tile is converted to fp16 while staging and the 4-corner blend runs as
+//    v_pk_fma_f16 (2 channels per instruction, no bf16 unpack/pack): fp16 carries 11 significant
+//    bits, so the sampled operand is MORE precise than a bf16-rounded sample, and the f16 MFMA
+//    runs at the bf16 rate.  Weights of DCN layers are packed as fp16 by the host;
+//  * each lane blends exactly the 8 channels its MFMA B-fragment needs, for its own pixel, so the
+//    sampled tile never goes back to LDS and a tap costs no barrier: 2 barriers per chunk.
+//  * f32 (parity) mode keeps the reference's float operation order (sum of 4 products, then *mask).
+#include "common.h"
+#include "epilogue.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+
+template <typename T> struct SE;  // "sample element": type of the LDS halo, the blend and the MFMA operands
+
+template <> struct SE<float> {
+    using S = float;
+    static constexpr int SS = 4;
+    struct frag { f32x4 lo, hi; };
+    static __device__ __forceinline__ frag lds(const char *p)
+    {
+        frag f;
+        f.lo = *reinterpret_cast<const f32x4 *>(p);
+        f.hi = *reinterpret_cast<const f32x4 *>(p + 16);
+        return f;
+    }
+    static __device__ __forceinline__ frag zero() { frag f; f.lo = f32x4{0, 0, 0, 0}; f.hi = f.lo; return f; }
+    static __device__ __forceinline__ frag global8(const char *p) { return lds(p); }   // 8 floats
+    static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
+    {
+        ET<float>::frag fa, fb;
+        fa.lo = a.lo; fa.hi = a.hi; fb.lo = b.lo; fb.hi = b.hi;
+        ET<float>::mma(acc, fa, fb);
+    }
+    // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask
+    static __device__ __forceinline__ frag blend(const frag (&v)[4], const float (&w)[4], float mask)
+    {
+        frag o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o.lo[e] = (w[0] * v[0].lo[e] + w[1] * v[1].lo[e] + w[2] * v[2].lo[e] + w[3] * v[3].lo[e]) * mask;
+            o.hi[e] = (w[0] * v[0].hi[e] + w[1] * v[1].hi[e] + w[2] * v[2].hi[e] + w[3] * v[3].hi[e]) * mask;
+        }
+        return o;
+    }
+    // staging: 16 bytes of T=float -> 16 bytes of S
+    static __device__ __forceinline__ u32x4 convert16(u32x4 raw) { return raw; }
+};
+
+template <> struct SE<bf16_t> {
+    using S = _Float16;
+    static constexpr int SS = 2;
+    struct frag { half8_t v; };
+    static __device__ __forceinline__ frag lds(const char *p)
+    {
+        frag f;
+        f.v = *reinterpret_cast<const half8_t *>(p);
+        return f;
+    }
+    static __device__ __forceinline__ frag zero()
+    {
+        frag f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f.v[e] = (_Float16)0.f;
+        return f;
+    }
+    static __device__ __forceinline__ _Float16 cvt(uint32_t bits_hi)   // bf16 in the high half of an f32 pattern
+    {
+        const float x = __uint_as_float(bits_hi);
+        return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);           // no inf from bf16's wider range
+    }
+    static __device__ __forceinline__ u32x4 convert16(u32x4 raw)        // 8 bf16 -> 8 fp16
+    {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] = cvt(raw[e] << 16);
+            o[2 * e + 1] = cvt(raw[e] & 0xffff0000u);
+        }
+        return __builtin_bit_cast(u32x4, o);
+    }
+    static __device__ __forceinline__ frag global8(const char *p)       // 8 bf16 from global -> fp16
+    {
+        frag f;
+        f.v = __builtin_bit_cast(half8_t, convert16(*reinterpret_cast<const u32x4 *>(p)));
+        return f;
+    }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag blend(const frag (&v)[4], const float (&w)[4], float mask)
+    {
+        // mask folded into the fp32 corner weights, then one fp16 rounding per weight
+        const _Float16 w0 = (_Float16)(w[0] * mask), w1 = (_Float16)(w[1] * mask), w2 = (_Float16)(w[2] * mask),
+                       w3 = (_Float16)(w[3] * mask);
+        frag o;
+        o.v = v[0].v * w0 + v[1].v * w1 + v[2].v * w2 + v[3].v * w3;   // 4 x v_pk_{mul,fma}_f16 per 8 channels
+        return o;
+    }
+};
+
+struct Dcn2Args {
+    const char *in;
+    const char *w;     // [rows][9][Cin] of S (fp16 in bf16 mode, fp32 in f32 mode)
+    const float *bias;
+    const float *om;   // [B,H,W,om_cs] fp32: 0..17 offsets (2t = dh, 2t+1 = dw), 18..26 mask logits
+    char *out;
+    int B, H, W, Cin, in_cs, om_cs;
+    int Cout, out_cs, relu, out_mode;
+    int tiles_x, tiles_y;
+};
+
+template <typename T, int MT, int CK, int MARGIN>
+struct Dcn2Cfg {
+    static constexpr int ES = sizeof(T);
+    static constexpr int SS = SE<T>::SS;
+    static constexpr int HH = 16 + 2 + 2 * MARGIN;      // halo height = width
+    static constexpr int SBH = CK * SS + 16;            // halo pixel stride (bytes)
+    static constexpr int RBH = HH * SBH;
+    static constexpr int WB = 9 * CK * SS + 16;
+    static constexpr int BN = 32 * MT;
+    static constexpr int NT = 2;
+    static constexpr int VPP = CK * SS / 16;            // 16-byte vectors of S per pixel
+    static constexpr int LDS_H = HH * RBH;
+    static constexpr int LDS = LDS_H + BN * WB;
+};
+
+__device__ __forceinline__ float dcn2_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <typename T, int MT, int CK, int MARGIN>
+__global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
+{
+    using C = Dcn2Cfg<T, MT, CK, MARGIN>;
+    using X = SE<T>;
+    constexpr int ES = C::ES, SS = C::SS, NT = C::NT;
+    __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+    char *s_h = smem;
+    char *s_w = smem + C::LDS_H;
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int hy0 = oy0 - 1 - MARGIN, hx0 = ox0 - 1 - MARGIN;   // image coords of halo pixel (0,0)
+    const int cout0 = blockIdx.y * C::BN;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    // this lane's output pixel per N-tile, and its offset/mask row
+    int oy[NT], ox[NT];
+    const float *omp[NT];
+    bool live[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        oy[n] = oy0 + wv * 4 + n * 2 + (r >> 4);
+        ox[n] = ox0 + (r & 15);
+        live[n] = (oy[n] < a.H && ox[n] < a.W);
+        const int cy = live[n] ? oy[n] : 0, cx = live[n] ? ox[n] : 0;
+        omp[n] = a.om + ((size_t)(b * a.H + cy) * a.W + cx) * a.om_cs;
+    }
+    const char *img = a.in + (size_t)b * a.H * a.W * a.in_cs * ES;
+    const int aoff = r * C::WB + 8 * h * SS;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        __syncthreads();
+        // ---- stage halo chunk (converted to S, zero outside the image) ---------------------------
+        for (int i = tid; i < C::HH * C::HH * C::VPP; i += 256) {
+            const int v = i % C::VPP, pix = i / C::VPP;
+            const int iy = pix / C::HH, ix = pix - iy * C::HH;
+            const int gy = hy0 + iy, gx = hx0 + ix;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const char *src = img + ((size_t)(gy * a.W + gx) * a.in_cs + c0) * ES;
+                if constexpr (ES == SS) {
+                    val = X::convert16(*reinterpret_cast<const u32x4 *>(src + v * 16));
+                } else {
+                    static_assert(ES == SS, "staging assumes sizeof(T) == sizeof(S)");
+                }
+            }
+            *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + v * 16) = val;
+        }
+        // ---- stage weight chunk [BN][9][CK] of S ------------------------------------------------------
+        constexpr int WV = 9 * C::VPP;
+        for (int i = tid; i < C::BN * WV; i += 256) {
+            const int row = i / WV, q = i - row * WV;
+            const int tap = q / C::VPP, v = q - tap * C::VPP;
+            const u32x4 val = *reinterpret_cast<const u32x4 *>(
+                a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+            *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = val;
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ti = tap / 3, tj = tap - ti * 3;
+            typename X::frag fb[NT][CK / 16];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                // ---- sampling geometry of (pixel, tap): the reference's float arithmetic ------------
+                float w4[4] = {0.f, 0.f, 0.f, 0.f};
+                float mask = 0.f;
+                int hl = 0, wl = 0;
+                bool inside = false;
+                if (live[n]) {
+                    const float h_im = (float)(oy[n] - 1 + ti) + omp[n][2 * tap];
+                    const float w_im = (float)(ox[n] - 1 + tj) + omp[n][2 * tap + 1];
+                    inside = (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
+                    if (inside) {
+                        mask = dcn2_sigmoid(omp[n][18 + tap]);
+                        hl = (int)floorf(h_im);
+                        wl = (int)floorf(w_im);
+                        const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        w4[0] = hh * hw; w4[1] = hh * lw; w4[2] = lh * hw; w4[3] = lh * lw;
+                    }
+                }
+                // all four corners inside the staged apron? (rows hl, hl+1; cols wl, wl+1)
+                const int ry = hl - hy0, rx = wl - hx0;
+                const bool in_halo = (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH);
+                if (!inside) {
+#pragma unroll
+                    for (int kk = 0; kk < CK / 16; ++kk) fb[n][kk] = X::zero();
+                } else if (in_halo) {
+                    const char *p00 = s_h + ry * C::RBH + rx * C::SBH + 8 * h * SS;
+#pragma unroll
+                    for (int kk = 0; kk < CK / 16; ++kk) {
+                        typename X::frag v[4];
+                        v[0] = X::lds(p00 + kk * 16 * SS);
+                        v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
+                        v[2] = X::lds(p00 + C::RBH + kk * 16 * SS);
+                        v[3] = X::lds(p00 + C::RBH + C::SBH + kk * 16 * SS);
+                        fb[n][kk] = X::blend(v, w4, mask);
+                    }
+                } else {
+                    // per-lane global path: corners outside the image contribute zero
+                    const bool okh0 = hl >= 0, okh1 = hl + 1 <= a.H - 1, okw0 = wl >= 0, okw1 = wl + 1 <= a.W - 1;
+                    const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+                    const int pix[4] = {hl * a.W + wl, hl * a.W + wl + 1, (hl + 1) * a.W + wl, (hl + 1) * a.W + wl + 1};
+#pragma unroll
+                    for (int kk = 0; kk < CK / 16; ++kk) {
+                        typename X::frag v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            v[k] = ok[k] ? X::global8(img + ((size_t)pix[k] * a.in_cs + c0 + kk * 16 + 8 * h) * ES) : X::zero();
+                        fb[n][kk] = X::blend(v, w4, mask);
+                    }
+                }
+            }
+            // ---- contraction of this tap ------------------------------------------------------------
+#pragma unroll
+            for (int kk = 0; kk < CK / 16; ++kk) {
+                typename X::frag fa[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) X::mma(acc[m][n], fa[m], fb[n][kk]);
+            }
+        }
+    }
+    EpiArgs e;
+    e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
+    e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
+    tile_epilogue<T, MT, NT>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+}
+
+template <typename T, int MT, int CK, int MARGIN>
+static int launch_dcn2_cfg(const Dcn2Args &a0, hipStream_t st)
+{
+    using C = Dcn2Cfg<T, MT, CK, MARGIN>;
+    static_assert(C::LDS <= 160 * 1024, "LDS budget");
+    Dcn2Args a = a0;
+    a.tiles_x = cdiv(a.W, 16);
+    a.tiles_y = cdiv(a.H, 16);
+    dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
+    if (h3d_note_kernel("dcn2_kernel<%s, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN))
+        return H3D_OK;
+    hipLaunchKernelGGL((dcn2_kernel<T, MT, CK, MARGIN>), grid, dim3(256), 0, st, a);
+    H3D_CHECK_LAUNCH("dcn2_kernel");
+    return H3D_OK;
+}
+
+int h3d_launch_dcn2(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.w || !op.bias || !op.out || !op.in2) H3D_FAIL(H3D_ERR_ARG, "dcn: null pointer");
+    const int es = op.dtype == H3D_BF16 ? 2 : 4;
+    if (op.ksize != 3 || op.stride != 1 || op.Ho != op.H || op.Wo != op.W)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn op: network path covers 3x3 s1 p1 d1 dg1 only (k=%d s=%d)", op.ksize, op.stride);
+    if (op.Cin % 16 || op.in_cs % (16 / es) || op.Cin > op.in_cs || op.in2_cs < 27)
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn: Cin=%d (stride %d) must be a multiple of 16; offset stride %d >= 27", op.Cin,
+                 op.in_cs, op.in2_cs);
+    if (op.wrows < ((op.Cout + 127) / 128) * 128)
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn: packed weight rows %d < Cout %d padded to 128", op.wrows, op.Cout);
+    if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn: out channel stride %d", op.out_cs);
+    if ((long)op.H * op.W > (1L << 30)) H3D_FAIL(H3D_ERR_SHAPE, "dcn: image too large");
+    Dcn2Args a;
+    a.in = (const char *)op.in; a.w = (const char *)op.w; a.bias = op.bias; a.om = (const float *)op.in2;
+    a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
+    a.om_cs = op.in2_cs; a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode;
+    a.tiles_x = a.tiles_y = 0;
+    if (op.dtype == H3D_BF16) {
+        if (op.Cin % 32 == 0 && op.Cout <= 64) {
+            if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 32, 2>(a, st);
+            return launch_dcn2_cfg<bf16_t, 2, 32, 2>(a, st);
+        }
+        if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 16, 2>(a, st);
+        if (op.Cout <= 64) return launch_dcn2_cfg<bf16_t, 2, 16, 2>(a, st);
+        return launch_dcn2_cfg<bf16_t, 4, 16, 2>(a, st);
+    }
+    if (op.dtype == H3D_F32) {
+        if (op.Cout <= 32) return launch_dcn2_cfg<float, 1, 16, 2>(a, st);
+        return launch_dcn2_cfg<float, 2, 16, 2>(a, st);
+    }
+    H3D_FAIL(H3D_ERR_DTYPE, "dcn: dtype %d", op.dtype);
+}

@@ -73,9 +73,10 @@ class PackedWeights:
         b2 = ((b.double() - sd[bn + ".running_mean"].double()) * scale + sd[bn + ".bias"].double()).float()
         return w2, b2
 
-    def conv(self, wkey, bkey=None, bn=None, pad_cout_to=None):
-        """-> (packed weights [rows][kh*kw][Cin], bias fp32 [rows], Cout, Cin, k)."""
-        key = ("conv", wkey, bn, pad_cout_to)
+    def conv(self, wkey, bkey=None, bn=None, pad_cout_to=None, as_half=False):
+        """-> (packed weights [rows][kh*kw][Cin], bias fp32 [rows], Cout, Cin, k).
+        as_half: store fp16 instead of bf16 (DCN layers in bf16 mode, csrc/dcn2.hip)."""
+        key = ("conv", wkey, bn, pad_cout_to, as_half)
         if key not in self.t:
             w, b = self._fold(self.sd[wkey], self.sd[bkey] if bkey else None, bn)
             co, ci, kh, kw = w.shape
@@ -85,7 +86,8 @@ class PackedWeights:
             wp[:co] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
             bp = torch.zeros(rows)
             bp[:co] = b
-            self.t[key] = (wp.to(_TORCH_DT[self.dtype]).contiguous().to(self.device),
+            td = torch.float16 if (as_half and self.dtype == "bf16") else _TORCH_DT[self.dtype]
+            self.t[key] = (wp.to(td).contiguous().to(self.device),
                            bp.contiguous().to(self.device), cout, ci, kh, rows)
         return self.t[key]
 
@@ -185,7 +187,7 @@ class Plan:
         return out
 
     def dcn(self, x, om, wkey, bkey, bn, out=None):
-        wp, bp, cout, cin, k, rows = self.pw.conv(wkey, bkey, bn)
+        wp, bp, cout, cin, k, rows = self.pw.conv(wkey, bkey, bn, as_half=True)
         assert cin == x.C and k == 3
         if out is None:
             out = self._alloc(x.H, x.W, cout)

@@ -69,10 +69,12 @@ int h3d_dcn_v2_forward(const float *input, const float *weight, const float *bia
 enum {
     H3D_OP_STEM = 1,    /* base_layer 7x7 3->C0 conv+BN+ReLU from NCHW fp32 images (model.py:231-235) */
     H3D_OP_CONV = 2,    /* kxk (k=1|3, stride 1|2, pad k/2) conv + bias [+residual] [+ReLU]            */
-    H3D_OP_DCN = 3,     /* modulated deformable 3x3 s1 p1 d1 dg1 conv + bias [+ReLU] (model.py:346-362) */
+    H3D_OP_DCN = 3,     /* modulated deformable 3x3 s1 p1 d1 dg1 conv + bias [+ReLU] (model.py:346-362);
+                           weights [rows][9][Cin] are fp16 when dtype = bf16 (csrc/dcn2.hip), fp32 otherwise */
     H3D_OP_MAXPOOL = 4, /* 2x2 stride-2 max pool (Tree.downsample, model.py:200-201)                   */
     H3D_OP_UPADD = 5,   /* depthwise ConvTranspose2d(k=2f,s=f,p=f/2) + skip add (IDAUp, model.py:375-390) */
     H3D_OP_COPY = 6,    /* strided NHWC copy (y[i] = x[i].clone(), model.py:480-482)                   */
+    H3D_OP_DCN_V1 = 8,  /* first-generation DCN kernel (global gather, bf16 weights): kept as an A/B reference */
     H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
                            (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */
 };

@@ -100,25 +100,30 @@ def test_dcn_module_fresh_is_half_conv():
 NET_CASES = [(2, 64, 64, 16, 16), (1, 128, 64, 24, 40), (1, 256, 128, 16, 16), (1, 512, 256, 8, 8), (1, 32, 16, 20, 20)]
 
 
+@pytest.mark.parametrize("kind", ["dcn2", "dcn_v1"])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", NET_CASES)
-def test_network_dcn_op_vs_oracle(case, dtype):
+def test_network_dcn_op_vs_oracle(case, dtype, kind):
     B, Ci, Co, H, W = case
     x = rnd("x", (B, Ci, H, W))
     w = rnd("w", (Co, Ci, 3, 3)) * (1.5 / np.sqrt(Ci * 9))
     b = rnd("b", (Co,))
     om = rnd("om", (B, 27, H, W), -2.5, 2.5)          # raw conv_offset_mask output
     om[:, :18, :2, :] *= 4.0                              # some samples far outside the image
+    half_w = (dtype == "bf16" and kind == "dcn2")            # generation-2 kernel: fp16 weights + fp16 blend
     if dtype == "bf16":
-        x, w = bf16_round(x), bf16_round(w)
+        x = bf16_round(x)
+        w = w.half().float() if half_w else bf16_round(w)
     offset, mask = om[:, :18].contiguous(), torch.sigmoid(om[:, 18:]).contiguous()
     ref = F.relu(odcn.dcn_v2_forward(x, w, b, offset, mask, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64))
     xb, xp = nhwc(x, dtype)
     omb = torch.zeros(B, H, W, 32, dtype=torch.float32, device=DEV)
     omb[..., :27] = om.permute(0, 2, 3, 1).to(DEV)
     wp, bp, cout, rows = pack_conv(w, b, dtype)
+    if half_w:
+        wp = pack_conv(w, b, "f32")[0].half()
     out = torch.zeros(B, H, W, Co, dtype=TD[dtype], device=DEV)
-    run(mk(_lib.OP_DCN, dtype, in_=xp, in2=omb.data_ptr(), w=wp.data_ptr(), bias=bp.data_ptr(), out=out.data_ptr(), B=B,
+    run(mk(_lib.OP_DCN if kind == "dcn2" else _lib.OP_DCN_V1, dtype, in_=xp, in2=omb.data_ptr(), w=wp.data_ptr(), bias=bp.data_ptr(), out=out.data_ptr(), B=B,
            H=H, W=W, Cin=Ci, in_cs=Ci, in2_cs=32, Ho=H, Wo=W, Cout=Co, out_cs=Co, ksize=3, stride=1, relu=1,
            out_mode=_lib.OUT_NHWC, wrows=rows))
     got = from_nhwc(out, Co)
