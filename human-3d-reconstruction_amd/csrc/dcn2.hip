@@ -42,6 +42,14 @@ template <> struct SE<float> {
         fa.lo = a.lo; fa.hi = a.hi; fb.lo = b.lo; fb.hi = b.hi;
         ET<float>::mma(acc, fa, fb);
     }
+    struct geo { float w[4]; float mask; };     // per (pixel, tap) blend coefficients kept in registers
+    static __device__ __forceinline__ geo make_geo(const float (&w)[4], float mask)
+    {
+        geo g;
+        g.w[0] = w[0]; g.w[1] = w[1]; g.w[2] = w[2]; g.w[3] = w[3]; g.mask = mask;
+        return g;
+    }
+    static __device__ __forceinline__ frag blend(const frag (&v)[4], const geo &g) { return blend(v, g.w, g.mask); }
     // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask
     static __device__ __forceinline__ frag blend(const frag (&v)[4], const float (&w)[4], float mask)
     {
@@ -99,13 +107,18 @@ template <> struct SE<bf16_t> {
     {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, acc, 0, 0, 0);
     }
-    static __device__ __forceinline__ frag blend(const frag (&v)[4], const float (&w)[4], float mask)
+    struct geo { half2_t w01, w23; };           // mask folded into the fp32 corner weights, one fp16 rounding each
+    static __device__ __forceinline__ geo make_geo(const float (&w)[4], float mask)
     {
-        // mask folded into the fp32 corner weights, then one fp16 rounding per weight
-        const _Float16 w0 = (_Float16)(w[0] * mask), w1 = (_Float16)(w[1] * mask), w2 = (_Float16)(w[2] * mask),
-                       w3 = (_Float16)(w[3] * mask);
+        geo g;
+        g.w01 = half2_t{(_Float16)(w[0] * mask), (_Float16)(w[1] * mask)};
+        g.w23 = half2_t{(_Float16)(w[2] * mask), (_Float16)(w[3] * mask)};
+        return g;
+    }
+    static __device__ __forceinline__ frag blend(const frag (&v)[4], const geo &g)
+    {
         frag o;
-        o.v = v[0].v * w0 + v[1].v * w1 + v[2].v * w2 + v[3].v * w3;   // 4 x v_pk_{mul,fma}_f16 per 8 channels
+        o.v = v[0].v * g.w01[0] + v[1].v * g.w01[1] + v[2].v * g.w23[0] + v[3].v * g.w23[1];   // 4 v_pk_{mul,fma}_f16 / dword
         return o;
     }
 };
@@ -166,20 +179,46 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-    // this lane's output pixel per N-tile, and its offset/mask row
-    int oy[NT], ox[NT];
-    const float *omp[NT];
-    bool live[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        oy[n] = oy0 + wv * 4 + n * 2 + (r >> 4);
-        ox[n] = ox0 + (r & 15);
-        live[n] = (oy[n] < a.H && ox[n] < a.W);
-        const int cy = live[n] ? oy[n] : 0, cx = live[n] ? ox[n] : 0;
-        omp[n] = a.om + ((size_t)(b * a.H + cy) * a.W + cx) * a.om_cs;
-    }
     const char *img = a.in + (size_t)b * a.H * a.W * a.in_cs * ES;
     const int aoff = r * C::WB + 8 * h * SS;
+
+    // ---- sampling geometry of every (pixel, tap) of this lane, ONCE per workgroup: the reference's
+    //      float arithmetic (im2col.cu:163-185).  pos = (h_low << 16) | (w_low & 0xffff); a sample that
+    //      fails the (>-1, <H) gate gets zero coefficients and pos inside the apron (no branch later).
+    int pos[NT][9];
+    typename X::geo geo[NT][9];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int oy = oy0 + wv * 4 + n * 2 + (r >> 4), ox = ox0 + (r & 15);
+        const bool live = (oy < a.H && ox < a.W);
+        const float *omp = a.om + ((size_t)(b * a.H + (live ? oy : 0)) * a.W + (live ? ox : 0)) * a.om_cs;
+        float omv[28];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(omp + 4 * q);   // om_cs >= 28 and 16-byte aligned rows
+            omv[4 * q] = v[0]; omv[4 * q + 1] = v[1]; omv[4 * q + 2] = v[2]; omv[4 * q + 3] = v[3];
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ti = tap / 3, tj = tap - ti * 3;
+            const float h_im = (float)(oy - 1 + ti) + omv[2 * tap];
+            const float w_im = (float)(ox - 1 + tj) + omv[2 * tap + 1];
+            const bool inside = live && (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
+            float w4[4] = {0.f, 0.f, 0.f, 0.f};
+            float mask = 0.f;
+            int hl = oy, wl = ox;
+            if (inside) {
+                mask = dcn2_sigmoid(omv[18 + tap]);
+                hl = (int)floorf(h_im);
+                wl = (int)floorf(w_im);
+                const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                w4[0] = hh * hw; w4[1] = hh * lw; w4[2] = lh * hw; w4[3] = lh * lw;
+            }
+            pos[n][tap] = (hl << 16) | (wl & 0xffff);
+            geo[n][tap] = X::make_geo(w4, mask);
+        }
+    }
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();
@@ -189,14 +228,8 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
             const int iy = pix / C::HH, ix = pix - iy * C::HH;
             const int gy = hy0 + iy, gx = hx0 + ix;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                const char *src = img + ((size_t)(gy * a.W + gx) * a.in_cs + c0) * ES;
-                if constexpr (ES == SS) {
-                    val = X::convert16(*reinterpret_cast<const u32x4 *>(src + v * 16));
-                } else {
-                    static_assert(ES == SS, "staging assumes sizeof(T) == sizeof(S)");
-                }
-            }
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                val = X::convert16(*reinterpret_cast<const u32x4 *>(img + ((size_t)(gy * a.W + gx) * a.in_cs + c0) * ES + v * 16));
             *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + v * 16) = val;
         }
         // ---- stage weight chunk [BN][9][CK] of S ------------------------------------------------------
@@ -210,37 +243,19 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
         }
         __syncthreads();
 
-#pragma unroll 1
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int ti = tap / 3, tj = tap - ti * 3;
             typename X::frag fb[NT][CK / 16];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                // ---- sampling geometry of (pixel, tap): the reference's float arithmetic ------------
-                float w4[4] = {0.f, 0.f, 0.f, 0.f};
-                float mask = 0.f;
-                int hl = 0, wl = 0;
-                bool inside = false;
-                if (live[n]) {
-                    const float h_im = (float)(oy[n] - 1 + ti) + omp[n][2 * tap];
-                    const float w_im = (float)(ox[n] - 1 + tj) + omp[n][2 * tap + 1];
-                    inside = (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
-                    if (inside) {
-                        mask = dcn2_sigmoid(omp[n][18 + tap]);
-                        hl = (int)floorf(h_im);
-                        wl = (int)floorf(w_im);
-                        const float lh = h_im - (float)hl, lw = w_im - (float)wl;
-                        const float hh = 1.f - lh, hw = 1.f - lw;
-                        w4[0] = hh * hw; w4[1] = hh * lw; w4[2] = lh * hw; w4[3] = lh * lw;
-                    }
-                }
+                int pv = pos[n][tap];
+                asm volatile("" : "+v"(pv));   // opaque per chunk: stops LICM from hoisting 18 taps' worth of
+                                               // corner addresses out of the channel loop (register spills)
+                const int hl = pv >> 16, wl = (int)(short)(pv & 0xffff);
                 // all four corners inside the staged apron? (rows hl, hl+1; cols wl, wl+1)
                 const int ry = hl - hy0, rx = wl - hx0;
                 const bool in_halo = (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH);
-                if (!inside) {
-#pragma unroll
-                    for (int kk = 0; kk < CK / 16; ++kk) fb[n][kk] = X::zero();
-                } else if (in_halo) {
+                if (in_halo) {
                     const char *p00 = s_h + ry * C::RBH + rx * C::SBH + 8 * h * SS;
 #pragma unroll
                     for (int kk = 0; kk < CK / 16; ++kk) {
@@ -249,11 +264,12 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
                         v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
                         v[2] = X::lds(p00 + C::RBH + kk * 16 * SS);
                         v[3] = X::lds(p00 + C::RBH + C::SBH + kk * 16 * SS);
-                        fb[n][kk] = X::blend(v, w4, mask);
+                        fb[n][kk] = X::blend(v, geo[n][tap]);
                     }
                 } else {
                     // per-lane global path: corners outside the image contribute zero
-                    const bool okh0 = hl >= 0, okh1 = hl + 1 <= a.H - 1, okw0 = wl >= 0, okw1 = wl + 1 <= a.W - 1;
+                    const bool okh0 = hl >= 0 && hl <= a.H - 1, okh1 = hl + 1 >= 0 && hl + 1 <= a.H - 1;
+                    const bool okw0 = wl >= 0 && wl <= a.W - 1, okw1 = wl + 1 >= 0 && wl + 1 <= a.W - 1;
                     const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
                     const int pix[4] = {hl * a.W + wl, hl * a.W + wl + 1, (hl + 1) * a.W + wl, (hl + 1) * a.W + wl + 1};
 #pragma unroll
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             v[k] = ok[k] ? X::global8(img + ((size_t)pix[k] * a.in_cs + c0 + kk * 16 + 8 * h) * ES) : X::zero();
-                        fb[n][kk] = X::blend(v, w4, mask);
+                        fb[n][kk] = X::blend(v, geo[n][tap]);
                     }
                 }
             }
@@ -277,6 +293,7 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) X::mma(acc[m][n], fa[m], fb[n][kk]);
             }
+            __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every tap's gathers (spills)
         }
     }
     EpiArgs e;
@@ -307,9 +324,10 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st)
     const int es = op.dtype == H3D_BF16 ? 2 : 4;
     if (op.ksize != 3 || op.stride != 1 || op.Ho != op.H || op.Wo != op.W)
         H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn op: network path covers 3x3 s1 p1 d1 dg1 only (k=%d s=%d)", op.ksize, op.stride);
-    if (op.Cin % 16 || op.in_cs % (16 / es) || op.Cin > op.in_cs || op.in2_cs < 27)
-        H3D_FAIL(H3D_ERR_SHAPE, "dcn: Cin=%d (stride %d) must be a multiple of 16; offset stride %d >= 27", op.Cin,
-                 op.in_cs, op.in2_cs);
+    if (op.Cin % 16 || op.in_cs % (16 / es) || op.Cin > op.in_cs || op.in2_cs < 28 || op.in2_cs % 4)
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn: Cin=%d (stride %d) must be a multiple of 16; offset stride %d must be a multiple of 4, >= 28",
+                 op.Cin, op.in_cs, op.in2_cs);
+    if (op.H > 32767 || op.W > 32767) H3D_FAIL(H3D_ERR_SHAPE, "dcn: image larger than 32767");
     if (op.wrows < ((op.Cout + 127) / 128) * 128)
         H3D_FAIL(H3D_ERR_SHAPE, "dcn: packed weight rows %d < Cout %d padded to 128", op.wrows, op.Cout);
     if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
