@@ -121,4 +121,30 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t *p, float
     o[3] = __uint_as_float(v[1] & 0xffff0000u);
 }
 
+// Cooperative global -> LDS staging of TOTAL 16-byte vectors by NTHREADS threads: ALL loads are
+// issued before the first LDS store, so the vector-memory latency is paid once per stage instead
+// of once per vector (a plain `for (i = tid; ...) lds[i] = g[i]` loop serialises on s_waitcnt).
+template <int TOTAL, int NTHREADS, int MAXB = 16, typename LD, typename ST>
+__device__ __forceinline__ void stage_vectors(int tid, LD ld, ST st)
+{
+    constexpr int N = (TOTAL + NTHREADS - 1) / NTHREADS;   // vectors per thread
+    constexpr int NB = (N + MAXB - 1) / MAXB;              // batches (bounds the staging registers)
+    constexpr int PER = (N + NB - 1) / NB;
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+        u32x4 tmp[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + (bt * PER + j) * NTHREADS;
+            tmp[j] = u32x4{0u, 0u, 0u, 0u};
+            if (bt * PER + j < N && i < TOTAL) tmp[j] = ld(i);
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + (bt * PER + j) * NTHREADS;
+            if (bt * PER + j < N && i < TOTAL) st(i, tmp[j]);
+        }
+    }
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -87,26 +87,40 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a)
     const size_t in_img = (size_t)b * a.H * a.W;
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         if (c0) __syncthreads();
-        // ---- stage the input halo chunk [IN_H][IN_W][CK] (zero outside the image) -------------
-        for (int i = tid; i < C::IN_H * C::IN_W * C::VPP; i += 256) {
-            const int v = i % C::VPP, pix = i / C::VPP;
-            const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
-            const int gy = oy0 * STRIDE - C::PAD + iy, gx = ox0 * STRIDE - C::PAD + ix;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                val = *reinterpret_cast<const u32x4 *>(
-                    a.in + ((in_img + (size_t)gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
-            *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = val;
-        }
-        // ---- stage the weight chunk [BN][KS*KS][CK] --------------------------------------------
+        // ---- stage the input halo chunk [IN_H][IN_W][CK] (zero outside the image) and the weight
+        //      chunk [BN][KS*KS][CK]: every load of the stage is in flight before the first LDS store
         constexpr int WV = KS * KS * C::VPP;
-        for (int i = tid; i < C::BN * WV; i += 256) {
-            const int row = i / WV, q = i - row * WV;
-            const int tap = q / C::VPP, v = q - tap * C::VPP;
-            const u32x4 val = *reinterpret_cast<const u32x4 *>(
-                a.w + (((size_t)(cout0 + row) * (KS * KS) + tap) * a.Cin + c0) * ES + v * 16);
-            *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * ES + v * 16) = val;
-        }
+        constexpr int NH = C::IN_H * C::IN_W * C::VPP, NW = C::BN * WV;
+        stage_vectors<NH + NW, 256>(
+            tid,
+            [&](int i) -> u32x4 {
+                if (i < NH) {
+                    const int v = i % C::VPP, pix = i / C::VPP;
+                    const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
+                    const int gy = oy0 * STRIDE - C::PAD + iy, gx = ox0 * STRIDE - C::PAD + ix;
+                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                        return *reinterpret_cast<const u32x4 *>(
+                            a.in + ((in_img + (size_t)gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
+                    return u32x4{0u, 0u, 0u, 0u};
+                }
+                const int q0 = i - NH;
+                const int row = q0 / WV, q = q0 - row * WV;
+                const int tap = q / C::VPP, v = q - tap * C::VPP;
+                return *reinterpret_cast<const u32x4 *>(
+                    a.w + (((size_t)(cout0 + row) * (KS * KS) + tap) * a.Cin + c0) * ES + v * 16);
+            },
+            [&](int i, u32x4 val) {
+                if (i < NH) {
+                    const int v = i % C::VPP, pix = i / C::VPP;
+                    const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
+                    *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = val;
+                } else {
+                    const int q0 = i - NH;
+                    const int row = q0 / WV, q = q0 - row * WV;
+                    const int tap = q / C::VPP, v = q - tap * C::VPP;
+                    *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * ES + v * 16) = val;
+                }
+            });
         __syncthreads();
         // ---- contraction over this chunk: taps x CK/16 k-steps -------------------------------------
 #pragma unroll

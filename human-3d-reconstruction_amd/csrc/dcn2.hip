@@ -134,7 +134,7 @@ struct Dcn2Args {
     int tiles_x, tiles_y;
 };
 
-template <typename T, int MT, int CK, int MARGIN>
+template <typename T, int MT, int CK, int MARGIN, int NT_>
 struct Dcn2Cfg {
     static constexpr int ES = sizeof(T);
     static constexpr int SS = SE<T>::SS;
@@ -143,7 +143,9 @@ struct Dcn2Cfg {
     static constexpr int RBH = HH * SBH;
     static constexpr int WB = 9 * CK * SS + 16;
     static constexpr int BN = 32 * MT;
-    static constexpr int NT = 2;
+    static constexpr int NT = NT_;                      // N-tiles (2 rows x 16 px) per wave
+    static constexpr int WAVES = 8 / NT_;               // 16 tile rows = WAVES * NT * 2
+    static constexpr int THREADS = 64 * WAVES;
     static constexpr int VPP = CK * SS / 16;            // 16-byte vectors of S per pixel
     static constexpr int LDS_H = HH * RBH;
     static constexpr int LDS = LDS_H + BN * WB;
@@ -151,10 +153,10 @@ struct Dcn2Cfg {
 
 __device__ __forceinline__ float dcn2_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 
-template <typename T, int MT, int CK, int MARGIN>
-__global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
+template <typename T, int MT, int CK, int MARGIN, int NT_>
+__global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
 {
-    using C = Dcn2Cfg<T, MT, CK, MARGIN>;
+    using C = Dcn2Cfg<T, MT, CK, MARGIN, NT_>;
     using X = SE<T>;
     constexpr int ES = C::ES, SS = C::SS, NT = C::NT;
     __shared__ __attribute__((aligned(16))) char smem[C::LDS];
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
     typename X::geo geo[NT][9];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-        const int oy = oy0 + wv * 4 + n * 2 + (r >> 4), ox = ox0 + (r & 15);
+        const int oy = oy0 + wv * (2 * NT) + n * 2 + (r >> 4), ox = ox0 + (r & 15);
         const bool live = (oy < a.H && ox < a.W);
         const float *omp = a.om + ((size_t)(b * a.H + (live ? oy : 0)) * a.W + (live ? ox : 0)) * a.om_cs;
         float omv[28];
@@ -222,25 +224,38 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();
-        // ---- stage halo chunk (converted to S, zero outside the image) ---------------------------
-        for (int i = tid; i < C::HH * C::HH * C::VPP; i += 256) {
-            const int v = i % C::VPP, pix = i / C::VPP;
-            const int iy = pix / C::HH, ix = pix - iy * C::HH;
-            const int gy = hy0 + iy, gx = hx0 + ix;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                val = X::convert16(*reinterpret_cast<const u32x4 *>(img + ((size_t)(gy * a.W + gx) * a.in_cs + c0) * ES + v * 16));
-            *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + v * 16) = val;
-        }
-        // ---- stage weight chunk [BN][9][CK] of S ------------------------------------------------------
+        // ---- stage halo chunk (converted to S, zero outside the image) + weight chunk [BN][9][CK] of S;
+        //      all loads in flight before the first LDS store ------------------------------------------
         constexpr int WV = 9 * C::VPP;
-        for (int i = tid; i < C::BN * WV; i += 256) {
-            const int row = i / WV, q = i - row * WV;
-            const int tap = q / C::VPP, v = q - tap * C::VPP;
-            const u32x4 val = *reinterpret_cast<const u32x4 *>(
-                a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
-            *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = val;
-        }
+        constexpr int NH = C::HH * C::HH * C::VPP, NW = C::BN * WV;
+        stage_vectors<NH + NW, C::THREADS, 6>(
+            tid,
+            [&](int i) -> u32x4 {
+                if (i < NH) {
+                    const int v = i % C::VPP, pix = i / C::VPP;
+                    const int iy = pix / C::HH, ix = pix - iy * C::HH;
+                    const int gy = hy0 + iy, gx = hx0 + ix;
+                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                        return *reinterpret_cast<const u32x4 *>(img + ((size_t)(gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
+                    return u32x4{0u, 0u, 0u, 0u};
+                }
+                const int q0 = i - NH;
+                const int row = q0 / WV, q = q0 - row * WV;
+                const int tap = q / C::VPP, v = q - tap * C::VPP;
+                return *reinterpret_cast<const u32x4 *>(a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+            },
+            [&](int i, u32x4 val) {
+                if (i < NH) {
+                    const int v = i % C::VPP, pix = i / C::VPP;
+                    const int iy = pix / C::HH, ix = pix - iy * C::HH;
+                    *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + v * 16) = X::convert16(val);
+                } else {
+                    const int q0 = i - NH;
+                    const int row = q0 / WV, q = q0 - row * WV;
+                    const int tap = q / C::VPP, v = q - tap * C::VPP;
+                    *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = val;
+                }
+            });
         __syncthreads();
 
 #pragma unroll
@@ -302,18 +317,18 @@ __global__ __launch_bounds__(256) void dcn2_kernel(Dcn2Args a)
     tile_epilogue<T, MT, NT>(acc, e, b, oy0, ox0, cout0, wv, r, h);
 }
 
-template <typename T, int MT, int CK, int MARGIN>
+template <typename T, int MT, int CK, int MARGIN, int NT_>
 static int launch_dcn2_cfg(const Dcn2Args &a0, hipStream_t st)
 {
-    using C = Dcn2Cfg<T, MT, CK, MARGIN>;
+    using C = Dcn2Cfg<T, MT, CK, MARGIN, NT_>;
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     Dcn2Args a = a0;
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
-    if (h3d_note_kernel("dcn2_kernel<%s, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN))
+    if (h3d_note_kernel("dcn2_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN, NT_))
         return H3D_OK;
-    hipLaunchKernelGGL((dcn2_kernel<T, MT, CK, MARGIN>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((dcn2_kernel<T, MT, CK, MARGIN, NT_>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("dcn2_kernel");
     return H3D_OK;
 }
@@ -340,16 +355,16 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st)
     a.tiles_x = a.tiles_y = 0;
     if (op.dtype == H3D_BF16) {
         if (op.Cin % 32 == 0 && op.Cout <= 64) {
-            if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 32, 2>(a, st);
-            return launch_dcn2_cfg<bf16_t, 2, 32, 2>(a, st);
+            if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 32, 2, 2>(a, st);
+            return launch_dcn2_cfg<bf16_t, 2, 32, 2, 2>(a, st);
         }
-        if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 16, 2>(a, st);
-        if (op.Cout <= 64) return launch_dcn2_cfg<bf16_t, 2, 16, 2>(a, st);
-        return launch_dcn2_cfg<bf16_t, 4, 16, 2>(a, st);
+        if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 16, 2, 2>(a, st);
+        if (op.Cout <= 64) return launch_dcn2_cfg<bf16_t, 2, 16, 2, 2>(a, st);
+        return launch_dcn2_cfg<bf16_t, 4, 16, 2, 1>(a, st);      // 8 waves x (32 px x 128 ch)
     }
     if (op.dtype == H3D_F32) {
-        if (op.Cout <= 32) return launch_dcn2_cfg<float, 1, 16, 2>(a, st);
-        return launch_dcn2_cfg<float, 2, 16, 2>(a, st);
+        if (op.Cout <= 32) return launch_dcn2_cfg<float, 1, 16, 2, 1>(a, st);
+        return launch_dcn2_cfg<float, 2, 16, 2, 1>(a, st);
     }
     H3D_FAIL(H3D_ERR_DTYPE, "dcn: dtype %d", op.dtype);
 }

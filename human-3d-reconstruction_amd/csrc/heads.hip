@@ -164,14 +164,30 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     prefetch(0);
     {
         const size_t in_img = (size_t)b * a.H * a.W;
-        for (int i = tid; i < C::IN_H * C::IN_W * C::VPR; i += 512) {
-            const int v = i % C::VPR, pix = i / C::VPR;
-            const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
-            const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                val = *reinterpret_cast<const u32x4 *>(a.in + ((in_img + (size_t)gy * a.W + gx) * a.in_cs) * ES + v * 16);
-            *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = val;
+        constexpr int NHV = C::IN_H * C::IN_W * C::VPR;
+        constexpr int HALF = (NHV + 1) / 2;                 // two batches bound the staging registers
+        for (int part = 0; part < 2; ++part) {
+            const int base = part * HALF;
+            stage_vectors<HALF, 512>(
+                tid,
+                [&](int j) -> u32x4 {
+                    const int i = base + j;
+                    if (i >= NHV) return u32x4{0u, 0u, 0u, 0u};
+                    const int v = i % C::VPR, pix = i / C::VPR;
+                    const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
+                    const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                        return *reinterpret_cast<const u32x4 *>(a.in + ((in_img + (size_t)gy * a.W + gx) * a.in_cs) * ES + v * 16);
+                    return u32x4{0u, 0u, 0u, 0u};
+                },
+                [&](int j, u32x4 val) {
+                    const int i = base + j;
+                    if (i < NHV) {
+                        const int v = i % C::VPR, pix = i / C::VPR;
+                        const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
+                        *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = val;
+                    }
+                });
         }
     }
     commit(0);
