@@ -49,6 +49,7 @@ template <> struct SE<float> {
         g.w[0] = w[0]; g.w[1] = w[1]; g.w[2] = w[2]; g.w[3] = w[3]; g.mask = mask;
         return g;
     }
+    static __device__ __forceinline__ geo zero_geo() { geo g; g.w[0] = g.w[1] = g.w[2] = g.w[3] = 0.f; g.mask = 0.f; return g; }
     static __device__ __forceinline__ frag blend(const frag (&v)[4], const geo &g) { return blend(v, g.w, g.mask); }
     // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask
     static __device__ __forceinline__ frag blend(const frag (&v)[4], const float (&w)[4], float mask)
@@ -107,19 +108,36 @@ template <> struct SE<bf16_t> {
     {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, acc, 0, 0, 0);
     }
-    struct geo { half2_t w01, w23; };           // mask folded into the fp32 corner weights, one fp16 rounding each
+    struct geo { uint32_t w01, w23; };          // fp16 pairs (w0 | w1 << 16), (w2 | w3 << 16); mask folded in
     static __device__ __forceinline__ geo make_geo(const float (&w)[4], float mask)
     {
         geo g;
-        g.w01 = half2_t{(_Float16)(w[0] * mask), (_Float16)(w[1] * mask)};
-        g.w23 = half2_t{(_Float16)(w[2] * mask), (_Float16)(w[3] * mask)};
+        g.w01 = __builtin_bit_cast(uint32_t, half2_t{(_Float16)(w[0] * mask), (_Float16)(w[1] * mask)});
+        g.w23 = __builtin_bit_cast(uint32_t, half2_t{(_Float16)(w[2] * mask), (_Float16)(w[3] * mask)});
         return g;
     }
+    static __device__ __forceinline__ geo zero_geo() { geo g; g.w01 = 0u; g.w23 = 0u; return g; }
+    // out = v0*w0 + v1*w1 + v2*w2 + v3*w3 on 8 fp16 channels: 4 packed ops per dword, the per-pixel
+    // weight is broadcast to both halves by op_sel (no duplicated weight registers).  The trailing
+    // s_nop covers the VALU-write -> MFMA-operand wait states hipcc does not pad inside asm.
     static __device__ __forceinline__ frag blend(const frag (&v)[4], const geo &g)
     {
-        frag o;
-        o.v = v[0].v * g.w01[0] + v[1].v * g.w01[1] + v[2].v * g.w23[0] + v[3].v * g.w23[1];   // 4 v_pk_{mul,fma}_f16 / dword
-        return o;
+        const u32x4 a = __builtin_bit_cast(u32x4, v[0].v), b = __builtin_bit_cast(u32x4, v[1].v),
+                    c = __builtin_bit_cast(u32x4, v[2].v), d = __builtin_bit_cast(u32x4, v[3].v);
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t x;
+            asm("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(x) : "v"(a[i]), "v"(g.w01));
+            asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(x) : "v"(b[i]), "v"(g.w01));
+            asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(x) : "v"(c[i]), "v"(g.w23));
+            asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(x) : "v"(d[i]), "v"(g.w23));
+            o[i] = x;
+        }
+        asm volatile("s_nop 1" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+        frag f;
+        f.v = __builtin_bit_cast(half8_t, u32x4{o[0], o[1], o[2], o[3]});
+        return f;
     }
 };
 
@@ -185,19 +203,24 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
     const int aoff = r * C::WB + 8 * h * SS;
 
     // ---- sampling geometry of every (pixel, tap) of this lane, ONCE per workgroup: the reference's
-    //      float arithmetic (im2col.cu:163-185).  pos = (h_low << 16) | (w_low & 0xffff); a sample that
-    //      fails the (>-1, <H) gate gets zero coefficients and pos inside the apron (no branch later).
-    int pos[NT][9];
+    //      float arithmetic (im2col.cu:163-185).  Kept in registers: boff = LDS byte offset of corner
+    //      (h_low, w_low) inside the staged apron, geo = the four blend coefficients (x mask).
+    //      A sample failing the (>-1, <H) gate gets zero coefficients.  A sample whose corners leave
+    //      the apron ALSO gets zero coefficients here and raises `slow`: pass 2 adds it back.
+    int boff[NT][9];
     typename X::geo geo[NT][9];
+    int oyx[NT];
+    bool slow = false;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int oy = oy0 + wv * (2 * NT) + n * 2 + (r >> 4), ox = ox0 + (r & 15);
         const bool live = (oy < a.H && ox < a.W);
+        oyx[n] = live ? ((oy << 16) | ox) : -1;
         const float *omp = a.om + ((size_t)(b * a.H + (live ? oy : 0)) * a.W + (live ? ox : 0)) * a.om_cs;
         float omv[28];
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(omp + 4 * q);   // om_cs >= 28 and 16-byte aligned rows
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(omp + 4 * q);   // om_cs >= 28, 16-byte aligned rows
             omv[4 * q] = v[0]; omv[4 * q + 1] = v[1]; omv[4 * q + 2] = v[2]; omv[4 * q + 3] = v[3];
         }
 #pragma unroll
@@ -206,22 +229,27 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
             const float h_im = (float)(oy - 1 + ti) + omv[2 * tap];
             const float w_im = (float)(ox - 1 + tj) + omv[2 * tap + 1];
             const bool inside = live && (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
-            float w4[4] = {0.f, 0.f, 0.f, 0.f};
-            float mask = 0.f;
-            int hl = oy, wl = ox;
+            typename X::geo g = X::zero_geo();
+            int off = 8 * h * SS;
             if (inside) {
-                mask = dcn2_sigmoid(omv[18 + tap]);
-                hl = (int)floorf(h_im);
-                wl = (int)floorf(w_im);
-                const float lh = h_im - (float)hl, lw = w_im - (float)wl;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                w4[0] = hh * hw; w4[1] = hh * lw; w4[2] = lh * hw; w4[3] = lh * lw;
+                const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                const int ry = hl - hy0, rx = wl - hx0;
+                if (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH) {
+                    const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                    g = X::make_geo(w4, dcn2_sigmoid(omv[18 + tap]));
+                    off += ry * C::RBH + rx * C::SBH;
+                } else {
+                    slow = true;
+                }
             }
-            pos[n][tap] = (hl << 16) | (wl & 0xffff);
-            geo[n][tap] = X::make_geo(w4, mask);
+            boff[n][tap] = off;
+            geo[n][tap] = g;
         }
     }
 
+    // ================= pass 1: every sample whose 2x2 corners lie in the apron (branch-free) ==========
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();
         // ---- stage halo chunk (converted to S, zero outside the image) + weight chunk [BN][9][CK] of S;
@@ -263,41 +291,17 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
             typename X::frag fb[NT][CK / 16];
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                int pv = pos[n][tap];
-                asm volatile("" : "+v"(pv));   // opaque per chunk: stops LICM from hoisting 18 taps' worth of
-                                               // corner addresses out of the channel loop (register spills)
-                const int hl = pv >> 16, wl = (int)(short)(pv & 0xffff);
-                // all four corners inside the staged apron? (rows hl, hl+1; cols wl, wl+1)
-                const int ry = hl - hy0, rx = wl - hx0;
-                const bool in_halo = (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH);
-                if (in_halo) {
-                    const char *p00 = s_h + ry * C::RBH + rx * C::SBH + 8 * h * SS;
+                const char *p00 = s_h + boff[n][tap];
 #pragma unroll
-                    for (int kk = 0; kk < CK / 16; ++kk) {
-                        typename X::frag v[4];
-                        v[0] = X::lds(p00 + kk * 16 * SS);
-                        v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
-                        v[2] = X::lds(p00 + C::RBH + kk * 16 * SS);
-                        v[3] = X::lds(p00 + C::RBH + C::SBH + kk * 16 * SS);
-                        fb[n][kk] = X::blend(v, geo[n][tap]);
-                    }
-                } else {
-                    // per-lane global path: corners outside the image contribute zero
-                    const bool okh0 = hl >= 0 && hl <= a.H - 1, okh1 = hl + 1 >= 0 && hl + 1 <= a.H - 1;
-                    const bool okw0 = wl >= 0 && wl <= a.W - 1, okw1 = wl + 1 >= 0 && wl + 1 <= a.W - 1;
-                    const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
-                    const int pix[4] = {hl * a.W + wl, hl * a.W + wl + 1, (hl + 1) * a.W + wl, (hl + 1) * a.W + wl + 1};
-#pragma unroll
-                    for (int kk = 0; kk < CK / 16; ++kk) {
-                        typename X::frag v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            v[k] = ok[k] ? X::global8(img + ((size_t)pix[k] * a.in_cs + c0 + kk * 16 + 8 * h) * ES) : X::zero();
-                        fb[n][kk] = X::blend(v, geo[n][tap]);
-                    }
+                for (int kk = 0; kk < CK / 16; ++kk) {
+                    typename X::frag v[4];
+                    v[0] = X::lds(p00 + kk * 16 * SS);
+                    v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
+                    v[2] = X::lds(p00 + C::RBH + kk * 16 * SS);
+                    v[3] = X::lds(p00 + C::RBH + C::SBH + kk * 16 * SS);
+                    fb[n][kk] = X::blend(v, geo[n][tap]);
                 }
             }
-            // ---- contraction of this tap ------------------------------------------------------------
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
                 typename X::frag fa[MT];
@@ -308,7 +312,69 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
 #pragma unroll
                     for (int n = 0; n < NT; ++n) X::mma(acc[m][n], fa[m], fb[n][kk]);
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every tap's gathers (spills)
+        }
+    }
+
+    // ================= pass 2 (rare): samples whose corners left the apron, gathered from global ======
+    // Compact rolled loops; geometry is recomputed from the offsets so pass 1 carries no slow-path code.
+    if (__syncthreads_or(slow ? 1 : 0)) {
+        for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+            __syncthreads();
+            constexpr int WV = 9 * C::VPP;
+            for (int i = tid; i < C::BN * WV; i += C::THREADS) {
+                const int row = i / WV, q = i - row * WV;
+                const int tap = q / C::VPP, v = q - tap * C::VPP;
+                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = *reinterpret_cast<const u32x4 *>(
+                    a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ti = tap / 3, tj = tap - ti * 3;
+                typename X::frag fb[NT][CK / 16];
+                bool any = false;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                    for (int kk = 0; kk < CK / 16; ++kk) fb[n][kk] = X::zero();
+                    if (oyx[n] < 0) continue;
+                    const int oy = oyx[n] >> 16, ox = oyx[n] & 0xffff;
+                    const float *omp = a.om + ((size_t)(b * a.H + oy) * a.W + ox) * a.om_cs;
+                    const float h_im = (float)(oy - 1 + ti) + omp[2 * tap];
+                    const float w_im = (float)(ox - 1 + tj) + omp[2 * tap + 1];
+                    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W)) continue;
+                    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                    const int ry = hl - hy0, rx = wl - hx0;
+                    if (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH) continue;   // done in pass 1
+                    any = true;
+                    const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                    const typename X::geo g = X::make_geo(w4, dcn2_sigmoid(omp[18 + tap]));
+                    const bool okh0 = hl >= 0, okh1 = hl + 1 <= a.H - 1, okw0 = wl >= 0, okw1 = wl + 1 <= a.W - 1;
+                    const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+                    const int pix[4] = {hl * a.W + wl, hl * a.W + wl + 1, (hl + 1) * a.W + wl, (hl + 1) * a.W + wl + 1};
+#pragma unroll
+                    for (int kk = 0; kk < CK / 16; ++kk) {
+                        typename X::frag v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            v[k] = ok[k] ? X::global8(img + ((size_t)pix[k] * a.in_cs + c0 + kk * 16 + 8 * h) * ES) : X::zero();
+                        fb[n][kk] = X::blend(v, g);
+                    }
+                }
+                if (!__any(any)) continue;          // wave-uniform: no lane of this wave has a slow sample at this tap
+#pragma unroll
+                for (int kk = 0; kk < CK / 16; ++kk) {
+                    typename X::frag fa[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) X::mma(acc[m][n], fa[m], fb[n][kk]);
+                }
+            }
         }
     }
     EpiArgs e;
