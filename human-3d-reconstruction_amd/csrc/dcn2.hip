@@ -150,6 +150,7 @@ struct Dcn2Args {
     int B, H, W, Cin, in_cs, om_cs;
     int Cout, out_cs, relu, out_mode;
     int tiles_x, tiles_y;
+    int dbg;   // ablation switches for profiling (h3d_op.reserved): 1 = stage only chunk 0, 2 = no gather/blend, 4 = no MFMA
 };
 
 template <typename T, int MT, int CK, int MARGIN, int NT_>
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
         //      all loads in flight before the first LDS store ------------------------------------------
         constexpr int WV = 9 * C::VPP;
         constexpr int NH = C::HH * C::HH * C::VPP, NW = C::BN * WV;
+        if (!((a.dbg & 1) && c0))
         stage_vectors<NH + NW, C::THREADS, 6>(
             tid,
             [&](int i) -> u32x4 {
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
                 const char *p00 = s_h + boff[n][tap];
 #pragma unroll
                 for (int kk = 0; kk < CK / 16; ++kk) {
+                    if (a.dbg & 2) { fb[n][kk] = X::lds(p00 + kk * 16 * SS); continue; }
                     typename X::frag v[4];
                     v[0] = X::lds(p00 + kk * 16 * SS);
                     v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
@@ -307,6 +310,13 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
                 typename X::frag fa[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+                if (a.dbg & 4) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(fa[m]), "v"(fb[n][kk]));
+                    continue;
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -419,6 +429,7 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st)
     a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
     a.om_cs = op.in2_cs; a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode;
     a.tiles_x = a.tiles_y = 0;
+    a.dbg = op.reserved;
     if (op.dtype == H3D_BF16) {
         if (op.Cin % 32 == 0 && op.Cout <= 64) {
             if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 32, 2, 2>(a, st);
