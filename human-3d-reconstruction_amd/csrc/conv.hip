@@ -85,43 +85,59 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a)
     const int aoff = r * C::WB + 8 * h * ES;
 
     const size_t in_img = (size_t)b * a.H * a.W;
-    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        if (c0) __syncthreads();
-        // ---- stage the input halo chunk [IN_H][IN_W][CK] (zero outside the image) and the weight
-        //      chunk [BN][KS*KS][CK]: every load of the stage is in flight before the first LDS store
-        constexpr int WV = KS * KS * C::VPP;
-        constexpr int NH = C::IN_H * C::IN_W * C::VPP, NW = C::BN * WV;
-        stage_vectors<NH + NW, 256>(
-            tid,
-            [&](int i) -> u32x4 {
-                if (i < NH) {
-                    const int v = i % C::VPP, pix = i / C::VPP;
-                    const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
-                    const int gy = oy0 * STRIDE - C::PAD + iy, gx = ox0 * STRIDE - C::PAD + ix;
-                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                        return *reinterpret_cast<const u32x4 *>(
-                            a.in + ((in_img + (size_t)gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
-                    return u32x4{0u, 0u, 0u, 0u};
-                }
+    // ---- software pipeline over channel chunks: the global loads of chunk c+1 (input halo
+    //      [IN_H][IN_W][CK], zero outside the image, and weight slab [BN][KS*KS][CK]) are issued into
+    //      registers BEFORE the MFMAs of chunk c and written to LDS after them, so only the first
+    //      chunk's memory latency is exposed.
+    constexpr int WV = KS * KS * C::VPP;
+    constexpr int NH = C::IN_H * C::IN_W * C::VPP, NW = C::BN * WV;
+    constexpr int NV = (NH + NW + 255) / 256;
+    u32x4 stg[NV];
+    auto load_stage = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 256;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (i < NH) {
+                const int v = i % C::VPP, pix = i / C::VPP;
+                const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
+                const int gy = oy0 * STRIDE - C::PAD + iy, gx = ox0 * STRIDE - C::PAD + ix;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    val = *reinterpret_cast<const u32x4 *>(
+                        a.in + ((in_img + (size_t)gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
+            } else if (i < NH + NW) {
                 const int q0 = i - NH;
                 const int row = q0 / WV, q = q0 - row * WV;
                 const int tap = q / C::VPP, v = q - tap * C::VPP;
-                return *reinterpret_cast<const u32x4 *>(
+                val = *reinterpret_cast<const u32x4 *>(
                     a.w + (((size_t)(cout0 + row) * (KS * KS) + tap) * a.Cin + c0) * ES + v * 16);
-            },
-            [&](int i, u32x4 val) {
-                if (i < NH) {
-                    const int v = i % C::VPP, pix = i / C::VPP;
-                    const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
-                    *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = val;
-                } else {
-                    const int q0 = i - NH;
-                    const int row = q0 / WV, q = q0 - row * WV;
-                    const int tap = q / C::VPP, v = q - tap * C::VPP;
-                    *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * ES + v * 16) = val;
-                }
-            });
+            }
+            stg[j] = val;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * 256;
+            if (i < NH) {
+                const int v = i % C::VPP, pix = i / C::VPP;
+                const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
+                *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = stg[j];
+            } else if (i < NH + NW) {
+                const int q0 = i - NH;
+                const int row = q0 / WV, q = q0 - row * WV;
+                const int tap = q / C::VPP, v = q - tap * C::VPP;
+                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * ES + v * 16) = stg[j];
+            }
+        }
+    };
+
+    load_stage(0);
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        if (c0) __syncthreads();            // every wave is done reading the previous chunk
+        store_stage();
         __syncthreads();
+        if (c0 + CK < a.Cin) load_stage(c0 + CK);
         // ---- contraction over this chunk: taps x CK/16 k-steps -------------------------------------
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {

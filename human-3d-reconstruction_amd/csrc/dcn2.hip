@@ -35,6 +35,7 @@ template <> struct SE<float> {
         return f;
     }
     static __device__ __forceinline__ frag zero() { frag f; f.lo = f32x4{0, 0, 0, 0}; f.hi = f.lo; return f; }
+    static __device__ __forceinline__ void keep(const frag &f) { asm volatile("" ::"v"(f.lo), "v"(f.hi)); }
     static __device__ __forceinline__ frag global8(const char *p) { return lds(p); }   // 8 floats
     static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
     {
@@ -83,6 +84,7 @@ template <> struct SE<bf16_t> {
         for (int e = 0; e < 8; ++e) f.v[e] = (_Float16)0.f;
         return f;
     }
+    static __device__ __forceinline__ void keep(const frag &f) { asm volatile("" ::"v"(f.v)); }
     static __device__ __forceinline__ _Float16 cvt(uint32_t bits_hi)   // bf16 in the high half of an f32 pattern
     {
         const float x = __uint_as_float(bits_hi);
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
         float omv[28];
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(omp + 4 * q);   // om_cs >= 28, 16-byte aligned rows
+            const f32x4 v = (a.dbg & 16) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(omp + 4 * q);   // om_cs >= 28, 16-byte aligned rows
             omv[4 * q] = v[0]; omv[4 * q + 1] = v[1]; omv[4 * q + 2] = v[2]; omv[4 * q + 3] = v[3];
         }
 #pragma unroll
@@ -251,42 +253,54 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
     }
 
     // ================= pass 1: every sample whose 2x2 corners lie in the apron (branch-free) ==========
-    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        __syncthreads();
-        // ---- stage halo chunk (converted to S, zero outside the image) + weight chunk [BN][9][CK] of S;
-        //      all loads in flight before the first LDS store ------------------------------------------
-        constexpr int WV = 9 * C::VPP;
-        constexpr int NH = C::HH * C::HH * C::VPP, NW = C::BN * WV;
-        if (!((a.dbg & 1) && c0))
-        stage_vectors<NH + NW, C::THREADS, 6>(
-            tid,
-            [&](int i) -> u32x4 {
-                if (i < NH) {
-                    const int v = i % C::VPP, pix = i / C::VPP;
-                    const int iy = pix / C::HH, ix = pix - iy * C::HH;
-                    const int gy = hy0 + iy, gx = hx0 + ix;
-                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                        return *reinterpret_cast<const u32x4 *>(img + ((size_t)(gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
-                    return u32x4{0u, 0u, 0u, 0u};
-                }
+    // Software pipeline over channel chunks: chunk c+1's global loads (apron tile + weight slab) are in
+    // flight in registers while chunk c is gathered/contracted; converted to S when written to LDS.
+    constexpr int WV = 9 * C::VPP;
+    constexpr int NH = C::HH * C::HH * C::VPP, NW = C::BN * WV;
+    constexpr int NV = (NH + NW + C::THREADS - 1) / C::THREADS;
+    u32x4 stg[NV];
+    auto load_stage = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * C::THREADS;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (i < NH) {
+                const int v = i % C::VPP, pix = i / C::VPP;
+                const int iy = pix / C::HH, ix = pix - iy * C::HH;
+                const int gy = hy0 + iy, gx = hx0 + ix;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    val = *reinterpret_cast<const u32x4 *>(img + ((size_t)(gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
+            } else if (i < NH + NW) {
                 const int q0 = i - NH;
                 const int row = q0 / WV, q = q0 - row * WV;
                 const int tap = q / C::VPP, v = q - tap * C::VPP;
-                return *reinterpret_cast<const u32x4 *>(a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
-            },
-            [&](int i, u32x4 val) {
-                if (i < NH) {
-                    const int v = i % C::VPP, pix = i / C::VPP;
-                    const int iy = pix / C::HH, ix = pix - iy * C::HH;
-                    *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + v * 16) = X::convert16(val);
-                } else {
-                    const int q0 = i - NH;
-                    const int row = q0 / WV, q = q0 - row * WV;
-                    const int tap = q / C::VPP, v = q - tap * C::VPP;
-                    *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = val;
-                }
-            });
+                val = *reinterpret_cast<const u32x4 *>(a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+            }
+            stg[j] = val;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * C::THREADS;
+            if (i < NH) {
+                const int v = i % C::VPP, pix = i / C::VPP;
+                const int iy = pix / C::HH, ix = pix - iy * C::HH;
+                *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + v * 16) = X::convert16(stg[j]);
+            } else if (i < NH + NW) {
+                const int q0 = i - NH;
+                const int row = q0 / WV, q = q0 - row * WV;
+                const int tap = q / C::VPP, v = q - tap * C::VPP;
+                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = stg[j];
+            }
+        }
+    };
+    load_stage(0);
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        if (c0) __syncthreads();
+        store_stage();
         __syncthreads();
+        if (c0 + CK < a.Cin) load_stage(c0 + CK);
 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -314,7 +328,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(fa[m]), "v"(fb[n][kk]));
+                        for (int n = 0; n < NT; ++n) { X::keep(fa[m]); X::keep(fb[n][kk]); }
                     continue;
                 }
 #pragma unroll
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
 
     // ================= pass 2 (rare): samples whose corners left the apron, gathered from global ======
     // Compact rolled loops; geometry is recomputed from the offsets so pass 1 carries no slow-path code.
-    if (__syncthreads_or(slow ? 1 : 0)) {
+    if (!(a.dbg & 8) && __syncthreads_or(slow ? 1 : 0)) {
         for (int c0 = 0; c0 < a.Cin; c0 += CK) {
             __syncthreads();
             constexpr int WV = 9 * C::VPP;

@@ -16,7 +16,7 @@ plan = det.model.engine(dev).plan(B, 512, 512)
 n = len(plan.ops)
 ms = (ctypes.c_float * n)()
 idx = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_DCN]
-for dbg in (0, 1, 2, 4, 6, 7):
+for dbg in (0, 1, 2, 4, 7, 8, 16, 31):
     for i in idx:
         plan.op_array[i].reserved = dbg
     tot = np.zeros(n)
