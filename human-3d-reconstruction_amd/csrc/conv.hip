@@ -309,6 +309,65 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
     }
 }
 
+// bf16 stem on MFMA (v_mfma_f32_16x16x32_bf16): A = weights [16 out ch][K], B = pixels [K][16 px].
+// The image tile is staged in LDS as interleaved pixels of 4 bf16 (c0,c1,c2,0), so for tap row dy the
+// K run (dx=0..6, c=0..3) of a pixel is 28 CONTIGUOUS elements: one K=32 step per dy (4 zero-weight
+// pad elements), 7 MFMAs per 16 pixels.  C/D map: col = lane&15 (pixel), row = 4*(lane>>4)+reg
+// (output channel) -> each lane owns 4 consecutive channels of one pixel: 8-byte NHWC stores,
+// 512 contiguous bytes per wave.  w: [16][7][32] bf16 (k = dx*4 + c), prepared by the host.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float *__restrict__ img, const bf16_t *__restrict__ w,
+                                                        const float *__restrict__ bias, bf16_t *__restrict__ out, int B,
+                                                        int H, int W, int out_cs, int tiles_x, int tiles_y)
+{
+    constexpr int TH = 16, TW = 64, IH = TH + 6, IW = TW + 6 + 2;   // +2: the K=32 run of the last pixel reads 8 px
+    __shared__ __attribute__((aligned(16))) uint2 s[IH][IW];        // 4 bf16 per pixel
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, p = l & 15, q = l >> 4;
+    const int tiles = tiles_x * tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    // weights: this lane's A fragments for the 7 tap rows (row = out channel p, k = 8q..8q+7)
+    u32x4 fa[7];
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy) fa[dy] = *reinterpret_cast<const u32x4 *>(w + (p * 7 + dy) * 32 + 8 * q);
+    const size_t plane = (size_t)H * W;
+    const float *im = img + (size_t)b * 3 * plane;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int iy = i / IW, ix = i - iy * IW;
+        const int gy = oy0 - 3 + iy, gx = ox0 - 3 + ix;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t o = (size_t)gy * W + gx;
+            c0 = im[o]; c1 = im[plane + o]; c2 = im[2 * plane + o];
+        }
+        s[iy][ix] = uint2{pack_bf16x2(c0, c1), pack_bf16x2(c2, 0.f)};
+    }
+    __syncthreads();
+    float bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bs[i] = bias[4 * q + i];
+    // 64 groups of 16 consecutive pixels; wave wv takes rows 4wv..4wv+3, 4 groups per row
+#pragma unroll 1
+    for (int g = 0; g < 16; ++g) {
+        const int py = wv * 4 + (g >> 2), px0 = (g & 3) * 16;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy) {
+            // K elements 8q..8q+7 of the run starting at pixel (py+dy, px0+p): pixels +2q, +2q+1
+            const uint2 lo = s[py + dy][px0 + p + 2 * q], hi = s[py + dy][px0 + p + 2 * q + 1];
+            const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[dy]), __builtin_bit_cast(bf16x8_t, fb),
+                                                          acc, 0, 0, 0);
+        }
+        const int oy = oy0 + py, ox = ox0 + px0 + p;
+        if (oy < H && ox < W)
+            store4<bf16_t>(out + ((size_t)(b * H + oy) * W + ox) * out_cs + 4 * q, fmaxf(acc[0] + bs[0], 0.f),
+                           fmaxf(acc[1] + bs[1], 0.f), fmaxf(acc[2] + bs[2], 0.f), fmaxf(acc[3] + bs[3], 0.f));
+    }
+}
+
 int h3d_launch_stem(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "stem: null pointer");
@@ -316,6 +375,15 @@ int h3d_launch_stem(const h3d_op &op, hipStream_t st)
         H3D_FAIL(H3D_ERR_SHAPE, "stem: expects 7x7 3->16 stride 1 (got k=%d %d->%d)", op.ksize, op.Cin, op.Cout);
     const int tx = cdiv(op.W, 16), ty = cdiv(op.H, 16);
     dim3 grid(op.B * tx * ty);
+    if (op.dtype == H3D_BF16) {
+        // op.w: bf16 [16][7][32] (k = dx*4 + c, zero padded) -- see engine.PackedWeights.stem
+        const int mx = cdiv(op.W, 64), my = cdiv(op.H, 16);
+        if (h3d_note_kernel("stem_mfma_kernel")) return H3D_OK;
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3(op.B * mx * my), dim3(256), 0, st, (const float *)op.in, (const bf16_t *)op.w,
+                           op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.out_cs, mx, my);
+        H3D_CHECK_LAUNCH("stem_mfma_kernel");
+        return H3D_OK;
+    }
     if (h3d_note_kernel("stem_kernel<%s>", op.dtype == H3D_BF16 ? "unsigned short" : "float")) return H3D_OK;
     if (op.dtype == H3D_BF16)
         hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, st, (const float *)op.in, (const float *)op.w,

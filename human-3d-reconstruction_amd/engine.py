@@ -95,6 +95,11 @@ class PackedWeights:
         key = ("stem",)
         if key not in self.t:
             w, b = self._fold(self.sd["base.base_layer.0.weight"], None, "base.base_layer.1")
+            if self.dtype == "bf16":
+                # MFMA stem (csrc/conv.hip stem_mfma_kernel): [16][7 dy][32] bf16 with k = dx*4 + c
+                wp = torch.zeros(16, 7, 8, 4)
+                wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)          # [o][dy][dx][c]
+                w = wp.reshape(16, 7, 32).to(torch.bfloat16)
             self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
         return self.t[key]
 

@@ -102,6 +102,11 @@ def test_stem(dtype):
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 3)).float()
     xi = x.contiguous().to(DEV)
     wd, bd = w.contiguous().to(DEV), b.to(DEV)
+    if dtype == "bf16":                                   # MFMA stem: bf16 image/weights, [16][7][32] k = dx*4+c
+        ref = F.relu(F.conv2d(bf16_round(x).double(), bf16_round(w).double(), b.double(), 1, 3)).float()
+        wp = torch.zeros(16, 7, 8, 4)
+        wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+        wd = wp.reshape(16, 7, 32).to(torch.bfloat16).contiguous().to(DEV)
     out = torch.zeros(2, 40, 56, 16, dtype=TD[dtype], device=DEV)
     run(mk(_lib.OP_STEM, dtype, in_=xi.data_ptr(), w=wd.data_ptr(), bias=bd.data_ptr(), out=out.data_ptr(), B=2, H=40,
            W=56, Cin=3, in_cs=3, Ho=40, Wo=56, Cout=16, out_cs=16, ksize=7, stride=1, relu=1))
