@@ -111,9 +111,13 @@ extern "C" int h3d_smpl_pose(const float *betas, const float *thetas, const floa
     return H3D_OK;
 }
 
-// Block = 256 lanes = 256 vertices, PT persons per block; coefficient vectors [beta | pose_feat]
-// (217 floats per person) and the A transforms (288 floats per person) sit in LDS and are read
-// as wave-uniform broadcasts.
+// Block = 256 lanes = 256 vertices x PT persons.  The blend-shape contraction
+//     v_posed[p][v][c] = v_template[v][c] + sum_k dirs[k][c][v] * coef[p][k]      (k = 10 betas + 207 pose feats)
+// keeps the PT x 3 accumulators of a lane in registers; direction tensors are stored [k][3][V]
+// (struct-of-arrays: each of the 3 loads of a k-step is one fully coalesced 256-byte row per
+// wave) and are re-read from L2 once per PT persons; the coefficient block sits in LDS as
+// [k][PT] so a k-step reads it with PT/4 broadcast ds_read_b128.  LBS then runs per person with
+// the 3x4 joint transforms broadcast from LDS (4-sparse skinning weights).
 template <int PT>
 __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict__ betas, const float *__restrict__ pose_feat,
                                                          const float *__restrict__ A, const float *__restrict__ v_template,
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict
                                                          int nnz, int P, int V, float *__restrict__ verts)
 {
     constexpr int NC = SMPL_NB + SMPL_PF;  // 217
-    __shared__ float s_coef[PT][NC + 3];
-    __shared__ float s_A[PT][SMPL_J * 12];
+    __shared__ __attribute__((aligned(16))) float s_coef[NC][PT];
+    __shared__ __attribute__((aligned(16))) float s_A[PT][SMPL_J * 12];
     const int tid = threadIdx.x;
     const int v = blockIdx.x * 256 + tid;
     const int p0 = blockIdx.y * PT;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict
         const int p = p0 + q;
         float val = 0.f;
         if (p < P) val = (k < SMPL_NB) ? betas[(size_t)p * SMPL_NB + k] : pose_feat[(size_t)p * SMPL_PF + (k - SMPL_NB)];
-        s_coef[q][k] = val;
+        s_coef[k][q] = val;
     }
     for (int i = tid; i < PT * SMPL_J * 12; i += 256) {
         const int q = i / (SMPL_J * 12), k = i - q * (SMPL_J * 12);
@@ -141,44 +145,70 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict
         s_A[q][k] = (p < P) ? A[(size_t)p * SMPL_J * 12 + k] : 0.f;
     }
     __syncthreads();
-    if (v >= V) return;
+    const int vc = v < V ? v : V - 1;      // clamp: out-of-range lanes compute a duplicate and do not store
     float acc[PT][3];
-    const float t0 = v_template[v * 3], t1 = v_template[v * 3 + 1], t2 = v_template[v * 3 + 2];
+    const float t0 = v_template[vc], t1 = v_template[V + vc], t2 = v_template[2 * V + vc];
 #pragma unroll
     for (int q = 0; q < PT; ++q) { acc[q][0] = t0; acc[q][1] = t1; acc[q][2] = t2; }
     const size_t V3 = (size_t)V * 3;
+#pragma unroll 2
     for (int k = 0; k < NC; ++k) {
         const float *dp = (k < SMPL_NB) ? (shapedirsT + (size_t)k * V3) : (posedirsT + (size_t)(k - SMPL_NB) * V3);
-        const float d0 = dp[v * 3], d1 = dp[v * 3 + 1], d2 = dp[v * 3 + 2];
+        const float d0 = dp[vc], d1 = dp[V + vc], d2 = dp[2 * V + vc];
 #pragma unroll
-        for (int q = 0; q < PT; ++q) {
-            const float c = s_coef[q][k];
-            acc[q][0] = fmaf(d0, c, acc[q][0]);
-            acc[q][1] = fmaf(d1, c, acc[q][1]);
-            acc[q][2] = fmaf(d2, c, acc[q][2]);
+        for (int q4 = 0; q4 < PT / 4; ++q4) {
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(&s_coef[k][q4 * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[q4 * 4 + e][0] = fmaf(d0, c[e], acc[q4 * 4 + e][0]);
+                acc[q4 * 4 + e][1] = fmaf(d1, c[e], acc[q4 * 4 + e][1]);
+                acc[q4 * 4 + e][2] = fmaf(d2, c[e], acc[q4 * 4 + e][2]);
+            }
         }
     }
-    float T[PT][12];
+    int jidx[4];
+    float jw[4];
+    const bool sparse4 = (nnz <= 4);
+    if (sparse4) {
 #pragma unroll
-    for (int q = 0; q < PT; ++q)
-#pragma unroll
-        for (int i = 0; i < 12; ++i) T[q][i] = 0.f;
-    for (int s = 0; s < nnz; ++s) {
-        const int j = lbs_idx[(size_t)v * nnz + s];
-        const float w = lbs_w[(size_t)v * nnz + s];
-#pragma unroll
-        for (int q = 0; q < PT; ++q)
-#pragma unroll
-            for (int i = 0; i < 12; ++i) T[q][i] = fmaf(w, s_A[q][j * 12 + i], T[q][i]);
+        for (int sI = 0; sI < 4; ++sI) {
+            jidx[sI] = sI < nnz ? lbs_idx[(size_t)vc * nnz + sI] : 0;
+            jw[sI] = sI < nnz ? lbs_w[(size_t)vc * nnz + sI] : 0.f;
+        }
     }
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int p = p0 + q;
-        if (p >= P) break;
-        float *o = verts + ((size_t)p * V + v) * 3;
+        if (p >= P) continue;
+        float T[12];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-            o[a] = T[q][a * 4] * acc[q][0] + T[q][a * 4 + 1] * acc[q][1] + T[q][a * 4 + 2] * acc[q][2] + T[q][a * 4 + 3];
+        for (int i = 0; i < 12; ++i) T[i] = 0.f;
+        if (sparse4) {
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const float *Ap = &s_A[q][jidx[sI] * 12];
+#pragma unroll
+                for (int i4 = 0; i4 < 3; ++i4) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(Ap + 4 * i4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) T[4 * i4 + e] = fmaf(jw[sI], a4[e], T[4 * i4 + e]);
+                }
+            }
+        } else {
+            for (int sI = 0; sI < nnz; ++sI) {
+                const int j = lbs_idx[(size_t)vc * nnz + sI];
+                const float w = lbs_w[(size_t)vc * nnz + sI];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[i] = fmaf(w, s_A[q][j * 12 + i], T[i]);
+            }
+        }
+        const float x = acc[q][0], y = acc[q][1], z = acc[q][2];
+        if (v < V) {
+            float *o = verts + ((size_t)p * V + v) * 3;
+            o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+            o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+            o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+        }
     }
 }
 
@@ -189,10 +219,18 @@ extern "C" int h3d_smpl_verts(const float *betas, const float *pose_feat, const 
     if (!betas || !pose_feat || !A || !v_template || !shapedirsT || !posedirsT || !lbs_idx || !lbs_w || !verts)
         H3D_FAIL(H3D_ERR_ARG, "smpl_verts: null pointer");
     if (P <= 0 || V <= 0 || nnz <= 0 || nnz > SMPL_J) H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts: P=%d V=%d nnz=%d", P, V, nnz);
-    constexpr int PT = 8;
-    dim3 grid(cdiv(V, 256), cdiv(P, PT));
-    hipLaunchKernelGGL(smpl_verts_kernel<PT>, grid, dim3(256), 0, (hipStream_t)stream, betas, pose_feat, A, v_template,
-                       shapedirsT, posedirsT, lbs_idx, lbs_w, nnz, P, V, verts);
+    dim3 grid(cdiv(V, 256), 1);
+    if (P >= 64) {
+        constexpr int PT = 32;
+        grid.y = cdiv(P, PT);
+        hipLaunchKernelGGL(smpl_verts_kernel<PT>, grid, dim3(256), 0, (hipStream_t)stream, betas, pose_feat, A, v_template,
+                           shapedirsT, posedirsT, lbs_idx, lbs_w, nnz, P, V, verts);
+    } else {
+        constexpr int PT = 8;
+        grid.y = cdiv(P, PT);
+        hipLaunchKernelGGL(smpl_verts_kernel<PT>, grid, dim3(256), 0, (hipStream_t)stream, betas, pose_feat, A, v_template,
+                           shapedirsT, posedirsT, lbs_idx, lbs_w, nnz, P, V, verts);
+    }
     H3D_CHECK_LAUNCH("smpl_verts_kernel");
     return H3D_OK;
 }

@@ -85,9 +85,10 @@ def _device_pack(model, device, nnz=None):
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     return {
         "V": V, "nnz": nnz,
-        "v_template": to(model.v_template.reshape(-1)),
-        "shapedirsT": to(model.shapedirs.reshape(V * 3, NUM_BETAS).T),
-        "posedirsT": to(model.posedirs.reshape(V * 3, NUM_POSE_FEAT).T),
+        # struct-of-arrays: [3][V] and [k][3][V], so a wave's load of one coordinate is one contiguous row
+        "v_template": to(model.v_template.T),
+        "shapedirsT": to(model.shapedirs.transpose(2, 1, 0)),
+        "posedirsT": to(model.posedirs.transpose(2, 1, 0)),
         "j_template": to(j_template.reshape(-1)),
         "j_shapedirs": to(j_dirs.reshape(NUM_JOINTS * 3, NUM_BETAS)),
         "parents": to(model.parents.astype(np.int32)),

@@ -197,7 +197,7 @@ int h3d_multi_pose_post_process(const float *dets, const float *c, const float *
 /* =====================================================================================
  * 4. SMPL pose/shape -> LBS mesh (north_star; no reference code: published formulation).
  *    Model tensors are packed by the host (h3d_amd/smpl.py: SMPLModel.device_pack):
- *      v_template [V*3], shapedirsT [10][V*3], posedirsT [207][V*3], j_template [24*3],
+ *      v_template [3][V], shapedirsT [10][3][V], posedirsT [207][3][V], j_template [24*3],
  *      j_shapedirs [24*3][10], parents i32[24], lbs_idx i32[V][nnz], lbs_w f32[V][nnz]
  * ===================================================================================== */
 /* per person: Rodrigues (24), pose feature (207), joints, kinematic chain.
