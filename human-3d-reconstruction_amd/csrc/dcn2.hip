@@ -88,7 +88,7 @@ template <> struct SE<bf16_t> {
     static __device__ __forceinline__ _Float16 cvt(uint32_t bits_hi)   // bf16 in the high half of an f32 pattern
     {
         const float x = __uint_as_float(bits_hi);
-        return (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);           // no inf from bf16's wider range
+        return (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);  // v_med3_f32: no inf from bf16's wider range
     }
     static __device__ __forceinline__ u32x4 convert16(u32x4 raw)        // 8 bf16 -> 8 fp16
     {
@@ -172,7 +172,7 @@ struct Dcn2Cfg {
     static constexpr int LDS = LDS_H + BN * WB;
 };
 
-__device__ __forceinline__ float dcn2_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float dcn2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }   // v_exp + v_rcp (1 ulp each)
 
 template <typename T, int MT, int CK, int MARGIN, int NT_>
 __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
@@ -447,7 +447,7 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st)
     if (op.dtype == H3D_BF16) {
         if (op.Cin % 32 == 0 && op.Cout <= 64) {
             if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 32, 2, 2>(a, st);
-            return launch_dcn2_cfg<bf16_t, 2, 32, 2, 2>(a, st);
+            return launch_dcn2_cfg<bf16_t, 2, 32, 2, 1>(a, st);      // 8 waves x (32 px x 64 ch)
         }
         if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 16, 2, 2>(a, st);
         if (op.Cout <= 64) return launch_dcn2_cfg<bf16_t, 2, 16, 2, 2>(a, st);

@@ -44,6 +44,9 @@ def test_full_batch_size_properties(model):
     v = smpl.lbs(model, betas, thetas)
     assert v.shape == (P, 6890, 3) and bool(torch.isfinite(v).all())
     v2 = smpl.lbs(model, betas[100:108].contiguous(), thetas[100:108].contiguous())
-    assert torch.equal(v[100:108], v2)                   # person-tile position invariance
+    # person-tile position invariance (different tile instantiation: same math, fma contraction may differ)
+    assert float((v[100:108] - v2).abs().max()) < 1e-6
+    v3 = smpl.lbs(model, betas[64:192].contiguous(), thetas[64:192].contiguous())
+    assert torch.equal(v[64:192], v3)                    # same instantiation, other tile position: bitwise
     v_ref, _ = osmpl.lbs(betas[:2].cpu().numpy(), thetas[:2].cpu().numpy(), model.numpy_dict())
     assert np.abs(v[:2].cpu().numpy() - v_ref).max() < 1e-4
