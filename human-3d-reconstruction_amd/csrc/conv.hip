@@ -187,11 +187,20 @@ template <typename T> static int launch_conv_t(const h3d_op &op, const ConvArgs 
 template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipStream_t st)
 {
     const int cin = op.Cin, co = op.Cout;
+    // workgroups a (TH rows x 16 px) x (bn channels) tiling produces; small-resolution layers
+    // (level3..5, B*H*W <= 256k px) are re-tiled finer so every CU gets >= 4 workgroups
+    auto nblk = [&](int th, int bn) { return (long)op.B * cdiv(op.Wo, 16) * cdiv(op.Ho, th) * cdiv(co, bn); };
+    constexpr long WANT = 1024;
     if (op.ksize == 3 && op.stride == 1) {
         if (cin % 32 == 0) {
             if (co <= 32) return launch_conv_cfg<bf16_t, 3, 1, 1, 32, 16>(a, st);
-            if (co <= 64) return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 16>(a, st);
-            return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 16>(a, st);
+            if (co <= 64) {
+                if (nblk(16, 64) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 16>(a, st);
+                return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 8>(a, st);
+            }
+            if (nblk(16, 128) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 16>(a, st);
+            if (nblk(8, 128) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 8>(a, st);
+            return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 8>(a, st);
         }
         if (co <= 32) return launch_conv_cfg<bf16_t, 3, 1, 1, 16, 16>(a, st);
         if (co <= 64) return launch_conv_cfg<bf16_t, 3, 1, 2, 16, 16>(a, st);
@@ -199,14 +208,16 @@ template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipSt
     }
     if (op.ksize == 3 && op.stride == 2) {
         if (co <= 32) return launch_conv_cfg<bf16_t, 3, 2, 1, 16, 8>(a, st);
-        if (co <= 64) return launch_conv_cfg<bf16_t, 3, 2, 2, 16, 8>(a, st);
+        if (co <= 64 || nblk(8, 128) < WANT) return launch_conv_cfg<bf16_t, 3, 2, 2, 16, 8>(a, st);
         return launch_conv_cfg<bf16_t, 3, 2, 4, 16, 8>(a, st);
     }
     if (op.ksize == 1 && op.stride == 1) {
         if (cin % 64 == 0) {
             if (co <= 32) return launch_conv_cfg<bf16_t, 1, 1, 1, 64, 16>(a, st);
             if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 16>(a, st);
-            return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 16>(a, st);
+            if (nblk(16, 128) >= WANT) return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 16>(a, st);
+            if (nblk(8, 128) >= WANT) return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 8>(a, st);
+            return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 8>(a, st);
         }
         if (co <= 32) return launch_conv_cfg<bf16_t, 1, 1, 1, 16, 16>(a, st);
         if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 16, 16>(a, st);
