@@ -30,7 +30,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;
 };
 
-template <typename T, int KS, int STRIDE, int MT, int CK, int TH>
+template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4>
 struct ConvCfg {
     static constexpr int TW = 16;
     static constexpr int ES = sizeof(T);
@@ -41,17 +41,18 @@ struct ConvCfg {
     static constexpr int RB = ((IN_W * SB + 255) / 256) * 256;
     static constexpr int WB = KS * KS * CK * ES + 16;
     static constexpr int BN = 32 * MT;
-    static constexpr int NT = TH / 8;
+    static constexpr int NT = TH / (2 * WAVES);   // N-tiles (2 rows x 16 px) per wave
+    static constexpr int THREADS = 64 * WAVES;
     static constexpr int VPP = CK * ES / 16;  // 16-byte vectors per pixel per chunk
     static constexpr int LDS_IN = IN_H * RB;
     static constexpr int LDS_W = BN * WB;
     static constexpr int LDS = LDS_IN + LDS_W;
 };
 
-template <typename T, int KS, int STRIDE, int MT, int CK, int TH>
-__global__ __launch_bounds__(256) void conv_kernel(ConvArgs a)
+template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
 {
-    using C = ConvCfg<T, KS, STRIDE, MT, CK, TH>;
+    using C = ConvCfg<T, KS, STRIDE, MT, CK, TH, WAVES>;
     using E = ET<T>;
     constexpr int ES = C::ES;
     __shared__ __attribute__((aligned(16))) char smem[C::LDS];
@@ -91,12 +92,12 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a)
     //      chunk's memory latency is exposed.
     constexpr int WV = KS * KS * C::VPP;
     constexpr int NH = C::IN_H * C::IN_W * C::VPP, NW = C::BN * WV;
-    constexpr int NV = (NH + NW + 255) / 256;
+    constexpr int NV = (NH + NW + C::THREADS - 1) / C::THREADS;
     u32x4 stg[NV];
     auto load_stage = [&](int c0) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * 256;
+            const int i = tid + j * C::THREADS;
             u32x4 val = {0u, 0u, 0u, 0u};
             if (i < NH) {
                 const int v = i % C::VPP, pix = i / C::VPP;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a)
     auto store_stage = [&]() {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + j * 256;
+            const int i = tid + j * C::THREADS;
             if (i < NH) {
                 const int v = i % C::VPP, pix = i / C::VPP;
                 const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
@@ -165,19 +166,19 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs a)
     tile_epilogue<T, MT, C::NT>(acc, e, b, oy0, ox0, cout0, wv, r, h);
 }
 
-template <typename T, int KS, int STRIDE, int MT, int CK, int TH>
+template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4>
 static int launch_conv_cfg(const ConvArgs &a0, hipStream_t st)
 {
-    using C = ConvCfg<T, KS, STRIDE, MT, CK, TH>;
+    using C = ConvCfg<T, KS, STRIDE, MT, CK, TH, WAVES>;
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     ConvArgs a = a0;
     a.tiles_x = cdiv(a.Wo, C::TW);
     a.tiles_y = cdiv(a.Ho, TH);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
-    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
-                        CK, TH))
+    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
+                        CK, TH, WAVES))
         return H3D_OK;
-    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("conv_kernel");
     return H3D_OK;
 }
@@ -198,7 +199,8 @@ template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipSt
                 if (nblk(16, 64) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 16>(a, st);
                 return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 8>(a, st);
             }
-            if (nblk(16, 128) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 16>(a, st);
+            // 8 waves x (32 px x 128 ch), CK = 32: a chunk's MFMA time now exceeds the prefetch latency
+            if (nblk(16, 128) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 4, 32, 16, 8>(a, st);
             if (nblk(8, 128) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 8>(a, st);
             return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 8>(a, st);
         }
