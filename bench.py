@@ -200,10 +200,17 @@ def main():
             total_ms = sum(g["ms"] for g in groups.values())
             name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes of this build
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError, KeyError):
+                pass
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1),
                                 "peak": PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                                 "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                                "traffic": None, "launches_per_step": g["launches"],
+                                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, "
+                                "separate --pmc passes)" if traffic else None, "launches_per_step": g["launches"],
                                 "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                                 "share_of_network_time": round(g["ms"] / total_ms, 3),
                                 "network_ms_per_step": round(total_ms, 3)}
