@@ -97,10 +97,23 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__re
         s_hist[tid] = 0;
         __syncthreads();
         const int sh = pass * 8;
+        // run-length aggregation: NMS leaves most of a heat map at exactly 0 (one hot bin), so a plain
+        // atomic per element would serialise ~HW LDS atomics on one address
+        uint32_t run_bin = 0xffffffffu, run_cnt = 0;
         for (int i = tid; i < HW; i += NMS_THREADS) {
             const uint32_t k = s_key[i];
-            if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> sh) & 255u], 1u);
+            if ((k & pmask) == prefix) {
+                const uint32_t bin = (k >> sh) & 255u;
+                if (bin == run_bin) {
+                    ++run_cnt;
+                } else {
+                    if (run_cnt) atomicAdd(&s_hist[run_bin], run_cnt);
+                    run_bin = bin;
+                    run_cnt = 1;
+                }
+            }
         }
+        if (run_cnt) atomicAdd(&s_hist[run_bin], run_cnt);
         __syncthreads();
         // inclusive suffix sum over bins (Hillis-Steele, 8 steps)
         uint32_t v = s_hist[tid];
