@@ -151,29 +151,18 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict
 #pragma unroll
     for (int q = 0; q < PT; ++q) { acc[q][0] = t0; acc[q][1] = t1; acc[q][2] = t2; }
     const size_t V3 = (size_t)V * 3;
-    // 217 = 31 x 7: seven k-steps per iteration with their 21 direction loads issued together, so the
-    // L2 latency is paid once per 7 steps (the plain loop was latency-bound at 27 % of the FMA rate)
-    static_assert(NC % 7 == 0, "k unroll");
-#pragma unroll 1
-    for (int k0 = 0; k0 < NC; k0 += 7) {
-        float d[7][3];
+#pragma unroll 2
+    for (int k = 0; k < NC; ++k) {
+        const float *dp = (k < SMPL_NB) ? (shapedirsT + (size_t)k * V3) : (posedirsT + (size_t)(k - SMPL_NB) * V3);
+        const float d0 = dp[vc], d1 = dp[V + vc], d2 = dp[2 * V + vc];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            const int k = k0 + u;
-            const float *dp = (k < SMPL_NB) ? (shapedirsT + (size_t)k * V3) : (posedirsT + (size_t)(k - SMPL_NB) * V3);
-            d[u][0] = dp[vc]; d[u][1] = dp[V + vc]; d[u][2] = dp[2 * V + vc];
-        }
+        for (int q4 = 0; q4 < PT / 4; ++q4) {
+            const f32x4 c = *reinterpret_cast<const f32x4 *>(&s_coef[k][q4 * 4]);
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
-#pragma unroll
-            for (int q4 = 0; q4 < PT / 4; ++q4) {
-                const f32x4 c = *reinterpret_cast<const f32x4 *>(&s_coef[k0 + u][q4 * 4]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[q4 * 4 + e][0] = fmaf(d[u][0], c[e], acc[q4 * 4 + e][0]);
-                    acc[q4 * 4 + e][1] = fmaf(d[u][1], c[e], acc[q4 * 4 + e][1]);
-                    acc[q4 * 4 + e][2] = fmaf(d[u][2], c[e], acc[q4 * 4 + e][2]);
-                }
+            for (int e = 0; e < 4; ++e) {
+                acc[q4 * 4 + e][0] = fmaf(d0, c[e], acc[q4 * 4 + e][0]);
+                acc[q4 * 4 + e][1] = fmaf(d1, c[e], acc[q4 * 4 + e][1]);
+                acc[q4 * 4 + e][2] = fmaf(d2, c[e], acc[q4 * 4 + e][2]);
             }
         }
     }
