@@ -57,8 +57,9 @@ SIGNATURES = {
     "h3d_multi_pose_assemble": [c_vp] * 13 + [c_i] * 5 + [c_vp, c_vp],
     "h3d_ctdet_assemble": [c_vp] * 7 + [c_i] * 6 + [c_vp, c_vp],
     "h3d_multi_pose_post_process": [c_vp] * 3 + [c_i] * 5 + [c_vp, c_vp],
-    "h3d_smpl_pose": [c_vp] * 5 + [c_i] + [c_vp] * 3 + [c_vp],
-    "h3d_smpl_verts": [c_vp] * 8 + [c_i] * 3 + [c_vp, c_vp],
+    "h3d_smpl_pose": [c_vp] * 5 + [c_i] + [c_vp] * 4 + [c_i, c_vp],
+    "h3d_smpl_verts": [c_vp] * 8 + [c_i] * 4 + [c_vp, c_vp],
+    "h3d_smpl_verts2": [c_vp] * 7 + [c_i] * 5 + [c_vp, c_vp],
     "h3d_sigmoid_clamp": [c_vp, c_vp, ctypes.c_size_t, c_vp],
 }
 

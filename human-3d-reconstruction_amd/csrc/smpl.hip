@@ -20,13 +20,16 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__
                                                        const float *__restrict__ j_shapedirs,
                                                        const int32_t *__restrict__ parents, int P,
                                                        float *__restrict__ pose_feat, float *__restrict__ A,
-                                                       float *__restrict__ joints)
+                                                       float *__restrict__ joints, float *__restrict__ coefT, int Ppad)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     float beta[SMPL_NB];
 #pragma unroll
-    for (int k = 0; k < SMPL_NB; ++k) beta[k] = betas[(size_t)p * SMPL_NB + k];
+    for (int k = 0; k < SMPL_NB; ++k) {
+        beta[k] = betas[(size_t)p * SMPL_NB + k];
+        if (coefT) coefT[(size_t)k * Ppad + p] = beta[k];      // k-major [beta | pose_feat] for the verts kernel
+    }
     // global transforms G_j = [R | t], kept in registers/scratch per lane (24 x 12 floats)
     float G[SMPL_J][12];
     float Jp[SMPL_J][3];
@@ -65,7 +68,11 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__
         if (j > 0) {
             float *pf = pose_feat + (size_t)p * SMPL_PF + (j - 1) * 9;
 #pragma unroll
-            for (int i = 0; i < 9; ++i) pf[i] = R[i] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f);
+            for (int i = 0; i < 9; ++i) {
+                const float f = R[i] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f);
+                pf[i] = f;
+                if (coefT) coefT[(size_t)(SMPL_NB + (j - 1) * 9 + i) * Ppad + p] = f;
+            }
         }
         const int par = parents[j];
         if (par < 0) {
@@ -100,13 +107,14 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__
 }
 
 extern "C" int h3d_smpl_pose(const float *betas, const float *thetas, const float *j_template, const float *j_shapedirs,
-                             const int32_t *parents, int P, float *pose_feat, float *A, float *joints, void *stream)
+                             const int32_t *parents, int P, float *pose_feat, float *A, float *joints, float *coefT,
+                             int Ppad, void *stream)
 {
     if (!betas || !thetas || !j_template || !j_shapedirs || !parents || !pose_feat || !A || !joints)
         H3D_FAIL(H3D_ERR_ARG, "smpl_pose: null pointer");
-    if (P <= 0) H3D_FAIL(H3D_ERR_SHAPE, "smpl_pose: P=%d", P);
+    if (P <= 0 || (coefT && Ppad < P)) H3D_FAIL(H3D_ERR_SHAPE, "smpl_pose: P=%d Ppad=%d", P, Ppad);
     hipLaunchKernelGGL(smpl_pose_kernel, dim3(cdiv(P, 64)), dim3(64), 0, (hipStream_t)stream, betas, thetas, j_template,
-                       j_shapedirs, parents, P, pose_feat, A, joints);
+                       j_shapedirs, parents, P, pose_feat, A, joints, coefT, Ppad);
     H3D_CHECK_LAUNCH("smpl_pose_kernel");
     return H3D_OK;
 }
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict
                                                          const float *__restrict__ shapedirsT,
                                                          const float *__restrict__ posedirsT,
                                                          const int32_t *__restrict__ lbs_idx, const float *__restrict__ lbs_w,
-                                                         int nnz, int P, int V, float *__restrict__ verts)
+                                                         int nnz, int P, int V, int Vpad, float *__restrict__ verts)
 {
     constexpr int NC = SMPL_NB + SMPL_PF;  // 217
     __shared__ __attribute__((aligned(16))) float s_coef[NC][PT];
@@ -147,14 +155,14 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict
     __syncthreads();
     const int vc = v < V ? v : V - 1;      // clamp: out-of-range lanes compute a duplicate and do not store
     float acc[PT][3];
-    const float t0 = v_template[vc], t1 = v_template[V + vc], t2 = v_template[2 * V + vc];
+    const float t0 = v_template[vc], t1 = v_template[Vpad + vc], t2 = v_template[2 * Vpad + vc];
 #pragma unroll
     for (int q = 0; q < PT; ++q) { acc[q][0] = t0; acc[q][1] = t1; acc[q][2] = t2; }
-    const size_t V3 = (size_t)V * 3;
+    const size_t V3 = (size_t)Vpad * 3;
 #pragma unroll 2
     for (int k = 0; k < NC; ++k) {
         const float *dp = (k < SMPL_NB) ? (shapedirsT + (size_t)k * V3) : (posedirsT + (size_t)(k - SMPL_NB) * V3);
-        const float d0 = dp[vc], d1 = dp[V + vc], d2 = dp[2 * V + vc];
+        const float d0 = dp[vc], d1 = dp[Vpad + vc], d2 = dp[2 * Vpad + vc];
 #pragma unroll
         for (int q4 = 0; q4 < PT / 4; ++q4) {
             const f32x4 c = *reinterpret_cast<const f32x4 *>(&s_coef[k][q4 * 4]);
@@ -212,24 +220,185 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Generation 2 of the vertex kernel (gen 1 above was latency-bound on per-lane L2 loads: 42 TFLOP/s).
+// Workgroup = 64 vertices x 128 persons: lane = vertex, wave w = persons [32w, 32w+32).  The
+// direction tensors [k][3][Vpad] and the k-major coefficients coefT[k][Ppad] are streamed through
+// LDS in chunks of 31 k (217 = 7 x 31), double buffered with a register prefetch, so every
+// direction element is fetched from L2 once per 128 persons and the inner loop only touches LDS:
+// 3 conflict-free ds_read_b32 + 8 broadcast ds_read_b128 per 96 FMAs.  LBS: the 3x4 transforms of
+// 16 persons per wave are staged into the (then idle) stream buffers, twice.
+constexpr int SV_KC = 31, SV_VT = 64, SV_PT = 32, SV_PB = 128;
+__global__ __launch_bounds__(256) void smpl_verts2_kernel(const float *__restrict__ coefT, const float *__restrict__ A,
+                                                          const float *__restrict__ v_template,
+                                                          const float *__restrict__ shapedirsT,
+                                                          const float *__restrict__ posedirsT,
+                                                          const int32_t *__restrict__ lbs_idx, const float *__restrict__ lbs_w,
+                                                          int nnz, int P, int Ppad, int V, int Vpad, float *__restrict__ verts)
+{
+    constexpr int NC = SMPL_NB + SMPL_PF;            // 217
+    constexpr int DCH = SV_KC * 3 * SV_VT;           // floats of one direction chunk
+    constexpr int CCH = SV_KC * SV_PB;               // floats of one coefficient chunk
+    constexpr int BUF = DCH + CCH;
+    static_assert(NC % SV_KC == 0, "k chunking");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int v0 = blockIdx.x * SV_VT, p0 = blockIdx.y * SV_PB;
+    const int v = v0 + lane;
+    constexpr int ND = DCH / 4 / 256 + 1, NCV = CCH / 4 / 256 + 1;   // float4 per thread (rounded up)
+    f32x4 sd[ND], sc[NCV];
+    auto load_chunk = [&](int ch) {
+        const int k0 = ch * SV_KC;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + j * 256;                 // float4 index inside [KC][3][64]
+            sd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < DCH / 4) {
+                const int row = i / (SV_VT / 4), q = i - row * (SV_VT / 4);   // row = kl*3 + c
+                const int k = k0 + row / 3, c = row - (row / 3) * 3;
+                const float *dp = (k < SMPL_NB) ? (shapedirsT + ((size_t)k * 3 + c) * Vpad)
+                                                : (posedirsT + ((size_t)(k - SMPL_NB) * 3 + c) * Vpad);
+                sd[j] = *reinterpret_cast<const f32x4 *>(dp + v0 + 4 * q);    // Vpad, v0 multiples of 64: aligned, in bounds
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCV; ++j) {
+            const int i = tid + j * 256;                 // float4 index inside [KC][128]
+            sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < CCH / 4) {
+                const int kl = i / (SV_PB / 4), q = i - kl * (SV_PB / 4);
+                sc[j] = *reinterpret_cast<const f32x4 *>(coefT + (size_t)(k0 + kl) * Ppad + p0 + 4 * q);   // Ppad multiple of 128
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float *d = smem + buf * BUF, *c = d + DCH;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + j * 256;
+            if (i < DCH / 4) *reinterpret_cast<f32x4 *>(d + 4 * i) = sd[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NCV; ++j) {
+            const int i = tid + j * 256;
+            if (i < CCH / 4) *reinterpret_cast<f32x4 *>(c + 4 * i) = sc[j];
+        }
+    };
+
+    const int vc = v < V ? v : V - 1;
+    float acc[SV_PT][3];
+    {
+        const float t0 = v_template[vc], t1 = v_template[Vpad + vc], t2 = v_template[2 * Vpad + vc];
+#pragma unroll
+        for (int q = 0; q < SV_PT; ++q) { acc[q][0] = t0; acc[q][1] = t1; acc[q][2] = t2; }
+    }
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    constexpr int NCH = NC / SV_KC;
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) load_chunk(ch + 1);
+        const float *d = smem + (ch & 1) * BUF, *c = d + DCH + wv * SV_PT;
+#pragma unroll 1
+        for (int kl = 0; kl < SV_KC; ++kl) {
+            const float d0 = d[(kl * 3 + 0) * SV_VT + lane], d1 = d[(kl * 3 + 1) * SV_VT + lane], d2 = d[(kl * 3 + 2) * SV_VT + lane];
+#pragma unroll
+            for (int q4 = 0; q4 < SV_PT / 4; ++q4) {
+                const f32x4 cf = *reinterpret_cast<const f32x4 *>(c + kl * SV_PB + 4 * q4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[q4 * 4 + e][0] = fmaf(d0, cf[e], acc[q4 * 4 + e][0]);
+                    acc[q4 * 4 + e][1] = fmaf(d1, cf[e], acc[q4 * 4 + e][1]);
+                    acc[q4 * 4 + e][2] = fmaf(d2, cf[e], acc[q4 * 4 + e][2]);
+                }
+            }
+        }
+        if (ch + 1 < NCH) store_chunk((ch + 1) & 1);
+        __syncthreads();
+    }
+    // ---- LBS: stage the 3x4 transforms of 16 persons per wave (4 x 16 x 288 floats) into smem, twice ----
+    int jidx[4];
+    float jw[4];
+#pragma unroll
+    for (int sI = 0; sI < 4; ++sI) {
+        jidx[sI] = sI < nnz ? lbs_idx[(size_t)vc * nnz + sI] : 0;
+        jw[sI] = sI < nnz ? lbs_w[(size_t)vc * nnz + sI] : 0.f;
+    }
+    static_assert(4 * 16 * SMPL_J * 12 <= 2 * BUF, "A staging fits the stream buffers");
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();
+        // each wave stages its own 16 persons: [16][288] floats = 1152 float4, 18 per lane
+        float *sA = smem + wv * (16 * SMPL_J * 12);
+        for (int i = lane; i < 16 * SMPL_J * 3; i += 64) {
+            const int q = i / (SMPL_J * 3), r = i - q * (SMPL_J * 3);
+            const int p = p0 + wv * SV_PT + half * 16 + q;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (p < P) val = *reinterpret_cast<const f32x4 *>(A + (size_t)p * SMPL_J * 12 + 4 * r);
+            *reinterpret_cast<f32x4 *>(sA + q * SMPL_J * 12 + 4 * r) = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = p0 + wv * SV_PT + half * 16 + q;
+            float T[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = 0.f;
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const float *Ap = sA + q * SMPL_J * 12 + jidx[sI] * 12;
+#pragma unroll
+                for (int i4 = 0; i4 < 3; ++i4) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(Ap + 4 * i4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) T[4 * i4 + e] = fmaf(jw[sI], a4[e], T[4 * i4 + e]);
+                }
+            }
+            const float x = acc[half * 16 + q][0], y = acc[half * 16 + q][1], z = acc[half * 16 + q][2];
+            if (v < V && p < P) {
+                float *o = verts + ((size_t)p * V + v) * 3;
+                o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+                o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+                o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+            }
+        }
+    }
+}
+
+extern "C" int h3d_smpl_verts2(const float *coefT, const float *A, const float *v_template, const float *shapedirsT,
+                               const float *posedirsT, const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad,
+                               int V, int Vpad, float *verts, void *stream)
+{
+    if (!coefT || !A || !v_template || !shapedirsT || !posedirsT || !lbs_idx || !lbs_w || !verts)
+        H3D_FAIL(H3D_ERR_ARG, "smpl_verts2: null pointer");
+    if (P <= 0 || V <= 0 || nnz <= 0 || nnz > 4 || Ppad % SV_PB || Ppad < P || Vpad % SV_VT || Vpad < V)
+        H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts2: P=%d (pad %d, multiple of %d) V=%d (pad %d, multiple of %d) nnz=%d (<= 4)", P, Ppad,
+                 SV_PB, V, Vpad, SV_VT, nnz);
+    dim3 grid(Vpad / SV_VT, Ppad / SV_PB);
+    hipLaunchKernelGGL(smpl_verts2_kernel, grid, dim3(256), 0, (hipStream_t)stream, coefT, A, v_template, shapedirsT, posedirsT,
+                       lbs_idx, lbs_w, nnz, P, Ppad, V, Vpad, verts);
+    H3D_CHECK_LAUNCH("smpl_verts2_kernel");
+    return H3D_OK;
+}
+
 extern "C" int h3d_smpl_verts(const float *betas, const float *pose_feat, const float *A, const float *v_template,
                               const float *shapedirsT, const float *posedirsT, const int32_t *lbs_idx, const float *lbs_w,
-                              int nnz, int P, int V, float *verts, void *stream)
+                              int nnz, int P, int V, int Vpad, float *verts, void *stream)
 {
     if (!betas || !pose_feat || !A || !v_template || !shapedirsT || !posedirsT || !lbs_idx || !lbs_w || !verts)
         H3D_FAIL(H3D_ERR_ARG, "smpl_verts: null pointer");
-    if (P <= 0 || V <= 0 || nnz <= 0 || nnz > SMPL_J) H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts: P=%d V=%d nnz=%d", P, V, nnz);
+    if (P <= 0 || V <= 0 || Vpad < V || nnz <= 0 || nnz > SMPL_J) H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts: P=%d V=%d nnz=%d", P, V, nnz);
     dim3 grid(cdiv(V, 256), 1);
     if (P >= 64) {
         constexpr int PT = 32;
         grid.y = cdiv(P, PT);
         hipLaunchKernelGGL(smpl_verts_kernel<PT>, grid, dim3(256), 0, (hipStream_t)stream, betas, pose_feat, A, v_template,
-                           shapedirsT, posedirsT, lbs_idx, lbs_w, nnz, P, V, verts);
+                           shapedirsT, posedirsT, lbs_idx, lbs_w, nnz, P, V, Vpad, verts);
     } else {
         constexpr int PT = 8;
         grid.y = cdiv(P, PT);
         hipLaunchKernelGGL(smpl_verts_kernel<PT>, grid, dim3(256), 0, (hipStream_t)stream, betas, pose_feat, A, v_template,
-                           shapedirsT, posedirsT, lbs_idx, lbs_w, nnz, P, V, verts);
+                           shapedirsT, posedirsT, lbs_idx, lbs_w, nnz, P, V, Vpad, verts);
     }
     H3D_CHECK_LAUNCH("smpl_verts_kernel");
     return H3D_OK;

@@ -83,12 +83,19 @@ def _device_pack(model, device, nnz=None):
     j_template = (Jr @ model.v_template.astype(np.float64)).astype(np.float32)                 # [24,3]
     j_dirs = np.einsum("jv,vck->jck", Jr, model.shapedirs.astype(np.float64)).astype(np.float32)  # [24,3,10]
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    Vpad = ((V + 63) // 64) * 64
+
+    def soa(a):                 # [..., V] -> [..., Vpad] zero padded
+        out = np.zeros(a.shape[:-1] + (Vpad,), np.float32)
+        out[..., :V] = a
+        return out
     return {
-        "V": V, "nnz": nnz,
-        # struct-of-arrays: [3][V] and [k][3][V], so a wave's load of one coordinate is one contiguous row
-        "v_template": to(model.v_template.T),
-        "shapedirsT": to(model.shapedirs.transpose(2, 1, 0)),
-        "posedirsT": to(model.posedirs.transpose(2, 1, 0)),
+        "V": V, "Vpad": Vpad, "nnz": nnz,
+        # struct-of-arrays with padded rows: [3][Vpad] and [k][3][Vpad] -- a wave's load of one
+        # coordinate is one contiguous, 16-byte aligned row
+        "v_template": to(soa(model.v_template.T)),
+        "shapedirsT": to(soa(model.shapedirs.transpose(2, 1, 0))),
+        "posedirsT": to(soa(model.posedirs.transpose(2, 1, 0))),
         "j_template": to(j_template.reshape(-1)),
         "j_shapedirs": to(j_dirs.reshape(NUM_JOINTS * 3, NUM_BETAS)),
         "parents": to(model.parents.astype(np.int32)),
@@ -96,8 +103,10 @@ def _device_pack(model, device, nnz=None):
     }
 
 
-def lbs(model, betas, thetas, return_joints=False):
-    """betas [P,10], thetas [P,72] (CUDA fp32) -> vertices [P,V,3] (and posed joints [P,24,3])."""
+def lbs(model, betas, thetas, return_joints=False, kernel="auto"):
+    """betas [P,10], thetas [P,72] (CUDA fp32) -> vertices [P,V,3] (and posed joints [P,24,3]).
+    kernel: "gen2" = LDS-streamed kernel (needs <= 4 skinning weights per vertex), "gen1" = register
+    kernel, "auto" = gen2 when applicable and P >= 64."""
     import torch
     from . import _lib
     _lib.require_cuda(betas, thetas)
@@ -113,11 +122,21 @@ def lbs(model, betas, thetas, return_joints=False):
     joints = torch.empty(P, NUM_JOINTS, 3, dtype=torch.float32, device=dev)
     verts = torch.empty(P, d["V"], 3, dtype=torch.float32, device=dev)
     L, st = _lib.lib(), _lib.stream_ptr()
+    gen2 = kernel == "gen2" or (kernel == "auto" and d["nnz"] <= 4 and P >= 64)
+    Ppad = ((P + 127) // 128) * 128
+    coefT = torch.zeros(NUM_BETAS + NUM_POSE_FEAT, Ppad, dtype=torch.float32, device=dev) if gen2 else None
     with torch.cuda.device(dev):
         _lib.check(L.h3d_smpl_pose(_lib.ptr(betas), _lib.ptr(thetas), _lib.ptr(d["j_template"]),
                                    _lib.ptr(d["j_shapedirs"]), _lib.ptr(d["parents"]), P, _lib.ptr(pf),
-                                   _lib.ptr(A), _lib.ptr(joints), st), "smpl_pose")
-        _lib.check(L.h3d_smpl_verts(_lib.ptr(betas), _lib.ptr(pf), _lib.ptr(A), _lib.ptr(d["v_template"]),
-                                    _lib.ptr(d["shapedirsT"]), _lib.ptr(d["posedirsT"]), _lib.ptr(d["lbs_idx"]),
-                                    _lib.ptr(d["lbs_w"]), d["nnz"], P, d["V"], _lib.ptr(verts), st), "smpl_verts")
+                                   _lib.ptr(A), _lib.ptr(joints), _lib.ptr(coefT), Ppad, st), "smpl_pose")
+        if gen2:
+            _lib.check(L.h3d_smpl_verts2(_lib.ptr(coefT), _lib.ptr(A), _lib.ptr(d["v_template"]),
+                                         _lib.ptr(d["shapedirsT"]), _lib.ptr(d["posedirsT"]), _lib.ptr(d["lbs_idx"]),
+                                         _lib.ptr(d["lbs_w"]), d["nnz"], P, Ppad, d["V"], d["Vpad"], _lib.ptr(verts), st),
+                       "smpl_verts2")
+        else:
+            _lib.check(L.h3d_smpl_verts(_lib.ptr(betas), _lib.ptr(pf), _lib.ptr(A), _lib.ptr(d["v_template"]),
+                                        _lib.ptr(d["shapedirsT"]), _lib.ptr(d["posedirsT"]), _lib.ptr(d["lbs_idx"]),
+                                        _lib.ptr(d["lbs_w"]), d["nnz"], P, d["V"], d["Vpad"], _lib.ptr(verts), st),
+                       "smpl_verts")
     return (verts, joints) if return_joints else verts

@@ -197,20 +197,27 @@ int h3d_multi_pose_post_process(const float *dets, const float *c, const float *
 /* =====================================================================================
  * 4. SMPL pose/shape -> LBS mesh (north_star; no reference code: published formulation).
  *    Model tensors are packed by the host (h3d_amd/smpl.py: SMPLModel.device_pack):
- *      v_template [3][V], shapedirsT [10][3][V], posedirsT [207][3][V], j_template [24*3],
+ *      v_template [3][Vpad], shapedirsT [10][3][Vpad], posedirsT [207][3][Vpad], j_template [24*3],
  *      j_shapedirs [24*3][10], parents i32[24], lbs_idx i32[V][nnz], lbs_w f32[V][nnz]
  * ===================================================================================== */
 /* per person: Rodrigues (24), pose feature (207), joints, kinematic chain.
  *   betas [P,10], thetas [P,72] -> pose_feat [P,207], A [P,24,12] (3x4 skinning transforms),
- *   joints [P,24,3] (posed joint positions) */
+ *   joints [P,24,3] (posed joint positions); if coefT != NULL also the k-major coefficient matrix
+ *   coefT [217][Ppad] = [beta | pose_feat]^T consumed by h3d_smpl_verts2 (Ppad multiple of 128). */
 int h3d_smpl_pose(const float *betas, const float *thetas, const float *j_template,
                   const float *j_shapedirs, const int32_t *parents, int P,
-                  float *pose_feat, float *A, float *joints, void *stream);
-/* blend shapes + LBS: verts [P,V,3] */
+                  float *pose_feat, float *A, float *joints, float *coefT, int Ppad, void *stream);
+/* blend shapes + LBS: verts [P,V,3].  Model tensors struct-of-arrays with row stride Vpad:
+ * v_template [3][Vpad], shapedirsT [10][3][Vpad], posedirsT [207][3][Vpad]. */
 int h3d_smpl_verts(const float *betas, const float *pose_feat, const float *A,
                    const float *v_template, const float *shapedirsT, const float *posedirsT,
-                   const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int V,
+                   const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int V, int Vpad,
                    float *verts, void *stream);
+/* same result, LDS-streamed generation 2 (needs nnz <= 4, Vpad % 64 == 0, Ppad % 128 == 0). */
+int h3d_smpl_verts2(const float *coefT, const float *A, const float *v_template,
+                    const float *shapedirsT, const float *posedirsT, const int32_t *lbs_idx,
+                    const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad, float *verts,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -17,13 +17,14 @@ def model():
     return smpl.SMPLModel.synthetic(seed=0)
 
 
-def test_lbs_matches_fp64_oracle(model):
-    P = 19                                               # not a multiple of the person tile
+@pytest.mark.parametrize("kernel,P", [("gen1", 19), ("gen2", 19), ("gen2", 150), ("gen1", 70)])
+def test_lbs_matches_fp64_oracle(model, kernel, P):
     betas = synth.normalish("betas", (P, 10), 0.0, 1.0, 1)
     thetas = synth.normalish("thetas", (P, 72), 0.0, 0.3, 1)
     thetas[3] = 0.0                                      # rest pose
     thetas[4, :3] = [0.0, 3.0, 0.0]                      # large global rotation
-    v, j = smpl.lbs(model, torch.from_numpy(betas).to(DEV), torch.from_numpy(thetas).to(DEV), return_joints=True)
+    v, j = smpl.lbs(model, torch.from_numpy(betas).to(DEV), torch.from_numpy(thetas).to(DEV), return_joints=True,
+                    kernel=kernel)
     v_ref, j_ref = osmpl.lbs(betas, thetas, model.numpy_dict())
     assert np.abs(v.cpu().numpy() - v_ref).max() < 1e-4
     assert np.abs(j.cpu().numpy() - j_ref).max() < 1e-4
