@@ -1,0 +1,343 @@
+// DeformConv with its offset/mask convolution fused in (reference model.py:346-362 DeformConv ->
+// dcn_v2.py:118-128 DCN.forward: conv_offset_mask -> chunk/cat/sigmoid -> dcn_v2_conv -> BN -> ReLU).
+//
+// One workgroup = 16x16 output pixels x (32*MT) channels, 8 waves x (32 px), two phases that share
+// one register-prefetch pipeline over channel chunks:
+//   phase A  plain 3x3 conv of the apron tile with the 27 offset/mask filters (32 MFMA rows):
+//            the offsets never go to HBM (the reference materialises them as a [B,27,H,W] tensor and
+//            re-reads it once per channel in the im2col kernel, dcn_v2_im2col_cuda.cu:170-172).
+//            The host permutes the 27 filters over the 32 accumulator rows so that lane half h of
+//            a pixel ends up holding complete (dh, dw, mask) triples: h=0 -> taps 0..4, h=1 -> 5..8.
+//   geometry each half computes the sampling geometry of ITS taps only (no duplication) and the two
+//            halves exchange the results with one cross-half shuffle per value.
+//   phase B  dcn2's branch-free gather + fp16 blend + MFMA over the same chunks (csrc/dcn2.hip).
+//   pass 2   (rare) samples whose corners left the apron: offsets are re-broadcast from the phase-A
+//            accumulators, corners gathered from global memory.
+#include "common.h"
+#include "epilogue.h"
+#include "dcn_traits.h"
+
+struct Dcn3Args {
+    const char *in;
+    const char *w;      // main weights [rows][9][Cin] of S
+    const char *woff;   // offset/mask weights [32][9][Cin] of S, rows permuted (engine.pack_offset_conv)
+    const float *bias;  // [rows] main bias followed by [32] permuted offset bias
+    char *out;
+    int B, H, W, Cin, in_cs;
+    int Cout, out_cs, relu, out_mode, wrows;
+    int tiles_x, tiles_y;
+};
+
+template <typename T, int MT, int CK, int MARGIN>
+struct Dcn3Cfg {
+    static constexpr int ES = sizeof(T);
+    static constexpr int SS = SE<T>::SS;
+    static constexpr int HH = 16 + 2 + 2 * MARGIN;
+    static constexpr int SBH = CK * SS + 16;
+    static constexpr int RBH = HH * SBH;
+    static constexpr int WB = 9 * CK * SS + 16;
+    static constexpr int BN = 32 * MT;
+    static constexpr int THREADS = 512;
+    static constexpr int VPP = CK * SS / 16;
+    static constexpr int LDS_H = HH * RBH;
+    static constexpr int LDS = LDS_H + BN * WB;
+};
+
+template <typename T, int MT, int CK, int MARGIN>
+__global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
+{
+    using C = Dcn3Cfg<T, MT, CK, MARGIN>;
+    using X = SE<T>;
+    constexpr int ES = C::ES, SS = C::SS;
+    __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+    char *s_h = smem;
+    char *s_w = smem + C::LDS_H;
+
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int hy0 = oy0 - 1 - MARGIN, hx0 = ox0 - 1 - MARGIN;
+    const int cout0 = blockIdx.y * C::BN;
+    const int py = wv * 2 + (r >> 4), px = r & 15;          // this lane's pixel inside the tile
+    const int oy = oy0 + py, ox = ox0 + px;
+    const bool live = (oy < a.H && ox < a.W);
+    const char *img = a.in + (size_t)b * a.H * a.W * a.in_cs * ES;
+    const int aoff = r * C::WB + 8 * h * SS;
+    const int nchunks = a.Cin / CK;
+
+    // ---- one staging pipeline for both phases: stage s < nchunks = (apron chunk s, offset filters),
+    //      stage s >= nchunks = (apron chunk s - nchunks, main filters) ---------------------------------
+    constexpr int WV = 9 * C::VPP;
+    constexpr int NH = C::HH * C::HH * C::VPP, NW = C::BN * WV;
+    constexpr int NV = (NH + NW + C::THREADS - 1) / C::THREADS;
+    u32x4 stg[NV];
+    auto load_stage = [&](int s) {
+        const bool phaseA = s < nchunks;
+        const int c0 = (phaseA ? s : s - nchunks) * CK;
+        const char *wsrc = phaseA ? a.woff : a.w;
+        const int wr0 = phaseA ? 0 : cout0;
+        const int nrows = phaseA ? 32 : C::BN;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * C::THREADS;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (i < NH) {
+                const int v = i % C::VPP, pix = i / C::VPP;
+                const int iy = pix / C::HH, ix = pix - iy * C::HH;
+                const int gy = hy0 + iy, gx = hx0 + ix;
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    val = *reinterpret_cast<const u32x4 *>(img + ((size_t)(gy * a.W + gx) * a.in_cs + c0) * ES + v * 16);
+            } else if (i < NH + NW) {
+                const int q0 = i - NH;
+                const int row = q0 / WV, q = q0 - row * WV;
+                const int tap = q / C::VPP, v = q - tap * C::VPP;
+                if (row < nrows)
+                    val = *reinterpret_cast<const u32x4 *>(wsrc + (((size_t)(wr0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+            }
+            stg[j] = val;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * C::THREADS;
+            if (i < NH) {
+                const int v = i % C::VPP, pix = i / C::VPP;
+                const int iy = pix / C::HH, ix = pix - iy * C::HH;
+                *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + v * 16) = X::convert16(stg[j]);
+            } else if (i < NH + NW) {
+                const int q0 = i - NH;
+                const int row = q0 / WV, q = q0 - row * WV;
+                const int tap = q / C::VPP, v = q - tap * C::VPP;
+                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = stg[j];
+            }
+        }
+    };
+
+    // ================= phase A: offsets/mask = conv3x3(x; 27 filters) ===============================
+    f32x16 aoffs;   // rows (i&3)+8(i>>2)+4h of the permuted offset conv for this lane's pixel
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aoffs[i] = 0.f;
+    const int bconv = (MARGIN + py) * C::RBH + (MARGIN + px) * C::SBH + 8 * h * SS;   // tap (0,0) of the plain conv
+    load_stage(0);
+    for (int s = 0; s < nchunks; ++s) {
+        if (s) __syncthreads();
+        store_stage();
+        __syncthreads();
+        load_stage(s + 1);                       // s + 1 == nchunks is phase B's first stage
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int kk = 0; kk < CK / 16; ++kk) {
+                const typename X::frag fa = X::lds(s_w + aoff + (tap * CK + kk * 16) * SS);
+                const typename X::frag fb = X::lds(s_h + bconv + dy * C::RBH + dx * C::SBH + kk * 16 * SS);
+                X::mma(aoffs, fa, fb);
+            }
+        }
+    }
+    {   // + bias (permuted like the rows)
+        const float *bo = a.bias + a.wrows;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
+    }
+
+    // ================= geometry: my taps (h=0: 0..4, h=1: 5..8), then cross-half exchange ===========
+    int boff[9];
+    typename X::geo geo[9];
+    bool slow = false;
+    {
+        int my_off[5];
+        typename X::geo my_geo[5];
+        const int tb = h ? 5 : 0;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int tap = tb + u;
+            const int ti = tap / 3, tj = tap - ti * 3;
+            const float h_im = (float)(oy - 1 + ti) + aoffs[3 * u];
+            const float w_im = (float)(ox - 1 + tj) + aoffs[3 * u + 1];
+            const bool inside = live && tap < 9 && (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
+            typename X::geo g = X::zero_geo();
+            int off = 0;
+            if (inside) {
+                const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                const int ry = hl - hy0, rx = wl - hx0;
+                if (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH) {
+                    const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                    g = X::make_geo(w4, dcn2_sigmoid(aoffs[3 * u + 2]));
+                    off = ry * C::RBH + rx * C::SBH;
+                } else {
+                    slow = true;
+                }
+            }
+            my_off[u] = off;
+            my_geo[u] = g;
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int o_off = __shfl_xor(my_off[u], 32);
+            const typename X::geo o_geo = X::shfl_xor32(my_geo[u]);
+            // tap u (u < 5) belongs to half 0, tap 5 + u (u < 4) to half 1
+            boff[u] = (h == 0 ? my_off[u] : o_off) + 8 * h * SS;
+            geo[u] = (h == 0) ? my_geo[u] : o_geo;
+            if (u < 4) {
+                boff[5 + u] = (h == 1 ? my_off[u] : o_off) + 8 * h * SS;
+                geo[5 + u] = (h == 1) ? my_geo[u] : o_geo;
+            }
+        }
+    }
+
+    // ================= phase B: deformable contraction (branch-free, apron samples) ==================
+    f32x16 acc[MT][1];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
+    for (int s = nchunks; s < 2 * nchunks; ++s) {
+        __syncthreads();
+        store_stage();
+        __syncthreads();
+        if (s + 1 < 2 * nchunks) load_stage(s + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            typename X::frag fb[CK / 16];
+            const char *p00 = s_h + boff[tap];
+#pragma unroll
+            for (int kk = 0; kk < CK / 16; ++kk) {
+                typename X::frag v[4];
+                v[0] = X::lds(p00 + kk * 16 * SS);
+                v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
+                v[2] = X::lds(p00 + C::RBH + kk * 16 * SS);
+                v[3] = X::lds(p00 + C::RBH + C::SBH + kk * 16 * SS);
+                fb[kk] = X::blend(v, geo[tap]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < CK / 16; ++kk) {
+                typename X::frag fa[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb[kk]);
+            }
+        }
+    }
+
+    // ================= pass 2 (rare): samples whose corners left the apron ===========================
+    if (__syncthreads_or(slow ? 1 : 0)) {
+        for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+            __syncthreads();
+            for (int i = tid; i < C::BN * WV; i += C::THREADS) {
+                const int row = i / WV, q = i - row * WV;
+                const int tap = q / C::VPP, v = q - tap * C::VPP;
+                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = *reinterpret_cast<const u32x4 *>(
+                    a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ti = tap / 3, tj = tap - ti * 3;
+                // raw (dh, dw, mask logit) of this tap live in the half that owns it: broadcast to both
+                const int src = (tap < 5) ? r : r + 32, u = (tap < 5) ? tap : tap - 5;
+                const float d_h = __shfl(aoffs[3 * u], src), d_w = __shfl(aoffs[3 * u + 1], src),
+                            d_m = __shfl(aoffs[3 * u + 2], src);
+                typename X::frag fb[CK / 16];
+#pragma unroll
+                for (int kk = 0; kk < CK / 16; ++kk) fb[kk] = X::zero();
+                bool any = false;
+                const float h_im = (float)(oy - 1 + ti) + d_h;
+                const float w_im = (float)(ox - 1 + tj) + d_w;
+                if (live && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+                    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                    const int ry = hl - hy0, rx = wl - hx0;
+                    if (!(ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH)) {
+                        any = true;
+                        const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                        const typename X::geo g = X::make_geo(w4, dcn2_sigmoid(d_m));
+                        const bool okh0 = hl >= 0, okh1 = hl + 1 <= a.H - 1, okw0 = wl >= 0, okw1 = wl + 1 <= a.W - 1;
+                        const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+                        const int pix[4] = {hl * a.W + wl, hl * a.W + wl + 1, (hl + 1) * a.W + wl, (hl + 1) * a.W + wl + 1};
+#pragma unroll
+                        for (int kk = 0; kk < CK / 16; ++kk) {
+                            typename X::frag v[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                v[k] = ok[k] ? X::global8(img + ((size_t)pix[k] * a.in_cs + c0 + kk * 16 + 8 * h) * ES) : X::zero();
+                            fb[kk] = X::blend(v, g);
+                        }
+                    }
+                }
+                if (!__any(any)) continue;
+#pragma unroll
+                for (int kk = 0; kk < CK / 16; ++kk) {
+                    typename X::frag fa[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb[kk]);
+                }
+            }
+        }
+    }
+
+    EpiArgs e;
+    e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
+    e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
+    tile_epilogue<T, MT, 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+}
+
+template <typename T, int MT, int CK, int MARGIN>
+static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
+{
+    using C = Dcn3Cfg<T, MT, CK, MARGIN>;
+    static_assert(C::LDS <= 160 * 1024, "LDS budget");
+    Dcn3Args a = a0;
+    a.tiles_x = cdiv(a.W, 16);
+    a.tiles_y = cdiv(a.H, 16);
+    dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
+    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN)) return H3D_OK;
+    hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN>), grid, dim3(C::THREADS), 0, st, a);
+    H3D_CHECK_LAUNCH("dcn3_kernel");
+    return H3D_OK;
+}
+
+int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.w || !op.bias || !op.out || !op.in2) H3D_FAIL(H3D_ERR_ARG, "dcn_fused: null pointer");
+    const int es = op.dtype == H3D_BF16 ? 2 : 4;
+    if (op.ksize != 3 || op.stride != 1 || op.Ho != op.H || op.Wo != op.W)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused: covers 3x3 s1 p1 d1 dg1 only (k=%d s=%d)", op.ksize, op.stride);
+    if (op.Cin % 16 || op.in_cs % (16 / es) || op.Cin > op.in_cs)
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused: Cin=%d (stride %d) must be a multiple of 16", op.Cin, op.in_cs);
+    if (op.H > 32767 || op.W > 32767) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused: image larger than 32767");
+    if (op.wrows < ((op.Cout + 127) / 128) * 128)
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused: packed weight rows %d < Cout %d padded to 128", op.wrows, op.Cout);
+    if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused: out channel stride %d", op.out_cs);
+    Dcn3Args a;
+    a.in = (const char *)op.in; a.w = (const char *)op.w; a.woff = (const char *)op.in2; a.bias = op.bias;
+    a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
+    a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode; a.wrows = op.wrows;
+    a.tiles_x = a.tiles_y = 0;
+    if (op.dtype == H3D_BF16) {
+        if (op.Cin % 32 == 0 && op.Cout <= 64) {
+            if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 32, 2>(a, st);
+            return launch_dcn3_cfg<bf16_t, 2, 32, 2>(a, st);
+        }
+        if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 2>(a, st);
+        if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 2>(a, st);
+        return launch_dcn3_cfg<bf16_t, 4, 16, 2>(a, st);
+    }
+    if (op.dtype == H3D_F32) {
+        if (op.Cout <= 32) return launch_dcn3_cfg<float, 1, 16, 2>(a, st);
+        return launch_dcn3_cfg<float, 2, 16, 2>(a, st);
+    }
+    H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused: dtype %d", op.dtype);
+}

@@ -1,0 +1,147 @@
+// Sample-element traits shared by the DCN kernels (dcn2.hip, dcn3.hip): type of the LDS apron tile,
+// of the bilinear blend and of the MFMA operands (fp32 in parity mode, fp16 in bf16 mode).
+#pragma once
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+
+template <typename T> struct SE;  // "sample element": type of the LDS halo, the blend and the MFMA operands
+
+template <> struct SE<float> {
+    using S = float;
+    static constexpr int SS = 4;
+    struct frag { f32x4 lo, hi; };
+    static __device__ __forceinline__ frag lds(const char *p)
+    {
+        frag f;
+        f.lo = *reinterpret_cast<const f32x4 *>(p);
+        f.hi = *reinterpret_cast<const f32x4 *>(p + 16);
+        return f;
+    }
+    static __device__ __forceinline__ frag zero() { frag f; f.lo = f32x4{0, 0, 0, 0}; f.hi = f.lo; return f; }
+    static __device__ __forceinline__ void keep(const frag &f) { asm volatile("" ::"v"(f.lo), "v"(f.hi)); }
+    static __device__ __forceinline__ frag global8(const char *p) { return lds(p); }   // 8 floats
+    static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
+    {
+        ET<float>::frag fa, fb;
+        fa.lo = a.lo; fa.hi = a.hi; fb.lo = b.lo; fb.hi = b.hi;
+        ET<float>::mma(acc, fa, fb);
+    }
+    struct geo { float w[4]; float mask; };     // per (pixel, tap) blend coefficients kept in registers
+    static __device__ __forceinline__ geo make_geo(const float (&w)[4], float mask)
+    {
+        geo g;
+        g.w[0] = w[0]; g.w[1] = w[1]; g.w[2] = w[2]; g.w[3] = w[3]; g.mask = mask;
+        return g;
+    }
+    static __device__ __forceinline__ geo zero_geo() { geo g; g.w[0] = g.w[1] = g.w[2] = g.w[3] = 0.f; g.mask = 0.f; return g; }
+    static __device__ __forceinline__ geo shfl_xor32(const geo &g)
+    {
+        geo o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.w[i] = __shfl_xor(g.w[i], 32);
+        o.mask = __shfl_xor(g.mask, 32);
+        return o;
+    }
+    static __device__ __forceinline__ frag blend(const frag (&v)[4], const geo &g) { return blend(v, g.w, g.mask); }
+    // reference order: (w1*v1 + w2*v2 + w3*v3 + w4*v4) * mask
+    static __device__ __forceinline__ frag blend(const frag (&v)[4], const float (&w)[4], float mask)
+    {
+        frag o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o.lo[e] = (w[0] * v[0].lo[e] + w[1] * v[1].lo[e] + w[2] * v[2].lo[e] + w[3] * v[3].lo[e]) * mask;
+            o.hi[e] = (w[0] * v[0].hi[e] + w[1] * v[1].hi[e] + w[2] * v[2].hi[e] + w[3] * v[3].hi[e]) * mask;
+        }
+        return o;
+    }
+    // staging: 16 bytes of T=float -> 16 bytes of S
+    static __device__ __forceinline__ u32x4 convert16(u32x4 raw) { return raw; }
+};
+
+template <> struct SE<bf16_t> {
+    using S = _Float16;
+    static constexpr int SS = 2;
+    struct frag { half8_t v; };
+    static __device__ __forceinline__ frag lds(const char *p)
+    {
+        frag f;
+        f.v = *reinterpret_cast<const half8_t *>(p);
+        return f;
+    }
+    static __device__ __forceinline__ frag zero()
+    {
+        frag f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f.v[e] = (_Float16)0.f;
+        return f;
+    }
+    static __device__ __forceinline__ void keep(const frag &f) { asm volatile("" ::"v"(f.v)); }
+    static __device__ __forceinline__ _Float16 cvt(uint32_t bits_hi)   // bf16 in the high half of an f32 pattern
+    {
+        const float x = __uint_as_float(bits_hi);
+        return (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);  // v_med3_f32: no inf from bf16's wider range
+    }
+    static __device__ __forceinline__ u32x4 convert16(u32x4 raw)        // 8 bf16 -> 8 fp16
+    {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[2 * e] = cvt(raw[e] << 16);
+            o[2 * e + 1] = cvt(raw[e] & 0xffff0000u);
+        }
+        return __builtin_bit_cast(u32x4, o);
+    }
+    static __device__ __forceinline__ frag global8(const char *p)       // 8 bf16 from global -> fp16
+    {
+        frag f;
+        f.v = __builtin_bit_cast(half8_t, convert16(*reinterpret_cast<const u32x4 *>(p)));
+        return f;
+    }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, acc, 0, 0, 0);
+    }
+    struct geo { uint32_t w01, w23; };          // fp16 pairs (w0 | w1 << 16), (w2 | w3 << 16); mask folded in
+    static __device__ __forceinline__ geo make_geo(const float (&w)[4], float mask)
+    {
+        geo g;
+        g.w01 = __builtin_bit_cast(uint32_t, half2_t{(_Float16)(w[0] * mask), (_Float16)(w[1] * mask)});
+        g.w23 = __builtin_bit_cast(uint32_t, half2_t{(_Float16)(w[2] * mask), (_Float16)(w[3] * mask)});
+        return g;
+    }
+    static __device__ __forceinline__ geo zero_geo() { geo g; g.w01 = 0u; g.w23 = 0u; return g; }
+    static __device__ __forceinline__ geo shfl_xor32(const geo &g)
+    {
+        geo o;
+        o.w01 = (uint32_t)__shfl_xor((int)g.w01, 32);
+        o.w23 = (uint32_t)__shfl_xor((int)g.w23, 32);
+        return o;
+    }
+    // out = v0*w0 + v1*w1 + v2*w2 + v3*w3 on 8 fp16 channels: 4 packed ops per dword, the per-pixel
+    // weight is broadcast to both halves by op_sel (no duplicated weight registers).  The trailing
+    // s_nop covers the VALU-write -> MFMA-operand wait states hipcc does not pad inside asm.
+    static __device__ __forceinline__ frag blend(const frag (&v)[4], const geo &g)
+    {
+        const u32x4 a = __builtin_bit_cast(u32x4, v[0].v), b = __builtin_bit_cast(u32x4, v[1].v),
+                    c = __builtin_bit_cast(u32x4, v[2].v), d = __builtin_bit_cast(u32x4, v[3].v);
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t x;
+            asm("v_pk_mul_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(x) : "v"(a[i]), "v"(g.w01));
+            asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(x) : "v"(b[i]), "v"(g.w01));
+            asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(x) : "v"(c[i]), "v"(g.w23));
+            asm("v_pk_fma_f16 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(x) : "v"(d[i]), "v"(g.w23));
+            o[i] = x;
+        }
+        asm volatile("s_nop 1" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+        frag f;
+        f.v = __builtin_bit_cast(half8_t, u32x4{o[0], o[1], o[2], o[3]});
+        return f;
+    }
+};
+
+
+__device__ __forceinline__ float dcn2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }   // v_exp + v_rcp (1 ulp each)

@@ -103,6 +103,28 @@ class PackedWeights:
             self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
         return self.t[key]
 
+    def offset_conv(self, wkey, bkey, main_rows):
+        """conv_offset_mask packed for the fused DeformConv kernel (csrc/dcn3.hip): the 27 filters are
+        spread over 32 MFMA rows so that accumulator half h of a pixel owns whole (dh, dw, mask)
+        triples -- value i = 3u + c of half h sits in row (i&3) + 8*(i>>2) + 4*h; half 0 holds taps
+        0..4, half 1 taps 5..8.  Returns (weights [128 rows][9][Cin] (32 used), permuted bias fp32 [32])."""
+        key = ("offconv", wkey)
+        if key not in self.t:
+            w, b = self.sd[wkey], self.sd[bkey]              # [27,Cin,3,3], [27]
+            ci = w.shape[1]
+            wp = torch.zeros(128, 9, ci)
+            bp = torch.zeros(32)
+            for tap in range(9):
+                hh, u = (0, tap) if tap < 5 else (1, tap - 5)
+                for c, ch in enumerate((2 * tap, 2 * tap + 1, 18 + tap)):
+                    i = 3 * u + c
+                    row = (i & 3) + 8 * (i >> 2) + 4 * hh
+                    wp[row] = w[ch].permute(1, 2, 0).reshape(9, ci)
+                    bp[row] = b[ch]
+            td = torch.float16 if self.dtype == "bf16" else torch.float32
+            self.t[key] = (wp.to(td).contiguous().to(self.device), bp)
+        return self.t[key]
+
     def fused_heads(self):
         """Fused-heads pack: 3x3 weights of all heads stacked [nheads*head_conv][9][64]; per head the
         1x1 weights as [96 rows][head_conv] with K re-ordered to the MFMA accumulator row order
@@ -140,8 +162,9 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W, fuse_heads=True):
+    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True):
         self.fuse_heads = fuse_heads
+        self.fuse_offsets = fuse_offsets
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -253,6 +276,19 @@ class Plan:
 
     def _deform(self, x, p, out=None):
         """DeformConv (model.py:346-362): DCN or plain 3x3 conv, then BN + ReLU (folded)."""
+        if self.pw.use_dcn and self.fuse_offsets:
+            wp, bp, cout, cin, k, rows = self.pw.conv(p + ".conv.weight", p + ".conv.bias", p + ".actf.0", as_half=True)
+            wo, bo = self.pw.offset_conv(p + ".conv.conv_offset_mask.weight", p + ".conv.conv_offset_mask.bias", rows)
+            key = ("dcnbias", p)
+            if key not in self.pw.t:
+                self.pw.t[key] = torch.cat([bp.cpu(), bo]).contiguous().to(self.pw.device)
+            bias = self.pw.t[key]
+            if out is None:
+                out = self._alloc(x.H, x.W, cout)
+            self._op(_lib.OP_DCN_FUSED, in_=x.ptr, in2=wo.data_ptr(), w=wp.data_ptr(), bias=bias.data_ptr(), out=out.ptr,
+                     H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3, stride=1,
+                     relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
+            return out
         if self.pw.use_dcn:
             om = self.conv(x, p + ".conv.conv_offset_mask.weight", bkey=p + ".conv.conv_offset_mask.bias",
                            relu=False, out_mode=_lib.OUT_NHWC_F32, pad_cout_to=32)
@@ -338,12 +374,13 @@ class DLAEngine:
         self.pw = PackedWeights(state_dict, heads, use_dcn, dtype, self.device, head_conv)
         self.plans = {}
         self.fuse_heads = True          # False: one conv3x3 + conv1x1 launch pair per head (debug/ablation)
+        self.fuse_offsets = True        # False: conv_offset_mask as its own launch + dcn2_kernel reading NHWC offsets
 
     def plan(self, B, H, W):
         key = (B, H, W)
         if key not in self.plans:
             with torch.cuda.device(self.device):
-                self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads)
+                self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets)
         return self.plans[key]
 
     def forward(self, images):

@@ -74,6 +74,8 @@ enum {
     H3D_OP_MAXPOOL = 4, /* 2x2 stride-2 max pool (Tree.downsample, model.py:200-201)                   */
     H3D_OP_UPADD = 5,   /* depthwise ConvTranspose2d(k=2f,s=f,p=f/2) + skip add (IDAUp, model.py:375-390) */
     H3D_OP_COPY = 6,    /* strided NHWC copy (y[i] = x[i].clone(), model.py:480-482)                   */
+    H3D_OP_DCN_FUSED = 9, /* DeformConv with conv_offset_mask fused in (csrc/dcn3.hip): in2 = offset/mask filters
+                             [32 permuted rows][9][Cin] (same element type as w), bias = [wrows main | 32 offset] */
     H3D_OP_DCN_V1 = 8,  /* first-generation DCN kernel (global gather, bf16 weights): kept as an A/B reference */
     H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
                            (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */

@@ -150,3 +150,40 @@ def test_fused_heads_match_per_head_convs(dtype, tol):
             ref = odla.DLAOracle(sd, heads, use_dcn=True)(xs.cpu())[0]
         for k in heads:
             np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=5e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 3e-4), ("bf16", 6e-2)])
+def test_fused_offset_dcn_matches_two_launch_path(dtype, tol):
+    # DeformConv with conv_offset_mask fused (csrc/dcn3.hip) vs offset conv + dcn2 launches, and vs the oracle
+    m, sd = _net(True, dtype)
+    xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=13)).to(DEV)
+    eng = m.engine(xs.device)
+    assert eng.fuse_offsets
+    fused = {k: v.clone() for k, v in m(xs)[0].items()}
+    eng.fuse_offsets = False
+    eng.plans.clear()
+    plain = {k: v.clone() for k, v in m(xs)[0].items()}
+    eng.fuse_offsets = True
+    eng.plans.clear()
+    for k in HEADS:
+        e = float((fused[k] - plain[k]).abs().max())
+        assert e <= tol, (k, e)
+    if dtype == "f32":
+        with torch.no_grad():
+            ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(xs.cpu())[0]
+        for k in HEADS:
+            np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=5e-4, err_msg=k)
+
+
+def test_fused_offset_dcn_large_offsets_take_the_global_path():
+    # offset filters scaled up so many samples leave the 2-pixel apron: pass 2 must add them back exactly
+    sd = synth.synth_state_dict(arch.state_dict_shapes(HEADS, True), seed=0, offset_scale=12.0)
+    m = model.dla_net(HEADS, not_use_dcn=False, dtype="f32")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    xs = synth.synth_images(1, 64, 96, seed=17)
+    out = m(torch.from_numpy(xs).to(DEV))[0]
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(torch.from_numpy(xs))[0]
+    for k in HEADS:
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=1e-3, err_msg=k)
