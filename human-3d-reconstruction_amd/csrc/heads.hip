@@ -124,8 +124,10 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     // ---- stage descriptor: what global data stage `s` needs in LDS -------------------------------
     // tap stage : 64 rows x 64 K of W1 (rows = intermediate channels of the slab) -> ring slot (k & 1)
     // W2 stage  : 96 rows x 64 K of the head's packed 1x1 weights                 -> s_w2
-    u32x4 stg[C::NSTG];
-    auto prefetch = [&](int s) {
+    // two staging register sets: the loads of stage s+2 are issued while stage s computes and are written
+    // to LDS one stage later, so a weight fetch has two stages (~1 us) to land instead of one
+    u32x4 stgA[C::NSTG], stgB[C::NSTG];
+    auto prefetch_into = [&](int s, u32x4 (&stg)[C::NSTG]) {
         const int head = s / stages_per_head, q = s - head * stages_per_head;
         const int slab = q / 10, k = q - slab * 10;
 #pragma unroll
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
             stg[j] = val;
         }
     };
-    auto commit = [&](int s) {
+    auto commit_from = [&](int s, u32x4 (&stg)[C::NSTG]) {
         const int q = s % stages_per_head;
         const int k = q % 10;
 #pragma unroll
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
         }
     };
 
-    // ---- prologue: halo tile (all 64 channels, zero outside the image) + stage 0 ------------------
-    prefetch(0);
+    // ---- prologue: halo tile (all 64 channels, zero outside the image) + stages 0 and 1 ------------
+    prefetch_into(0, stgA);
     {
         const size_t in_img = (size_t)b * a.H * a.W;
         constexpr int NHV = C::IN_H * C::IN_W * C::VPR;
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                 });
         }
     }
-    commit(0);
+    commit_from(0, stgA);
+    if (nstages > 1) prefetch_into(1, stgB);
     __syncthreads();
 
     int boff[NT];
@@ -217,33 +220,39 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc2[m][n][i] = 0.f;
         for (int slab = 0; slab < slabs; ++slab) {
-            for (int k = 0; k < 9; ++k, ++s) {
-                // ---- 3x3 tap k of this slab: acc[2][NT] += W1[64 x 64] . halo(tap)[64 x pixels] ----
-                if (s + 1 < nstages) prefetch(s + 1);
-                const int dy = k / 3, dx = k - dy * 3;
-                const char *wr = s_ring + (k & 1) * C::LDS_RING + aoff;
-                const char *br = s_in + dy * C::RB + dx * C::SB;
+            // 10 stages per slab (9 taps + the 1x1 stage), fully unrolled so the staging-set parity
+            // (stage s uses set s & 1; s is even at every slab start) is a compile-time choice
 #pragma unroll
-                for (int kk = 0; kk < HC_IN / 16; ++kk) {
-                    typename E::frag fa[2], fb[NT];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) fa[m] = E::lds_frag(wr + m * 32 * C::WB + kk * 16 * ES);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
+            for (int k = 0; k < 10; ++k, ++s) {
+                if (s + 2 < nstages) {
+                    if (k & 1) prefetch_into(s + 2, stgB); else prefetch_into(s + 2, stgA);
                 }
-                if (s + 1 < nstages) commit(s + 1);
+                if (k < 9) {
+                    // ---- 3x3 tap k of this slab: acc[2][NT] += W1[64 x 64] . halo(tap)[64 x pixels] ----
+                    const int dy = k / 3, dx = k - dy * 3;
+                    const char *wr = s_ring + (k & 1) * C::LDS_RING + aoff;
+                    const char *br = s_in + dy * C::RB + dx * C::SB;
+#pragma unroll
+                    for (int kk = 0; kk < HC_IN / 16; ++kk) {
+                        typename E::frag fa[2], fb[NT];
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) fa[m] = E::lds_frag(wr + m * 32 * C::WB + kk * 16 * ES);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
+                    }
+                } else {
+                    // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 ----
+                    gemm2<T, NT, M2>(acc, acc2, a.b1 + head * a.head_conv + slab * HC_SLAB, s_w2, C::W2B, r, h);
+                }
+                if (s + 1 < nstages) {
+                    if ((k + 1) & 1) commit_from(s + 1, stgB); else commit_from(s + 1, stgA);
+                }
                 __syncthreads();
             }
-            // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 --------
-            if (s + 1 < nstages) prefetch(s + 1);
-            gemm2<T, NT, M2>(acc, acc2, a.b1 + head * a.head_conv + slab * HC_SLAB, s_w2, C::W2B, r, h);
-            if (s + 1 < nstages) commit(s + 1);
-            __syncthreads();
-            ++s;
         }
         // ---- head done: z = acc2 + b2 -> NCHW fp32 (lane = pixel: coalesced rows) --------------------
         const int C_head = a.C[head];
