@@ -13,7 +13,6 @@
 // the accumulator row order, which the host bakes into the packed 1x1 weights).
 // Outputs are written as contiguous NCHW fp32 rows (lane = pixel), the reference's head layout.
 #include "common.h"
-#include <type_traits>
 
 constexpr int HEADS_MAX = 16;
 constexpr int HC_IN = 64;     // channels of y (DLA-34 first_level = 2)
@@ -98,7 +97,7 @@ __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][N
     }
 }
 
-template <typename T, int TH>
+template <typename T, int TH, int M2>
 __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 {
     using C = HeadsCfg<T, TH>;
@@ -204,8 +203,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     // One head with M2 row tiles of 1x1 output.  Accumulators are local to this instantiation so
     // no control-flow merge ever joins differently-updated accumulator sets (that costs copies
     // and spills); `s` is the running stage index of the weight pipeline.
-    auto run_head = [&](auto m2_tag, int head, int &s) {
-        constexpr int M2 = decltype(m2_tag)::value;
+    auto run_head = [&](int head, int &s) {
         f32x16 acc[2][NT], acc2[M2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -232,17 +230,28 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                     const int dy = k / 3, dx = k - dy * 3;
                     const char *wr = s_ring + (k & 1) * C::LDS_RING + aoff;
                     const char *br = s_in + dy * C::RB + dx * C::SB;
+                    // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk issue
+                    // (explicit double buffer: hipcc otherwise re-uses one register set and every
+                    // k-step waits out its own ds_read latency)
+                    typename E::frag fa[2][2], fb[2][NT];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) fa[0][m] = E::lds_frag(wr + m * 32 * C::WB);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) fb[0][n] = E::lds_frag(br + boff[n]);
 #pragma unroll
                     for (int kk = 0; kk < HC_IN / 16; ++kk) {
-                        typename E::frag fa[2], fb[NT];
+                        constexpr int NK = HC_IN / 16;
+                        const int cur = kk & 1, nxt = cur ^ 1;
+                        if (kk + 1 < NK) {
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) fa[m] = E::lds_frag(wr + m * 32 * C::WB + kk * 16 * ES);
+                            for (int m = 0; m < 2; ++m) fa[nxt][m] = E::lds_frag(wr + m * 32 * C::WB + (kk + 1) * 16 * ES);
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
+                            for (int n = 0; n < NT; ++n) fb[nxt][n] = E::lds_frag(br + boff[n] + (kk + 1) * 16 * ES);
+                        }
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
-                            for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
+                            for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[cur][m], fb[cur][n]);
                     }
                 } else {
                     // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 ----
@@ -281,12 +290,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     };
 
     int s = 0;
-    for (int head = 0; head < a.nheads; ++head) {
-        const int mt2 = (a.C[head] + 31) >> 5;   // wave-uniform
-        if (mt2 == 1) run_head(std::integral_constant<int, 1>{}, head, s);
-        else if (mt2 == 2) run_head(std::integral_constant<int, 2>{}, head, s);
-        else run_head(std::integral_constant<int, 3>{}, head, s);
-    }
+    for (int head = 0; head < a.nheads; ++head) run_head(head, s);
 }
 
 static_assert(HEADS_MAX == H3D_HEADS_MAX, "header/kernel mismatch");
@@ -309,18 +313,21 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
             H3D_FAIL(H3D_ERR_UNSUPPORTED, "heads: head %d has %d channels (max %d)", i, d->head[i].C, 32 * HC_MT2);
         a.w2[i] = (const char *)d->head[i].w2; a.b2[i] = d->head[i].b2; a.out[i] = d->head[i].out; a.C[i] = d->head[i].C;
     }
+    int m2 = 1;
+    for (int i = 0; i < d->nheads; ++i) m2 = max(m2, (d->head[i].C + 31) / 32);   // row tiles of the widest head
+    const int th = op.dtype == H3D_BF16 ? 16 : 8;
+    a.tiles_x = cdiv(op.W, 32); a.tiles_y = cdiv(op.H, th);
+    const dim3 grid(op.B * a.tiles_x * a.tiles_y), blk(512);
+    if (op.dtype != H3D_BF16 && op.dtype != H3D_F32) H3D_FAIL(H3D_ERR_DTYPE, "heads: dtype %d", op.dtype);
+    if (h3d_note_kernel("heads_kernel<%s, %d, %d>", op.dtype == H3D_BF16 ? "unsigned short" : "float", th, m2)) return H3D_OK;
     if (op.dtype == H3D_BF16) {
-        constexpr int TH = 16;
-        a.tiles_x = cdiv(op.W, 32); a.tiles_y = cdiv(op.H, TH);
-        if (h3d_note_kernel("heads_kernel<unsigned short, %d>", TH)) return H3D_OK;
-        hipLaunchKernelGGL((heads_kernel<bf16_t, TH>), dim3(op.B * a.tiles_x * a.tiles_y), dim3(512), 0, st, a);
-    } else if (op.dtype == H3D_F32) {
-        constexpr int TH = 8;
-        a.tiles_x = cdiv(op.W, 32); a.tiles_y = cdiv(op.H, TH);
-        if (h3d_note_kernel("heads_kernel<float, %d>", TH)) return H3D_OK;
-        hipLaunchKernelGGL((heads_kernel<float, TH>), dim3(op.B * a.tiles_x * a.tiles_y), dim3(512), 0, st, a);
+        if (m2 == 1) hipLaunchKernelGGL((heads_kernel<bf16_t, 16, 1>), grid, blk, 0, st, a);
+        else if (m2 == 2) hipLaunchKernelGGL((heads_kernel<bf16_t, 16, 2>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((heads_kernel<bf16_t, 16, 3>), grid, blk, 0, st, a);
     } else {
-        H3D_FAIL(H3D_ERR_DTYPE, "heads: dtype %d", op.dtype);
+        if (m2 == 1) hipLaunchKernelGGL((heads_kernel<float, 8, 1>), grid, blk, 0, st, a);
+        else if (m2 == 2) hipLaunchKernelGGL((heads_kernel<float, 8, 2>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((heads_kernel<float, 8, 3>), grid, blk, 0, st, a);
     }
     H3D_CHECK_LAUNCH("heads_kernel");
     return H3D_OK;

@@ -125,19 +125,21 @@ class PackedWeights:
             self.t[key] = (wp.to(td).contiguous().to(self.device), bp)
         return self.t[key]
 
-    def fused_heads(self):
+    def fused_heads(self, names=None):
         """Fused-heads pack: 3x3 weights of all heads stacked [nheads*head_conv][9][64]; per head the
         1x1 weights as [96 rows][head_conv] with K re-ordered to the MFMA accumulator row order
         (csrc/heads.hip): within every 32-channel group, position h*16 + r holds channel
         (r&3) + 8*(r>>2) + 4*h."""
-        key = ("heads",)
+        names = tuple(self.heads) if names is None else names
+        key = ("heads", names)
         if key not in self.t:
             hc = self.head_conv
             td = _TORCH_DT[self.dtype]
             w1, b1, per = [], [], []
             perm = torch.tensor([g * 32 + (r & 3) + 8 * (r >> 2) + 4 * h
                                  for g in range(hc // 32) for h in range(2) for r in range(16)])
-            for head, c in self.heads.items():
+            for head in names:
+                c = self.heads[head]
                 w = self.sd[head + ".0.weight"]                      # [hc,64,3,3]
                 w1.append(w.permute(0, 2, 3, 1).reshape(hc, 9, w.shape[1]))
                 b1.append(self.sd[head + ".0.bias"])
@@ -331,16 +333,23 @@ class Plan:
         fused = (self.pw.head_conv > 0 and self.pw.head_conv % 64 == 0 and feat.C == 64 and
                  len(self.pw.heads) <= _lib.HEADS_MAX and max(self.pw.heads.values()) <= 96 and self.fuse_heads)
         if fused:
-            w1, b1, per = self.pw.fused_heads()
-            desc = _lib.H3dHeadsDesc()
-            desc.nheads = len(per)
-            for i, (head, c, w2, b2) in enumerate(per):
-                o = torch.empty(B, c, Ho, Wo, dtype=torch.float32, device=self.pw.device)
-                self.outputs[head] = o
-                desc.head[i].w2, desc.head[i].b2, desc.head[i].out, desc.head[i].C = w2.data_ptr(), b2.data_ptr(), o.data_ptr(), c
-            self.keep.append(desc)
-            self._op(_lib.OP_HEADS, in_=feat.ptr, in2=ctypes.addressof(desc), w=w1.data_ptr(), bias=b1.data_ptr(),
-                     H=Ho, W=Wo, Cin=feat.C, in_cs=feat.cs, Ho=Ho, Wo=Wo, Cout=self.pw.head_conv, ksize=3, stride=1)
+            # one launch per group of heads with the same number of 32-row output tiles, so the
+            # narrow heads do not inherit the register footprint of the 72-channel pose head
+            groups = {}
+            for head, c in self.pw.heads.items():
+                groups.setdefault((c + 31) // 32, []).append(head)
+            for m2 in sorted(groups):
+                w1, b1, per = self.pw.fused_heads(tuple(groups[m2]))
+                desc = _lib.H3dHeadsDesc()
+                desc.nheads = len(per)
+                for i, (head, c, w2, b2) in enumerate(per):
+                    o = torch.empty(B, c, Ho, Wo, dtype=torch.float32, device=self.pw.device)
+                    self.outputs[head] = o
+                    desc.head[i].w2, desc.head[i].b2, desc.head[i].out, desc.head[i].C = w2.data_ptr(), b2.data_ptr(), o.data_ptr(), c
+                self.keep.append(desc)
+                self._op(_lib.OP_HEADS, in_=feat.ptr, in2=ctypes.addressof(desc), w=w1.data_ptr(), bias=b1.data_ptr(),
+                         H=Ho, W=Wo, Cin=feat.C, in_cs=feat.cs, Ho=Ho, Wo=Wo, Cout=self.pw.head_conv, ksize=3, stride=1)
+            self.outputs = {h: self.outputs[h] for h in self.pw.heads}      # reference head order
             return
         for head, c in self.pw.heads.items():
             o = torch.empty(B, c, Ho, Wo, dtype=torch.float32, device=self.pw.device)
