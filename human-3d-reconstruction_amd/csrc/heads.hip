@@ -30,6 +30,7 @@ struct HeadsArgs {
     int nheads, head_conv;
     int B, H, W, in_cs;
     int tiles_x, tiles_y;
+    int dbg;   // profiling ablation (h3d_op.reserved): 1 = skip the weight loads after the prologue
 };
 
 template <typename T, int TH>
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     // to LDS one stage later, so a weight fetch has two stages (~1 us) to land instead of one
     u32x4 stgA[C::NSTG], stgB[C::NSTG];
     auto prefetch_into = [&](int s, u32x4 (&stg)[C::NSTG]) {
+        if ((a.dbg & 1) && s > 1) return;
         const int head = s / stages_per_head, q = s - head * stages_per_head;
         const int slab = q / 10, k = q - slab * 10;
 #pragma unroll
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
         }
     }
     commit_from(0, stgA);
-    if (nstages > 1) prefetch_into(1, stgB);
+    prefetch_into(min(1, nstages - 1), stgB);
     __syncthreads();
 
     int boff[NT];
@@ -222,8 +224,10 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
             // (stage s uses set s & 1; s is even at every slab start) is a compile-time choice
 #pragma unroll
             for (int k = 0; k < 10; ++k, ++s) {
-                if (s + 2 < nstages) {
-                    if (k & 1) prefetch_into(s + 2, stgB); else prefetch_into(s + 2, stgA);
+                {   // unconditional (stage index clamped at the tail): a path-independent number of
+                    // outstanding loads lets hipcc emit a counted s_waitcnt vmcnt(N) at the commit below
+                    const int sp = min(s + 2, nstages - 1);
+                    if (k & 1) prefetch_into(sp, stgB); else prefetch_into(sp, stgA);
                 }
                 if (k < 9) {
                     // ---- 3x3 tap k of this slab: acc[2][NT] += W1[64 x 64] . halo(tap)[64 x pixels] ----
@@ -257,8 +261,9 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                     // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 ----
                     gemm2<T, NT, M2>(acc, acc2, a.b1 + head * a.head_conv + slab * HC_SLAB, s_w2, C::W2B, r, h);
                 }
-                if (s + 1 < nstages) {
-                    if ((k + 1) & 1) commit_from(s + 1, stgB); else commit_from(s + 1, stgA);
+                {
+                    const int sc = min(s + 1, nstages - 1);
+                    if ((k + 1) & 1) commit_from(sc, stgB); else commit_from(sc, stgA);
                 }
                 __syncthreads();
             }
@@ -306,6 +311,7 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
     if (d->nheads <= 0 || d->nheads > HEADS_MAX) H3D_FAIL(H3D_ERR_SHAPE, "heads: %d heads (max %d)", d->nheads, HEADS_MAX);
     HeadsArgs a;
     a.in = (const char *)op.in; a.w1 = (const char *)op.w; a.b1 = op.bias;
+    a.dbg = op.reserved;
     a.nheads = d->nheads; a.head_conv = op.Cout; a.B = op.B; a.H = op.H; a.W = op.W; a.in_cs = op.in_cs;
     for (int i = 0; i < d->nheads; ++i) {
         if (!d->head[i].w2 || !d->head[i].b2 || !d->head[i].out) H3D_FAIL(H3D_ERR_ARG, "heads: head %d null pointer", i);

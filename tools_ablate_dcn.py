@@ -15,8 +15,9 @@ det.run(x); torch.cuda.synchronize()
 plan = det.model.engine(dev).plan(B, 512, 512)
 n = len(plan.ops)
 ms = (ctypes.c_float * n)()
-idx = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_DCN]
-for dbg in (0, 1, 2, 4, 7, 8, 16, 31):
+KIND = {'dcn': _lib.OP_DCN, 'heads': _lib.OP_HEADS, 'dcnf': _lib.OP_DCN_FUSED}[sys.argv[2] if len(sys.argv) > 2 else 'dcn']
+idx = [i for i, op in enumerate(plan.ops) if op.kind == KIND]
+for dbg in ((0, 1) if KIND == _lib.OP_HEADS else (0, 1, 2, 4, 7, 8, 16, 31)):
     for i in idx:
         plan.op_array[i].reserved = dbg
     tot = np.zeros(n)
@@ -24,4 +25,4 @@ for dbg in (0, 1, 2, 4, 7, 8, 16, 31):
         _lib.check(_lib.lib().h3d_run_ops_timed(plan.op_array, n, _lib.stream_ptr(), ms), "timed")
         tot += np.frombuffer(ms, dtype=np.float32, count=n)
     tot /= 3
-    print("dbg=%d" % dbg, " ".join("%s:%.3f" % (kernel_name(plan.ops[i])[12:30].replace("unsigned short", "bf"), tot[i]) for i in idx[:16]))
+    print("dbg=%d" % dbg, " ".join("%s:%.3f" % (kernel_name(plan.ops[i])[:40].replace("unsigned short", "bf"), tot[i]) for i in idx[:16]))
