@@ -196,7 +196,7 @@ template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipSt
         if (cin % 32 == 0) {
             if (co <= 32) return launch_conv_cfg<bf16_t, 3, 1, 1, 32, 16>(a, st);
             if (co <= 64) {
-                if (nblk(16, 64) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 16>(a, st);
+                if (nblk(16, 64) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 16, 8>(a, st);   // 8 waves x (32 px x 64 ch)
                 return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 8>(a, st);
             }
             // 8 waves x (32 px x 128 ch), CK = 32: a chunk's MFMA time now exceeds the prefetch latency

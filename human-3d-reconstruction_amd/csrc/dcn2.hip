@@ -38,7 +38,8 @@ struct Dcn2Cfg {
     static constexpr int SS = SE<T>::SS;
     static constexpr int HH = 16 + 2 + 2 * MARGIN;      // halo height = width
     static constexpr int SBH = CK * SS + 16;            // halo pixel stride (bytes)
-    static constexpr int RBH = HH * SBH;
+    static constexpr int RBH = ((HH * SBH + 255) / 256) * 256;   // 256 B-aligned rows: the 2-row x 16-px gather of a
+                                                                 // 16-lane ds_read_b128 group then covers 16 distinct 16-B slots
     static constexpr int WB = 9 * CK * SS + 16;
     static constexpr int BN = 32 * MT;
     static constexpr int NT = NT_;                      // N-tiles (2 rows x 16 px) per wave
