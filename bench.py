@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--people", type=int, default=100, help="SMPL meshes per image (<= K)")
+    ap.add_argument("--streams", type=int, default=1, help="sub-batches run concurrently on their own HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -145,6 +146,7 @@ def main():
     opt = Opt(input_h=512, input_w=512, smpl=True, smpl_people=args.people, dtype=args.dtype, K=100)
     sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0)
     det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
+    det.model.engine(dev).streams = args.streams
     images = torch.from_numpy(synth.synth_images(1, 512, 512, seed=317 + rank)).to(dev)
     images = images.expand(args.batch, 3, 512, 512).contiguous()
     images += 0.01 * torch.arange(args.batch, device=dev, dtype=torch.float32).view(-1, 1, 1, 1)   # distinct images

@@ -362,6 +362,25 @@ class Plan:
                 self.conv(feat, head + ".weight", bkey=head + ".bias", relu=False,
                           out_mode=_lib.OUT_NCHW_F32, out_tensor=o)
 
+    def retarget_outputs(self, views):
+        """Point the head outputs at caller-provided contiguous [B,C,H,W] fp32 views (sub-batch plans)."""
+        for h, v in views.items():
+            assert v.is_contiguous() and tuple(v.shape) == tuple(self.outputs[h].shape)
+        for i, op in enumerate(self.ops):
+            if op.kind == _lib.OP_HEADS:
+                d = ctypes.cast(op.in2, ctypes.POINTER(_lib.H3dHeadsDesc)).contents
+                for j in range(d.nheads):
+                    for h, o in self.outputs.items():
+                        if d.head[j].out == o.data_ptr():
+                            d.head[j].out = views[h].data_ptr()
+                            break
+            elif op.kind == _lib.OP_CONV and op.out_mode == _lib.OUT_NCHW_F32:
+                for h, o in self.outputs.items():
+                    if op.out == o.data_ptr():
+                        self.op_array[i].out = views[h].data_ptr()
+                        break
+        self.outputs = dict(views)
+
     def run(self):
         rc = _lib.lib().h3d_run_ops(self.op_array, len(self.ops), _lib.stream_ptr())
         _lib.check(rc, "h3d_run_ops")
@@ -384,6 +403,7 @@ class DLAEngine:
         self.plans = {}
         self.fuse_heads = True          # False: one conv3x3 + conv1x1 launch pair per head (debug/ablation)
         self.fuse_offsets = True        # False: conv_offset_mask as its own launch + dcn2_kernel reading NHWC offsets
+        self.streams = 1                # >1: run that many sub-batches concurrently on their own HIP streams
 
     def plan(self, B, H, W):
         key = (B, H, W)
@@ -397,6 +417,8 @@ class DLAEngine:
         if images.dim() != 4 or images.shape[1] != 3:
             raise RuntimeError("expected images [B,3,H,W], got %s" % (tuple(images.shape),))
         B, _, H, W = images.shape
+        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 8:
+            return self._forward_split(images)
         plan = self.plan(B, H, W)
         with torch.cuda.device(self.device):
             if images.dtype == torch.float32 and images.is_contiguous():
@@ -405,5 +427,39 @@ class DLAEngine:
                 plan.images.copy_(images)
                 plan.op_array[0].in_ = plan.images.data_ptr()
             return plan.run()
+
+    def _forward_split(self, images):
+        """Sub-batches on separate HIP streams: the small-grid layers (level4/5, the 16x16 / 32x32 neck
+        layers: 128-512 workgroups on 256 CUs) and every kernel's tail overlap with the other
+        sub-batch's launches.  Outputs are written into one full-batch tensor per head."""
+        B, _, H, W = images.shape
+        n = self.streams
+        sub = B // n
+        key = ("split", B, H, W)
+        with torch.cuda.device(self.device):
+            if key not in self.plans:
+                plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets)
+                         for _ in range(n)]
+                full = {h: torch.empty((B,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
+                        for h, o in plans[0].outputs.items()}
+                for i, p in enumerate(plans):          # re-point the head outputs into the full-batch tensors
+                    p.retarget_outputs({h: full[h][i * sub:(i + 1) * sub] for h in full})
+                self.plans[key] = (plans, full, [torch.cuda.Stream(device=self.device) for _ in range(n)])
+            plans, full, streams = self.plans[key]
+            if not (images.dtype == torch.float32 and images.is_contiguous()):
+                images = images.float().contiguous()
+            cur = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            for i, (p, st) in enumerate(zip(plans, streams)):
+                st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    p.op_array[0].in_ = images[i * sub:(i + 1) * sub].data_ptr()
+                    p.run()
+                    done = torch.cuda.Event()
+                    done.record(st)
+                cur.wait_event(done)
+            self._keepalive = images
+            return full
 
     __call__ = forward

@@ -187,3 +187,16 @@ def test_fused_offset_dcn_large_offsets_take_the_global_path():
         ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(torch.from_numpy(xs))[0]
     for k in HEADS:
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=1e-3, err_msg=k)
+
+
+def test_stream_split_matches_single_stream():
+    m, _ = _net(True, "bf16")
+    xs = torch.from_numpy(synth.synth_images(16, 64, 64, seed=19)).to(DEV)
+    one = {k: v.clone() for k, v in m(xs)[0].items()}
+    eng = m.engine(xs.device)
+    eng.streams = 2
+    two = {k: v.clone() for k, v in m(xs)[0].items()}
+    torch.cuda.synchronize()
+    eng.streams = 1
+    for k in HEADS:
+        assert torch.equal(one[k], two[k]), k
