@@ -49,6 +49,14 @@ template <> struct ET<float> {
         f.hi = *reinterpret_cast<const f32x4 *>(p + 16);
         return f;
     }
+    // 8 K elements whose two 16-byte halves sit at different (swizzled) LDS addresses
+    static __device__ __forceinline__ frag lds_frag2(const char *lo, const char *hi)
+    {
+        frag f;
+        f.lo = *reinterpret_cast<const f32x4 *>(lo);
+        f.hi = *reinterpret_cast<const f32x4 *>(hi);
+        return f;
+    }
     static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
     {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[0], b.lo[0], acc, 0, 0, 0);
@@ -73,6 +81,7 @@ template <> struct ET<bf16_t> {
         f.v = *reinterpret_cast<const u32x4 *>(p);
         return f;
     }
+    static __device__ __forceinline__ frag lds_frag2(const char *lo, const char *) { return lds_frag(lo); }
     static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
     {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.v),

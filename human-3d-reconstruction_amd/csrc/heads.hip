@@ -4,13 +4,18 @@
 // head_conv(=256)-channel intermediate (16.8 MB/image in fp32) through memory for each of them:
 // 37 % of the network's multiply-accumulates and the largest single source of HBM traffic.
 //
-// Here ONE workgroup keeps the 64-channel input halo tile of a TH x 32 pixel tile in LDS for ALL
-// heads, streams the 3x3 weights tap by tap through a 2-slot LDS ring (prefetched into registers
-// one stage ahead), and never writes the intermediate: each 64-channel slab of it leaves the
-// MFMA accumulators as bf16 (bias + ReLU applied) and is fed straight back as the B operand of
-// the 1x1 contraction (accumulator tile -> next MFMA's operand: the 32x32 C/D map puts the
-// pixel on the lane and channels in the registers, exactly the B-operand shape; the K order is
-// the accumulator row order, which the host bakes into the packed 1x1 weights).
+// Here ONE workgroup (8 waves) keeps the 64-channel input halo tile of a TH x 32 pixel tile in LDS
+// for ALL heads of the launch and never writes the intermediate: each 64-channel slab of it leaves
+// the MFMA accumulators as bf16 (bias + ReLU applied) and is fed straight back as the B operand of
+// the 1x1 contraction (accumulator tile -> next MFMA's operand: the 32x32 C/D map puts the pixel on
+// the lane and channels in the registers, exactly the B-operand shape; the K order is the
+// accumulator row order, which the host bakes into the packed 1x1 weights).
+//
+// Weight pipeline: the 3x3 filters stream through a 2-slot LDS ring one tap ROW (3 taps, 24 KB) per
+// stage by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), issued one
+// stage (48 MFMAs per wave) ahead; one barrier per stage.  The ring rows are unpadded (an LDS-DMA
+// wave-instruction writes 1 KB contiguously) and XOR-swizzled through the per-lane SOURCE address
+// so the A-fragment ds_read_b128 stay conflict-free.  The 1x1 slice of a slab arrives the same way.
 // Outputs are written as contiguous NCHW fp32 rows (lane = pixel), the reference's head layout.
 #include "common.h"
 
@@ -39,26 +44,36 @@ struct HeadsCfg {
     static constexpr int ES = sizeof(T);
     static constexpr int NT = TH / 8;                 // N-tiles (rows of 32 pixels) per wave, 8 waves
     static constexpr int IN_H = TH + 2, IN_W = TW + 2;
-    static constexpr int SB = HC_IN * ES + 16;        // halo pixel stride
+    static constexpr int SB = HC_IN * ES + 16;        // halo pixel stride (padded: register-staged once)
     static constexpr int RB = IN_W * SB;              // halo row stride
-    static constexpr int WB = HC_IN * ES + 16;        // ring row stride (64 K-elements of one tap)
-    static constexpr int W2B = HC_SLAB * ES + 16;     // W2 slab row stride
+    static constexpr int RBW = HC_IN * ES;            // weight row bytes (64 K elements), UNPADDED: LDS-DMA image
+    static constexpr int CPR = RBW / 16;              // 16-byte chunks per weight row (8 bf16 / 16 f32)
+    static constexpr int SWZ_SHIFT = ES == 2 ? 1 : 0; // chunk' = chunk ^ ((row >> SWZ_SHIFT) & (CPR-1))
+    static constexpr int TAPS = ES == 2 ? 3 : 1;      // taps per stage (f32: LDS only fits one)
+    static constexpr int TRS = 9 / TAPS;              // stages per slab
+    static constexpr int SLOT = TAPS * HC_SLAB * RBW; // ring slot bytes
     static constexpr int LDS_IN = IN_H * RB;
-    static constexpr int LDS_RING = HC_SLAB * WB;     // one slot: 64 rows
-    static constexpr int LDS_W2 = 32 * HC_MT2 * W2B;  // 96 rows
-    static constexpr int LDS = LDS_IN + 2 * LDS_RING + LDS_W2;
-    static constexpr int VPR = HC_IN * ES / 16;       // 16-byte vectors per 64-element row
-    static constexpr int NSTG = (32 * HC_MT2 * VPR + 511) / 512;   // staging vectors per thread (W2 stage is the largest)
+    static constexpr int LDS_W2 = 32 * HC_MT2 * RBW;  // 96 rows
+    static constexpr int LDS = LDS_IN + 2 * SLOT + LDS_W2;
+    static constexpr int RPI = 1024 / RBW;            // weight rows per LDS-DMA wave-instruction
+    static constexpr int VPR = HC_IN * ES / 16;       // 16-byte vectors per halo pixel
 };
+
+__device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
 
 // Second contraction of a head: acc2[m2] += W2[rows of tile m2][slab K] . ReLU(acc + b1), then acc = 0.
 // The accumulator registers 8s..8s+7 of a 32x32 tile are K-step s of the B operand (lane = pixel);
-// the matching A fragment (K in accumulator-row order) sits at column m*32 + h*16 + s*8 of the
-// host-permuted W2 row.
-template <typename T, int NT, int M2>
+// the matching A fragment (K in accumulator-row order) sits at K offset m*32 + h*16 + s*8 of the
+// host-permuted W2 row (swizzled LDS image, see HeadsCfg).
+template <typename T, int TH, int NT, int M2>
 __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][NT], const float *__restrict__ b1,
-                                      const char *s_w2, int w2b, int r, int h)
+                                      const char *s_w2, int r, int h, int sw)
 {
+    using C = HeadsCfg<T, TH>;
     using E = ET<T>;
     constexpr int ES = sizeof(T);
 #pragma unroll
@@ -88,9 +103,11 @@ __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][N
                                     pack_bf16x2(x[6], x[7])};
                 }
             }
+            const int c = (m * 32 + h * 16 + sb * 8) * ES / 16;        // first 16-byte chunk of this K run
 #pragma unroll
             for (int m2 = 0; m2 < M2; ++m2) {
-                const typename E::frag fa = E::lds_frag(s_w2 + (m2 * 32 + r) * w2b + (m * 32 + h * 16 + sb * 8) * ES);
+                const char *row = s_w2 + (m2 * 32 + r) * C::RBW;
+                const typename E::frag fa = E::lds_frag2(row + ((c ^ sw) << 4), row + (((c + 1) ^ sw) << 4));
 #pragma unroll
                 for (int n = 0; n < NT; ++n) E::mma(acc2[m2][n], fa, fb[n]);
             }
@@ -108,7 +125,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     __shared__ __attribute__((aligned(16))) char smem[C::LDS];
     char *s_in = smem;
     char *s_ring = smem + C::LDS_IN;
-    char *s_w2 = s_ring + 2 * C::LDS_RING;
+    char *s_w2 = s_ring + 2 * C::SLOT;
 
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
@@ -118,53 +135,45 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * C::TW;
     const int slabs = a.head_conv / HC_SLAB;
-    const int stages_per_head = slabs * 10;            // 9 tap stages + 1 "W2" stage per slab
-    const int nstages = a.nheads * stages_per_head;
+    const int nstages = a.nheads * slabs * C::TRS;       // tap-row stages of the whole launch
+    const int sw = (r >> C::SWZ_SHIFT) & (C::CPR - 1);   // XOR swizzle of this lane's A-fragment rows
 
-    // ---- stage descriptor: what global data stage `s` needs in LDS -------------------------------
-    // tap stage : 64 rows x 64 K of W1 (rows = intermediate channels of the slab) -> ring slot (k & 1)
-    // W2 stage  : 96 rows x 64 K of the head's packed 1x1 weights                 -> s_w2
-    // two staging register sets: the loads of stage s+2 are issued while stage s computes and are written
-    // to LDS one stage later, so a weight fetch has two stages (~1 us) to land instead of one
-    u32x4 stgA[C::NSTG], stgB[C::NSTG];
-    auto prefetch_into = [&](int s, u32x4 (&stg)[C::NSTG]) {
-        if ((a.dbg & 1) && s > 1) return;
-        const int head = s / stages_per_head, q = s - head * stages_per_head;
-        const int slab = q / 10, k = q - slab * 10;
+    // ---- LDS-DMA of stage s: TAPS taps x 64 rows of W1 for (head, slab) -> ring slot s & 1 -----------
+    // lane i of a wave-instruction lands at byte i*16 of a 1 KB run = RPI rows; it fetches source
+    // chunk (i % CPR) ^ swz(row) so that LDS position p of a row holds chunk p ^ swz(row).
+    auto issue_w1 = [&](int s) {
+        if ((a.dbg & 1) && s > 0) return;
+        const int hs = s / C::TRS, tr = s - hs * C::TRS;        // hs = head * slabs + slab
+        const int head = hs / slabs, slab = hs - head * slabs;
+        char *slot = s_ring + (s & 1) * C::SLOT;
+        constexpr int NI = C::TAPS * HC_SLAB / C::RPI;          // wave-instructions per stage (24 / 16)
 #pragma unroll
-        for (int j = 0; j < C::NSTG; ++j) {
-            const int i = tid + j * 512;
-            const int row = i / C::VPR, v = i - row * C::VPR;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (k < 9) {
-                if (row < HC_SLAB)
-                    val = *reinterpret_cast<const u32x4 *>(
-                        a.w1 + (((size_t)(head * a.head_conv + slab * HC_SLAB + row) * 9 + k) * HC_IN) * ES + v * 16);
-            } else if (row < 32 * HC_MT2) {
-                val = *reinterpret_cast<const u32x4 *>(
-                    a.w2[head] + ((size_t)row * a.head_conv + slab * HC_SLAB) * ES + v * 16);
-            }
-            stg[j] = val;
+        for (int j = 0; j < NI / 8; ++j) {
+            const int g = j * 8 + wv;                            // 1 KB run index
+            const int row_all = g * C::RPI + l / C::CPR;         // = tap_in_stage * 64 + row
+            const int tp = row_all / HC_SLAB, row = row_all - tp * HC_SLAB;
+            const int c = (l % C::CPR) ^ ((row >> C::SWZ_SHIFT) & (C::CPR - 1));
+            const size_t chan = (size_t)head * a.head_conv + slab * HC_SLAB + row;
+            glds16(a.w1 + ((chan * 9 + tr * C::TAPS + tp) * HC_IN) * ES + c * 16, slot + g * 1024);
         }
     };
-    auto commit_from = [&](int s, u32x4 (&stg)[C::NSTG]) {
-        const int q = s % stages_per_head;
-        const int k = q % 10;
+    // ---- LDS-DMA of the 1x1 slice [96 rows][64 K of this slab] -> s_w2 --------------------------------
+    auto issue_w2 = [&](int head, int slab) {
+        if (a.dbg & 1) return;
+        constexpr int NI = 32 * HC_MT2 / C::RPI;                 // 12 / 24 wave-instructions
 #pragma unroll
-        for (int j = 0; j < C::NSTG; ++j) {
-            const int i = tid + j * 512;
-            const int row = i / C::VPR, v = i - row * C::VPR;
-            if (k < 9) {
-                if (row < HC_SLAB)
-                    *reinterpret_cast<u32x4 *>(s_ring + (k & 1) * C::LDS_RING + row * C::WB + v * 16) = stg[j];
-            } else if (row < 32 * HC_MT2) {
-                *reinterpret_cast<u32x4 *>(s_w2 + row * C::W2B + v * 16) = stg[j];
+        for (int j = 0; j < (NI + 7) / 8; ++j) {
+            const int g = j * 8 + wv;
+            if (g < NI) {
+                const int row = g * C::RPI + l / C::CPR;
+                const int c = (l % C::CPR) ^ ((row >> C::SWZ_SHIFT) & (C::CPR - 1));
+                glds16(a.w2[head] + ((size_t)row * a.head_conv + slab * HC_SLAB) * ES + c * 16, s_w2 + g * 1024);
             }
         }
     };
 
-    // ---- prologue: halo tile (all 64 channels, zero outside the image) + stages 0 and 1 ------------
-    prefetch_into(0, stgA);
+    // ---- prologue: stage 0 weights in flight, halo tile (all 64 channels, zero outside the image) -----
+    issue_w1(0);
     {
         const size_t in_img = (size_t)b * a.H * a.W;
         constexpr int NHV = C::IN_H * C::IN_W * C::VPR;
@@ -193,19 +202,14 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                 });
         }
     }
-    commit_from(0, stgA);
-    prefetch_into(min(1, nstages - 1), stgB);
-    __syncthreads();
+    __syncthreads();   // (emits s_waitcnt vmcnt(0): the LDS-DMA of stage 0 has landed)
 
     int boff[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n) boff[n] = (wv * NT + n) * C::RB + r * C::SB + 8 * h * ES;
-    const int aoff = r * C::WB + 8 * h * ES;
 
-    // One head with M2 row tiles of 1x1 output.  Accumulators are local to this instantiation so
-    // no control-flow merge ever joins differently-updated accumulator sets (that costs copies
-    // and spills); `s` is the running stage index of the weight pipeline.
-    auto run_head = [&](int head, int &s) {
+    int s = 0;
+    for (int head = 0; head < a.nheads; ++head) {
         f32x16 acc[2][NT], acc2[M2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -220,55 +224,40 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc2[m][n][i] = 0.f;
         for (int slab = 0; slab < slabs; ++slab) {
-            // 10 stages per slab (9 taps + the 1x1 stage), fully unrolled so the staging-set parity
-            // (stage s uses set s & 1; s is even at every slab start) is a compile-time choice
+#pragma unroll 1
+            for (int tr = 0; tr < C::TRS; ++tr, ++s) {
+                if (s + 1 < nstages) issue_w1(s + 1);          // slot (s+1)&1 was last read in stage s-1
+                if (tr == (C::TRS > 1 ? 1 : 0)) issue_w2(head, slab);   // after the barrier that follows the previous gemm2
+                const char *slot = s_ring + (s & 1) * C::SLOT;
 #pragma unroll
-            for (int k = 0; k < 10; ++k, ++s) {
-                {   // unconditional (stage index clamped at the tail): a path-independent number of
-                    // outstanding loads lets hipcc emit a counted s_waitcnt vmcnt(N) at the commit below
-                    const int sp = min(s + 2, nstages - 1);
-                    if (k & 1) prefetch_into(sp, stgB); else prefetch_into(sp, stgA);
-                }
-                if (k < 9) {
-                    // ---- 3x3 tap k of this slab: acc[2][NT] += W1[64 x 64] . halo(tap)[64 x pixels] ----
-                    const int dy = k / 3, dx = k - dy * 3;
-                    const char *wr = s_ring + (k & 1) * C::LDS_RING + aoff;
+                for (int tp = 0; tp < C::TAPS; ++tp) {
+                    const int tap = tr * C::TAPS + tp;
+                    const int dy = tap / 3, dx = tap - dy * 3;
                     const char *br = s_in + dy * C::RB + dx * C::SB;
-                    // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk issue
-                    // (explicit double buffer: hipcc otherwise re-uses one register set and every
-                    // k-step waits out its own ds_read latency)
-                    typename E::frag fa[2][2], fb[2][NT];
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) fa[0][m] = E::lds_frag(wr + m * 32 * C::WB);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) fb[0][n] = E::lds_frag(br + boff[n]);
 #pragma unroll
                     for (int kk = 0; kk < HC_IN / 16; ++kk) {
-                        constexpr int NK = HC_IN / 16;
-                        const int cur = kk & 1, nxt = cur ^ 1;
-                        if (kk + 1 < NK) {
+                        const int c = (kk * 16 + 8 * h) * ES / 16;
+                        typename E::frag fa[2], fb[NT];
 #pragma unroll
-                            for (int m = 0; m < 2; ++m) fa[nxt][m] = E::lds_frag(wr + m * 32 * C::WB + (kk + 1) * 16 * ES);
-#pragma unroll
-                            for (int n = 0; n < NT; ++n) fb[nxt][n] = E::lds_frag(br + boff[n] + (kk + 1) * 16 * ES);
+                        for (int m = 0; m < 2; ++m) {
+                            const char *row = slot + (tp * HC_SLAB + m * 32 + r) * C::RBW;
+                            fa[m] = E::lds_frag2(row + ((c ^ sw) << 4), row + (((c + 1) ^ sw) << 4));
                         }
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
-                            for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[cur][m], fb[cur][n]);
+                            for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
                     }
-                } else {
-                    // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 ----
-                    gemm2<T, NT, M2>(acc, acc2, a.b1 + head * a.head_conv + slab * HC_SLAB, s_w2, C::W2B, r, h);
                 }
-                {
-                    const int sc = min(s + 1, nstages - 1);
-                    if ((k + 1) & 1) commit_from(sc, stgB); else commit_from(sc, stgA);
-                }
-                __syncthreads();
+                __syncthreads();   // vmcnt(0) + barrier: next stage's weights (and the 1x1 slice) have landed
             }
+            // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 ------------
+            gemm2<T, TH, NT, M2>(acc, acc2, a.b1 + head * a.head_conv + slab * HC_SLAB, s_w2, r, h, sw);
+            if (C::TRS == 1) __syncthreads();   // (f32 path) s_w2 is rewritten in the very next stage
         }
-        // ---- head done: z = acc2 + b2 -> NCHW fp32 (lane = pixel: coalesced rows) --------------------
+        // ---- head done: z = acc2 + b2 -> NCHW fp32 (lane = pixel: coalesced rows) ------------------------
         const int C_head = a.C[head];
         const float *b2 = a.b2[head];
         float *out = a.out[head];
@@ -292,10 +281,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                 }
             }
         }
-    };
-
-    int s = 0;
-    for (int head = 0; head < a.nheads; ++head) run_head(head, s);
+    }
 }
 
 static_assert(HEADS_MAX == H3D_HEADS_MAX, "header/kernel mismatch");
