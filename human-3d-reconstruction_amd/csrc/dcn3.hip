@@ -26,6 +26,7 @@ struct Dcn3Args {
     int B, H, W, Cin, in_cs;
     int Cout, out_cs, relu, out_mode, wrows;
     int tiles_x, tiles_y;
+    int dbg;   // profiling ablation (h3d_op.reserved): 1 no phase-A MFMA, 2 no gather/blend, 4 no phase-B MFMA, 8 stage once
 };
 
 template <typename T, int MT, int CK, int MARGIN>
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     constexpr int NV = (NH + NW + C::THREADS - 1) / C::THREADS;
     u32x4 stg[NV];
     auto load_stage = [&](int s) {
+        if ((a.dbg & 8) && s > 0) return;
         const bool phaseA = s < nchunks;
         const int c0 = (phaseA ? s : s - nchunks) * CK;
         const char *wsrc = phaseA ? a.woff : a.w;
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
             stg[j] = val;
         }
     };
-    auto store_stage = [&]() {
+    auto store_stage = [&](int s) {
+        if ((a.dbg & 8) && s > 0) return;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * C::THREADS;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     load_stage(0);
     for (int s = 0; s < nchunks; ++s) {
         if (s) __syncthreads();
-        store_stage();
+        store_stage(s);
         __syncthreads();
         load_stage(s + 1);                       // s + 1 == nchunks is phase B's first stage
 #pragma unroll
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
             for (int kk = 0; kk < CK / 16; ++kk) {
                 const typename X::frag fa = X::lds(s_w + aoff + (tap * CK + kk * 16) * SS);
                 const typename X::frag fb = X::lds(s_h + bconv + dy * C::RBH + dx * C::SBH + kk * 16 * SS);
-                X::mma(aoffs, fa, fb);
+                if (a.dbg & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, fb);
             }
         }
     }
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
     for (int s = nchunks; s < 2 * nchunks; ++s) {
         __syncthreads();
-        store_stage();
+        store_stage(s);
         __syncthreads();
         if (s + 1 < 2 * nchunks) load_stage(s + 1);
 #pragma unroll
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
             const char *p00 = s_h + boff[tap];
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
+                if (a.dbg & 2) { fb[kk] = X::lds(p00 + kk * 16 * SS); continue; }
                 typename X::frag v[4];
                 v[0] = X::lds(p00 + kk * 16 * SS);
                 v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
@@ -223,6 +227,11 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
                 typename X::frag fa[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+                if (a.dbg & 4) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) { X::keep(fa[m]); X::keep(fb[kk]); }
+                    continue;
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb[kk]);
             }
@@ -327,6 +336,7 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
     a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode; a.wrows = op.wrows;
     a.tiles_x = a.tiles_y = 0;
+    a.dbg = op.reserved;
     if (op.dtype == H3D_BF16) {
         if (op.Cin % 32 == 0 && op.Cout <= 64) {
             if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 32, 2>(a, st);
