@@ -49,7 +49,7 @@ struct ConvCfg {
     static constexpr int LDS = LDS_IN + LDS_W;
 };
 
-template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4>
+template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4, bool FASTEPI = false>
 __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
 {
     using C = ConvCfg<T, KS, STRIDE, MT, CK, TH, WAVES>;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
     EpiArgs e;
     e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
-    tile_epilogue<T, MT, C::NT>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    tile_epilogue<T, MT, C::NT, FASTEPI>(acc, e, b, oy0, ox0, cout0, wv, r, h);
 }
 
 template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4>
@@ -178,7 +178,10 @@ static int launch_conv_cfg(const ConvArgs &a0, hipStream_t st)
     if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
                         CK, TH, WAVES))
         return H3D_OK;
-    hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES>), grid, dim3(C::THREADS), 0, st, a);
+    if (a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0)
+        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, true>), grid, dim3(C::THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, false>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("conv_kernel");
     return H3D_OK;
 }

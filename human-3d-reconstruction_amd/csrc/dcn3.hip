@@ -45,7 +45,7 @@ struct Dcn3Cfg {
     static constexpr int LDS = LDS_H + BN * WB;
 };
 
-template <typename T, int MT, int CK, int MARGIN>
+template <typename T, int MT, int CK, int MARGIN, bool FASTEPI = false>
 __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
 {
     using C = Dcn3Cfg<T, MT, CK, MARGIN>;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     EpiArgs e;
     e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
-    tile_epilogue<T, MT, 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    tile_epilogue<T, MT, 1, FASTEPI>(acc, e, b, oy0, ox0, cout0, wv, r, h);
 }
 
 template <typename T, int MT, int CK, int MARGIN>
@@ -313,7 +313,10 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN)) return H3D_OK;
-    hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN>), grid, dim3(C::THREADS), 0, st, a);
+    if (a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0)
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, true>), grid, dim3(C::THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, false>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("dcn3_kernel");
     return H3D_OK;
 }

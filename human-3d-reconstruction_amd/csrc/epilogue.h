@@ -13,11 +13,46 @@ struct EpiArgs {
     int Ho, Wo, Cout, out_cs, res_cs, relu, out_mode;
 };
 
-template <typename T, int MT, int NT>
+// FAST = the hot configuration only (NHWC output of type T, Cout % 4 == 0): a fraction of the general
+// epilogue's code, which matters because the conv/DCN kernels otherwise approach the 64 KB instruction
+// cache that two CUs share.  Launchers pick FAST whenever the op qualifies.
+template <typename T, int MT, int NT, bool FAST = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[MT][NT], const EpiArgs &a, int b, int oy0, int ox0,
                                               int cout0, int wv, int r, int h)
 {
     using E = ET<T>;
+    if constexpr (FAST) {
+        const bool has_res = a.res != nullptr;
+        const float lo = a.relu ? 0.f : -__builtin_inff();   // fmaxf(v, -inf) == v
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int py = wv * (2 * NT) + n * 2 + (r >> 4), px = r & 15;
+            const int oy = oy0 + py, ox = ox0 + px;
+            if (oy >= a.Ho || ox >= a.Wo) continue;
+            const size_t opix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+            T *op = reinterpret_cast<T *>(a.out) + opix * a.out_cs + cout0 + 4 * h;
+            const T *rp = reinterpret_cast<const T *>(a.res) + opix * a.res_cs + cout0 + 4 * h;
+            const float *bp = a.bias + cout0 + 4 * h;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = m * 32 + 8 * g;
+                    if (cout0 + co + 4 * h >= a.Cout) continue;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bp + co);
+                    float v0 = acc[m][n][4 * g + 0] + bv.x, v1 = acc[m][n][4 * g + 1] + bv.y;
+                    float v2 = acc[m][n][4 * g + 2] + bv.z, v3 = acc[m][n][4 * g + 3] + bv.w;
+                    if (has_res) {
+                        float rv[4];
+                        load4<T>(rp + co, rv);
+                        v0 += rv[0]; v1 += rv[1]; v2 += rv[2]; v3 += rv[3];
+                    }
+                    store4<T>(op + co, fmaxf(v0, lo), fmaxf(v1, lo), fmaxf(v2, lo), fmaxf(v3, lo));
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int py = wv * (2 * NT) + n * 2 + (r >> 4), px = r & 15;
