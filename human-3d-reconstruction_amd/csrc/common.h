@@ -20,6 +20,14 @@ void h3d_set_error(const char *fmt, ...);
 // Records the kernel instantiation an op maps to; returns true when the caller must NOT launch
 // (h3d_op_kernel_name's dry run).  Names match the kernel symbols rocprofv3 reports.
 bool h3d_note_kernel(const char *fmt, ...);
+
+// Profiling ablation switches (h3d_op.reserved) exist only in `make ABLATE=1` builds: as run-time
+// tests they put every MFMA in its own basic block and wreck the schedule of the production kernel.
+#ifdef H3D_ABLATE
+#define H3D_DBG(a) ((a).dbg)
+#else
+#define H3D_DBG(a) 0
+#endif
 #define H3D_FAIL(code, ...)        \
     do {                           \
         h3d_set_error(__VA_ARGS__); \

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
         float omv[28];
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            const f32x4 v = (a.dbg & 16) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(omp + 4 * q);   // om_cs >= 28, 16-byte aligned rows
+            const f32x4 v = (H3D_DBG(a) & 16) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(omp + 4 * q);   // om_cs >= 28, 16-byte aligned rows
             omv[4 * q] = v[0]; omv[4 * q + 1] = v[1]; omv[4 * q + 2] = v[2]; omv[4 * q + 3] = v[3];
         }
 #pragma unroll
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
                 const char *p00 = s_h + boff[n][tap];
 #pragma unroll
                 for (int kk = 0; kk < CK / 16; ++kk) {
-                    if (a.dbg & 2) { fb[n][kk] = X::lds(p00 + kk * 16 * SS); continue; }
+                    if (H3D_DBG(a) & 2) { fb[n][kk] = X::lds(p00 + kk * 16 * SS); continue; }
                     typename X::frag v[4];
                     v[0] = X::lds(p00 + kk * 16 * SS);
                     v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
                 typename X::frag fa[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
-                if (a.dbg & 4) {
+                if (H3D_DBG(a) & 4) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
 
     // ================= pass 2 (rare): samples whose corners left the apron, gathered from global ======
     // Compact rolled loops; geometry is recomputed from the offsets so pass 1 carries no slow-path code.
-    if (!(a.dbg & 8) && __syncthreads_or(slow ? 1 : 0)) {
+    if (!(H3D_DBG(a) & 8) && __syncthreads_or(slow ? 1 : 0)) {
         for (int c0 = 0; c0 < a.Cin; c0 += CK) {
             __syncthreads();
             constexpr int WV = 9 * C::VPP;

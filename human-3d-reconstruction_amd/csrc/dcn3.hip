@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     constexpr int NV = (NH + NW + C::THREADS - 1) / C::THREADS;
     u32x4 stg[NV];
     auto load_stage = [&](int s) {
-        if ((a.dbg & 8) && s > 0) return;
+        if ((H3D_DBG(a) & 8) && s > 0) return;
         const bool phaseA = s < nchunks;
         const int c0 = (phaseA ? s : s - nchunks) * CK;
         const char *wsrc = phaseA ? a.woff : a.w;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
         }
     };
     auto store_stage = [&](int s) {
-        if ((a.dbg & 8) && s > 0) return;
+        if ((H3D_DBG(a) & 8) && s > 0) return;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * C::THREADS;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
             for (int kk = 0; kk < CK / 16; ++kk) {
                 const typename X::frag fa = X::lds(s_w + aoff + (tap * CK + kk * 16) * SS);
                 const typename X::frag fb = X::lds(s_h + bconv + dy * C::RBH + dx * C::SBH + kk * 16 * SS);
-                if (a.dbg & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, fb);
+                if (H3D_DBG(a) & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, fb);
             }
         }
     }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
             const char *p00 = s_h + boff[tap];
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
-                if (a.dbg & 2) { fb[kk] = X::lds(p00 + kk * 16 * SS); continue; }
+                if (H3D_DBG(a) & 2) { fb[kk] = X::lds(p00 + kk * 16 * SS); continue; }
                 typename X::frag v[4];
                 v[0] = X::lds(p00 + kk * 16 * SS);
                 v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
                 typename X::frag fa[MT];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
-                if (a.dbg & 4) {
+                if (H3D_DBG(a) & 4) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) { X::keep(fa[m]); X::keep(fb[kk]); }
                     continue;

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     // lane i of a wave-instruction lands at byte i*16 of a 1 KB run = RPI rows; it fetches source
     // chunk (i % CPR) ^ swz(row) so that LDS position p of a row holds chunk p ^ swz(row).
     auto issue_w1 = [&](int s) {
-        if ((a.dbg & 1) && s > 0) return;
+        if ((H3D_DBG(a) & 1) && s > 0) return;
         const int hs = s / C::TRS, tr = s - hs * C::TRS;        // hs = head * slabs + slab
         const int head = hs / slabs, slab = hs - head * slabs;
         char *slot = s_ring + (s & 1) * C::SLOT;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     };
     // ---- LDS-DMA of the 1x1 slice [96 rows][64 K of this slab] -> s_w2 --------------------------------
     auto issue_w2 = [&](int head, int slab) {
-        if (a.dbg & 1) return;
+        if (H3D_DBG(a) & 1) return;
         constexpr int NI = 32 * HC_MT2 / C::RPI;                 // 12 / 24 wave-instructions
 #pragma unroll
         for (int j = 0; j < (NI + 7) / 8; ++j) {
