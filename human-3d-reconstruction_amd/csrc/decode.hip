@@ -51,50 +51,111 @@ __device__ __forceinline__ float sigmoid_clamp(float x)
     return fminf(fmaxf(y, 1e-4f), 1.0f - 1e-4f);
 }
 
-constexpr int NMS_THREADS = 256;
+constexpr int NMS_THREADS = 1024;   // 16 waves: a (b, c) map is one workgroup, so latency is hidden by waves, not by workgroups
+constexpr int NMS_WAVES = NMS_THREADS / 64;
 constexpr int NMS_MAXK = 1024;
 
+// exclusive prefix sum of `v` over the workgroup's threads (wave shuffles + one LDS word per wave);
+// *total = sum over all threads.  Two barriers; s_wave[NMS_WAVES] is free again on return.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave, int tid, uint32_t *total)
+{
+    const int lane = tid & 63, w = tid >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < NMS_WAVES; ++j) {
+        const uint32_t x = s_wave[j];
+        if (j < w) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
 __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__restrict__ heat, int C, int H, int W, int K,
-                                                               int flags, float *__restrict__ o_score,
+                                                               int ncand, int flags, float *__restrict__ o_score,
                                                                int64_t *__restrict__ o_ind, float *__restrict__ o_y,
                                                                float *__restrict__ o_x)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_key[];  // [HW] then candidates
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_key[];  // [HW] keys, then candidates, then keep bits
     __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_wave[NMS_WAVES];
     __shared__ uint32_t s_sel[2];  // [0] = chosen bin, [1] = remaining need
     __shared__ uint32_t s_cnt;
     const int tid = threadIdx.x;
     const int HW = H * W;
     const float *map = heat + (size_t)blockIdx.x * HW;
     u64 *s_cand = reinterpret_cast<u64 *>(s_key + ((HW + 1) & ~1));
+    u64 *s_mask = s_cand + ncand;             // keep bits, one word per 64 pixels
 
     // ---- sigmoid + 3x3 NMS -> order-preserving keys ----------------------------------------------
-    for (int i = tid; i < HW; i += NMS_THREADS) {
-        const int y = i / W, x = i - y * W;
-        const float v = map[i];
-        float m = v;
-        if (!(flags & 2))
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= H) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= W) continue;
-                m = fmaxf(m, map[yy * W + xx]);
-            }
+    // pass 1: (optional) sigmoid of every pixel ONCE, straight into LDS; 8 independent loads per
+    //         thread in flight per batch (8192 per workgroup)
+    float *s_val = reinterpret_cast<float *>(s_key);
+    for (int base = 0; base < HW; base += 8 * NMS_THREADS) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = base + j * NMS_THREADS + tid;
+            v[j] = (i < HW) ? map[i] : 0.f;
         }
-        float sv = v, sm = m;
-        if (flags & 1) { sv = sigmoid_clamp(v); sm = sigmoid_clamp(m); }
-        // heat * keep (keep in {0,1}); +0.0f folds -0 into +0 so equal values share one key
-        const float val = ((sm == sv) ? sv : sv * 0.0f) + 0.0f;
-        s_key[i] = fkey(val);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = base + j * NMS_THREADS + tid;
+            if (i < HW) s_val[i] = (flags & 1) ? sigmoid_clamp(v[j]) : v[j];
+        }
+    }
+    __syncthreads();
+    // pass 2: keep = (3x3 max == centre) on the LDS map (the reference pools the sigmoid outputs,
+    //         decode.py:6-13); one ballot word per 64 consecutive pixels
+    for (int base = 0; base < HW; base += NMS_THREADS) {
+        const int i = base + tid;
+        bool keep = false;
+        if (i < HW) {
+            const int y = i / W, x = i - y * W;
+            const float v = s_val[i];
+            float m = v;
+            if (!(flags & 2)) {
+                const int y0 = max(y - 1, 0), y1 = min(y + 1, H - 1), x0 = max(x - 1, 0), x1 = min(x + 1, W - 1);
+                // clamped taps repeat an in-range neighbour (or the centre): the max is unchanged
+                const float *r0 = s_val + y0 * W, *r1 = s_val + y * W, *r2 = s_val + y1 * W;
+                const float a0 = r0[x0], a1 = r0[x], a2 = r0[x1], b0 = r1[x0], b2 = r1[x1], c0 = r2[x0], c1 = r2[x],
+                            c2 = r2[x1];
+                m = fmaxf(fmaxf(fmaxf(fmaxf(a0, a1), fmaxf(a2, b0)), fmaxf(fmaxf(b2, c0), fmaxf(c1, c2))), v);
+            }
+            keep = (m == v);
+        }
+        const u64 word = __ballot(keep);
+        if ((tid & 63) == 0 && i < HW) s_mask[i >> 6] = word;        // i is a multiple of 64 in lane 0
+    }
+    __syncthreads();
+    // pass 3: heat * keep -> key, in place (+0.0f folds -0 into +0 so equal values share one key)
+    for (int base = 0; base < HW; base += NMS_THREADS) {
+        const int i = base + tid;
+        if (i < HW) {
+            const float sv = s_val[i];
+            const bool keep = (s_mask[i >> 6] >> (i & 63)) & 1ull;
+            const float val = (keep ? sv : sv * 0.0f) + 0.0f;
+            s_key[i] = fkey(val);
+        }
     }
     __syncthreads();
 
+#ifdef H3D_ABLATE
+    if (flags & 0x100) return;
+#endif
     // ---- radix select: key of the K-th largest element ------------------------------------------
     uint32_t prefix = 0, pmask = 0, need = (uint32_t)K;
     for (int pass = 3; pass >= 0; --pass) {
-        s_hist[tid] = 0;
+        if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
         const int sh = pass * 8;
         // run-length aggregation: NMS leaves most of a heat map at exactly 0 (one hot bin), so a plain
@@ -115,17 +176,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__re
         }
         if (run_cnt) atomicAdd(&s_hist[run_bin], run_cnt);
         __syncthreads();
-        // inclusive suffix sum over bins (Hillis-Steele, 8 steps)
-        uint32_t v = s_hist[tid];
-        for (int off = 1; off < 256; off <<= 1) {
-            const uint32_t add = (tid + off < 256) ? s_hist[tid + off] : 0u;
-            __syncthreads();
-            v += add;
-            s_hist[tid] = v;
-            __syncthreads();
-        }
-        const uint32_t above = (tid + 1 < 256) ? s_hist[tid + 1] : 0u;  // elements in bins > tid
-        if (v >= need && above < need) { s_sel[0] = (uint32_t)tid; s_sel[1] = need - above; }
+        // thread t < 256 owns bin t: elements in bins > t = total - inclusive prefix
+        const uint32_t hv = (tid < 256) ? s_hist[tid] : 0u;
+        uint32_t total;
+        const uint32_t excl = block_excl_scan(hv, s_wave, tid, &total);
+        const uint32_t above = total - excl - hv;
+        if (tid < 256 && above + hv >= need && above < need) { s_sel[0] = (uint32_t)tid; s_sel[1] = need - above; }
         __syncthreads();
         prefix |= s_sel[0] << sh;
         pmask |= 0xffu << sh;
@@ -135,6 +191,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__re
     const uint32_t kth = prefix;            // exact key of the K-th largest
     const uint32_t n_gt = (uint32_t)K - need;  // elements strictly greater; take `need` equal ones
 
+#ifdef H3D_ABLATE
+    if (flags & 0x200) return;
+#endif
     // ---- compaction: all keys > kth (any order), then `need` keys == kth in index order ----------
     if (tid == 0) s_cnt = 0;
     __syncthreads();
@@ -149,17 +208,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__re
     const int lo = tid * chunk, hi = min(lo + chunk, HW);
     uint32_t eq = 0;
     for (int i = lo; i < hi; ++i) eq += (s_key[i] == kth);
-    s_hist[tid] = eq;
-    __syncthreads();
-    uint32_t incl = eq;  // inclusive prefix sum over threads
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t add = (tid >= off) ? s_hist[tid - off] : 0u;
-        __syncthreads();
-        incl += add;
-        s_hist[tid] = incl;
-        __syncthreads();
-    }
-    uint32_t rank = incl - eq;
+    uint32_t total_eq;
+    uint32_t rank = block_excl_scan(eq, s_wave, tid, &total_eq);
     for (int i = lo; i < hi && rank < need; ++i)
         if (s_key[i] == kth) {
             s_cand[n_gt + rank] = ((u64)kth << 32) | (u64)(0xffffffffu - (uint32_t)i);
@@ -169,6 +219,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__re
     while (N < K) N <<= 1;
     for (int i = K + tid; i < N; i += NMS_THREADS) s_cand[i] = 0ull;
     __syncthreads();
+#ifdef H3D_ABLATE
+    if (flags & 0x400) return;
+#endif
     bitonic_desc(s_cand, N, tid, NMS_THREADS);
 
     for (int j = tid; j < K; j += NMS_THREADS) {
@@ -193,7 +246,7 @@ extern "C" int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K
         H3D_FAIL(H3D_ERR_UNSUPPORTED, "nms_topk: K=%d (max %d), H*W=%ld (max 36864)", K, NMS_MAXK, HW);
     int N = 1;
     while (N < K) N <<= 1;
-    const size_t lds = (size_t)((HW + 1) & ~1L) * 4 + (size_t)N * 8;
+    const size_t lds = (size_t)((HW + 1) & ~1L) * 4 + (size_t)N * 8 + (size_t)((HW + 63) / 64) * 8;
     static thread_local size_t max_set = 0;
     if (lds > 64 * 1024 && lds > max_set) {
         if (hipFuncSetAttribute((const void *)nms_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -201,7 +254,7 @@ extern "C" int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K
         max_set = lds;
     }
     hipLaunchKernelGGL(nms_topk_kernel, dim3(B * C), dim3(NMS_THREADS), lds, (hipStream_t)stream, heat, C, H, W, K,
-                       flags, scores, inds, ys, xs);
+                       N, flags, scores, inds, ys, xs);
     H3D_CHECK_LAUNCH("nms_topk_kernel");
     return H3D_OK;
 }
