@@ -38,7 +38,7 @@ PEAK_HBM_GBS = 8000.0
 def op_flops(op):
     """Algorithmic FLOPs of one plan op (2 per MAC; conv/deconv only, SURVEY 8d convention)."""
     px = op.B * op.Ho * op.Wo
-    if op.kind in (_lib.OP_CONV, _lib.OP_DCN, _lib.OP_STEM):
+    if op.kind in (_lib.OP_CONV, _lib.OP_CONV_STREAM, _lib.OP_DCN, _lib.OP_STEM):
         return 2.0 * px * op.Cout * op.Cin * op.ksize * op.ksize
     if op.kind == _lib.OP_DCN_FUSED:
         return 2.0 * px * (op.Cout + 27) * op.Cin * 9

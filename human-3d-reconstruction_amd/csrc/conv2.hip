@@ -1,0 +1,194 @@
+// 3x3 stride-1 convolution, generation 2 (bf16): implicit GEMM fed entirely by LDS-DMA.
+// (reference: the nn.Conv2d(k=3, s=1, p=1) + BN (+ residual) + ReLU of DLA-34's BasicBlock, model.py:42-71;
+//  same math as csrc/conv.hip, which keeps stride 2, 1x1, fp32 and non-NHWC outputs.)
+//
+// One workgroup = (2*WAVES) x 16 output pixels x (32*MT) output channels; wave w owns pixel rows
+// 2w, 2w+1 (one 32-pixel MFMA N-tile) and all MT M-tiles.  The contraction walks "stages" of 16 input
+// channels.  A stage's operands are two LDS images that `buffer_load ... lds` writes directly (no
+// staging registers, no ds_write, no address arithmetic in the loop):
+//   halo    [2*WAVES+2 rows][64 slots of 16 B]: pixel ix of a row owns slots 3ix, 3ix+1 (its 16
+//           channels) and a pad slot 3ix+2, so the pixel stride is 48 B (odd multiple of 16 B) and the
+//           row stride 1 KiB = ONE DMA wave-instruction; lanes whose pixel lies outside the image
+//           (or that own pad slots) carry an out-of-range buffer offset and the DMA writes zeros.
+//   weights [32*MT rows][19 slots]: slot 2*tap+h = input channels 8h..8h+7 of tap `tap`, slot 18 pad
+//           (row stride 304 B).  The host packs the filter bank stage-major in exactly this order
+//           (engine.PackedWeights.conv_stream), so the DMA is a linear copy of MT*9728 bytes.
+// Both strides make every 16-lane ds_read_b128 group hit 16 distinct 16-byte bank slots.
+// Two ring slots: stage s+1 is in flight while stage s feeds 9*MT MFMAs per wave; one barrier a stage.
+#include "common.h"
+#include "epilogue.h"
+
+struct Conv2Args {
+    const char *in;
+    const char *wimg;   // [Cin/16][G][32][19][16 B], G = row groups of 32 output channels (zero padded)
+    const float *bias;
+    const char *res;
+    char *out;
+    int B, H, W, Cin, in_cs;
+    int Cout, out_cs, res_cs, relu, out_mode;
+    int G, tiles_x, tiles_y;
+};
+
+template <int MT, int WAVES>
+struct Conv2Cfg {
+    static constexpr int TH = 2 * WAVES;
+    static constexpr int ROWS = TH + 2;                 // halo rows = DMA pieces of the halo image
+    static constexpr int HALO = ROWS * 1024;
+    static constexpr int WROW = 19 * 16;                // 304 B
+    static constexpr int WGRP = 32 * WROW;              // one 32-row group: 9728 B
+    static constexpr int WPIECES = (MT * WGRP + 1023) / 1024;
+    static constexpr int WALLOC = WPIECES * 1024;
+    static constexpr int SLOT = HALO + WALLOC;
+    static constexpr int LDS = 2 * SLOT;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int HP = (ROWS + WAVES - 1) / WAVES;       // halo pieces per wave
+    static constexpr int WP = (WPIECES + WAVES - 1) / WAVES;    // weight pieces per wave
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+// LDS-DMA of one stage into the ring slot at `base` (a plain function of plain arguments: the buffer-descriptor
+// type does not exist in the host pass, and a lambda capturing one silently drops the kernel's stub)
+template <int MT, int WAVES>
+__device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, const char *wimg, int w_bytes, char *base,
+                                            const int *hoff, int woff, int wv, int s, int wsrc)
+{
+    using C = Conv2Cfg<MT, WAVES>;
+    // descriptors are rebuilt from wave-uniform scalars at every call (4 SGPRs each, no memory traffic)
+    const auto r_in = __builtin_amdgcn_make_buffer_rsrc((void *)in_b, 0, in_bytes, 0x00020000);
+    const auto r_w = __builtin_amdgcn_make_buffer_rsrc((void *)wimg, 0, w_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < C::HP; ++j) {
+        const int p = wv + j * WAVES;
+        if (p < C::ROWS) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (lds_void *)(base + p * 1024), 16, hoff[j], s * 32, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < C::WP; ++j) {
+        const int p = wv + j * WAVES;
+        if (p < C::WPIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void *)(base + C::HALO + p * 1024), 16, woff, wsrc + p * 1024, 0, 0);
+    }
+}
+
+template <int MT, int WAVES, bool FASTEPI>
+__global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
+{
+    using C = Conv2Cfg<MT, WAVES>;
+    using E = ET<bf16_t>;
+    __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63, r = l & 31, h = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler too
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int oy0 = ty * C::TH, ox0 = tx * 16;
+    const int g0 = blockIdx.y * MT;                               // first 32-row group of this workgroup
+    const int cout0 = g0 * 32;
+    const int nst = a.Cin >> 4;
+
+    // ---- DMA descriptors: the image of batch b, and the packed filter bank ----------------------------
+    const size_t img_bytes = (size_t)a.H * a.W * a.in_cs * 2;
+    const char *in_b = a.in + (size_t)b * img_bytes;
+    const int w_bytes = nst * a.G * C::WGRP;
+    // per-lane source offsets of my halo pieces (stage 0); the stage adds 32 B through soffset
+    int hoff[C::HP];
+#pragma unroll
+    for (int j = 0; j < C::HP; ++j) {
+        const int iy = wv + j * WAVES;                            // halo row = piece
+        const int ix = l / 3, sub = l - 3 * ix;
+        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        const bool ok = iy < C::ROWS && ix < 18 && sub < 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        hoff[j] = ok ? ((gy * a.W + gx) * a.in_cs + sub * 8) * 2 : 0x7ffffff0;
+    }
+    const int woff = l * 16;
+
+    // fragment offsets inside a slot
+    const int py = 2 * wv + (r >> 4), px = r & 15;
+    const int boff = py * 1024 + px * 48 + h * 16;
+    const int aoff = C::HALO + r * C::WROW + h * 16;
+
+    f32x16 acc[MT][1];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
+
+    conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem, hoff, woff, wv, 0, g0 * C::WGRP);
+    for (int s = 0; s < nst; ++s) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): my pieces of stage s have landed
+        __syncthreads();                          // ... everyone's have; slot (s+1)&1 is no longer being read
+        if (s + 1 < nst)
+            conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + ((s + 1) & 1) * C::SLOT, hoff, woff, wv, s + 1, ((s + 1) * a.G + g0) * C::WGRP);
+        const char *sl = smem + (s & 1) * C::SLOT;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            const typename E::frag fb = E::lds_frag(sl + boff + dy * 1024 + dx * 48);
+            typename E::frag fa[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) fa[m] = E::lds_frag(sl + aoff + m * C::WGRP + tap * 32);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) E::mma(acc[m][0], fa[m], fb);
+        }
+    }
+
+    EpiArgs e;
+    e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
+    e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
+    tile_epilogue<bf16_t, MT, 1, FASTEPI>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+}
+
+template <int MT, int WAVES>
+static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
+{
+    using C = Conv2Cfg<MT, WAVES>;
+    static_assert(C::LDS <= 160 * 1024, "LDS budget");
+    Conv2Args a = a0;
+    a.tiles_x = cdiv(a.W, 16);
+    a.tiles_y = cdiv(a.H, C::TH);
+    dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
+    if (h3d_note_kernel("conv2_kernel<%d, %d>", MT, WAVES)) return H3D_OK;
+    if (a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0)
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, true>), grid, dim3(C::THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, false>), grid, dim3(C::THREADS), 0, st, a);
+    H3D_CHECK_LAUNCH("conv2_kernel");
+    return H3D_OK;
+}
+
+int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "conv_stream: null pointer");
+    if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "conv_stream: bf16 only (dtype %d)", op.dtype);
+    if (op.ksize != 3 || op.stride != 1 || op.Ho != op.H || op.Wo != op.W)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv_stream: covers 3x3 s1 p1 only (k=%d s=%d)", op.ksize, op.stride);
+    if (op.Cin % 16 || op.in_cs % 8 || op.Cin > op.in_cs)
+        H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: Cin=%d (stride %d) must be a multiple of 16", op.Cin, op.in_cs);
+    if ((size_t)op.H * op.W * op.in_cs * 2 >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: image of 2 GiB or more");
+    if (op.wrows % 32 || op.wrows < op.Cout)
+        H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: packed weight rows %d for Cout %d (multiple of 32 expected)", op.wrows, op.Cout);
+    if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
+        H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: out channel stride %d", op.out_cs);
+    if (op.in2 && (op.in2_cs % 4 || op.Cout > op.in2_cs)) H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: residual stride %d", op.in2_cs);
+    Conv2Args a;
+    a.in = (const char *)op.in; a.wimg = (const char *)op.w; a.bias = op.bias; a.res = (const char *)op.in2;
+    a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
+    a.Cout = op.Cout; a.out_cs = op.out_cs; a.res_cs = op.in2_cs; a.relu = op.relu; a.out_mode = op.out_mode;
+    a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0;
+    // workgroups a (th rows x 16 px) x (32*mt channels) tiling produces
+    const int gq = cdiv(op.Cout, 32);
+    auto nblk = [&](int th, int mt) { return (long)op.B * cdiv(op.W, 16) * cdiv(op.H, th) * cdiv(gq, mt); };
+    if (gq >= 4) {
+        if (nblk(16, 4) >= 256) return launch_conv2_cfg<4, 8>(a, st);
+        return launch_conv2_cfg<4, 4>(a, st);
+    }
+    if (gq >= 2) {
+        if (nblk(16, 2) >= 256) return launch_conv2_cfg<2, 8>(a, st);
+        return launch_conv2_cfg<2, 4>(a, st);
+    }
+    if (nblk(16, 1) >= 256) return launch_conv2_cfg<1, 8>(a, st);
+    return launch_conv2_cfg<1, 4>(a, st);
+}

@@ -380,8 +380,11 @@ extern "C" int h3d_gather_feat(const float *feat, const int64_t *ind, int B, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// One workgroup per image.  LDS: regressed keypoints [K][2J], boxes [K][4], joint candidates 3x[K].
-__global__ __launch_bounds__(256) void pose_assemble_kernel(
+// One workgroup per (image, joint) plus one per image for the box / score / class columns, so the
+// B*(J+1) independent searches run side by side instead of J rounds inside B workgroups.
+// LDS: this joint's regressed keypoints [K][2], boxes [K][4], joint candidates 3x[K].
+constexpr int PA_THREADS = 128;
+__global__ __launch_bounds__(PA_THREADS) void pose_assemble_kernel(
     const float *__restrict__ c_score, const int64_t *__restrict__ c_ind, const int32_t *__restrict__ c_cls,
     const float *__restrict__ c_y, const float *__restrict__ c_x, const float *__restrict__ hp_score,
     const int64_t *__restrict__ hp_ind, const float *__restrict__ hp_y, const float *__restrict__ hp_x,
@@ -389,75 +392,68 @@ __global__ __launch_bounds__(256) void pose_assemble_kernel(
     const float *__restrict__ hp_offset, int J, int HW, int K, float *__restrict__ dets)
 {
     extern __shared__ __attribute__((aligned(16))) float s_f[];
-    float *s_kp = s_f;               // [K][2J]
-    float *s_box = s_kp + K * 2 * J; // [K][4]
+    float *s_kp = s_f;               // [K][2]
+    float *s_box = s_kp + K * 2;     // [K][4]
     float *s_hx = s_box + K * 4;     // [K]
     float *s_hy = s_hx + K;
     float *s_hs = s_hy + K;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / (J + 1), j = blockIdx.x - b * (J + 1), tid = threadIdx.x;
     const int D = 5 + 2 * J + 1;
     const float thresh = 0.1f;
 
-    for (int k = tid; k < K; k += 256) {
+    for (int k = tid; k < K; k += PA_THREADS) {
         const size_t o = (size_t)b * K + k;
         const int64_t ind = c_ind[o];
         const float xs = c_x[o], ys = c_y[o];
-        for (int j = 0; j < J; ++j) {
-            s_kp[k * 2 * J + 2 * j] = hps[((size_t)b * 2 * J + 2 * j) * HW + ind] + xs;
-            s_kp[k * 2 * J + 2 * j + 1] = hps[((size_t)b * 2 * J + 2 * j + 1) * HW + ind] + ys;
-        }
         float cx, cy;
         if (reg) { cx = xs + reg[((size_t)b * 2) * HW + ind]; cy = ys + reg[((size_t)b * 2 + 1) * HW + ind]; }
         else { cx = xs + 0.5f; cy = ys + 0.5f; }
         const float w = wh[((size_t)b * 2) * HW + ind], hgt = wh[((size_t)b * 2 + 1) * HW + ind];
         const float l = cx - w / 2.f, t = cy - hgt / 2.f, r = cx + w / 2.f, bt = cy + hgt / 2.f;
-        s_box[k * 4] = l; s_box[k * 4 + 1] = t; s_box[k * 4 + 2] = r; s_box[k * 4 + 3] = bt;
-        float *d = dets + o * D;
-        d[0] = l; d[1] = t; d[2] = r; d[3] = bt;
-        d[4] = c_score[o];
-        d[5 + 2 * J] = (float)c_cls[o];
+        if (j == J) {                 // the per-image workgroup: bbox, score, class
+            float *d = dets + o * D;
+            d[0] = l; d[1] = t; d[2] = r; d[3] = bt;
+            d[4] = c_score[o];
+            d[5 + 2 * J] = (float)c_cls[o];
+        } else {
+            s_box[k * 4] = l; s_box[k * 4 + 1] = t; s_box[k * 4 + 2] = r; s_box[k * 4 + 3] = bt;
+            const float kx = hps[((size_t)b * 2 * J + 2 * j) * HW + ind] + xs;
+            const float ky = hps[((size_t)b * 2 * J + 2 * j + 1) * HW + ind] + ys;
+            s_kp[2 * k] = kx; s_kp[2 * k + 1] = ky;
+            if (!hp_score) { dets[o * D + 5 + 2 * j] = kx; dets[o * D + 5 + 2 * j + 1] = ky; }
+        }
+    }
+    if (j == J || !hp_score) return;
+    for (int c = tid; c < K; c += PA_THREADS) {
+        const size_t o = ((size_t)b * J + j) * K + c;
+        float hs = hp_score[o], hx = hp_x[o], hy = hp_y[o];
+        if (hp_offset) {
+            const int64_t ind = hp_ind[o];
+            hx = hx + hp_offset[((size_t)b * 2) * HW + ind];
+            hy = hy + hp_offset[((size_t)b * 2 + 1) * HW + ind];
+        } else { hx = hx + 0.5f; hy = hy + 0.5f; }
+        const bool m = hs > thresh;
+        s_hs[c] = m ? hs : -1.0f;
+        s_hx[c] = m ? hx : -10000.0f;
+        s_hy[c] = m ? hy : -10000.0f;
     }
     __syncthreads();
-    if (!hp_score) {
-        for (int i = tid; i < K * 2 * J; i += 256) {
-            const int k = i / (2 * J), q = i - k * 2 * J;
-            dets[((size_t)b * K + k) * D + 5 + q] = s_kp[i];
+    for (int k = tid; k < K; k += PA_THREADS) {
+        const float rx = s_kp[2 * k], ry = s_kp[2 * k + 1];
+        float best = 0.f;
+        int bi = -1;
+        for (int c = 0; c < K; ++c) {
+            const float dx = rx - s_hx[c], dy = ry - s_hy[c];
+            const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            if (bi < 0 || d < best) { best = d; bi = c; }
         }
-        return;
-    }
-    for (int j = 0; j < J; ++j) {
-        for (int c = tid; c < K; c += 256) {
-            const size_t o = ((size_t)b * J + j) * K + c;
-            float hs = hp_score[o], hx = hp_x[o], hy = hp_y[o];
-            if (hp_offset) {
-                const int64_t ind = hp_ind[o];
-                hx = hx + hp_offset[((size_t)b * 2) * HW + ind];
-                hy = hy + hp_offset[((size_t)b * 2 + 1) * HW + ind];
-            } else { hx = hx + 0.5f; hy = hy + 0.5f; }
-            const bool m = hs > thresh;
-            s_hs[c] = m ? hs : -1.0f;
-            s_hx[c] = m ? hx : -10000.0f;
-            s_hy[c] = m ? hy : -10000.0f;
-        }
-        __syncthreads();
-        for (int k = tid; k < K; k += 256) {
-            const float rx = s_kp[k * 2 * J + 2 * j], ry = s_kp[k * 2 * J + 2 * j + 1];
-            float best = 0.f;
-            int bi = -1;
-            for (int c = 0; c < K; ++c) {
-                const float dx = rx - s_hx[c], dy = ry - s_hy[c];
-                const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-                if (bi < 0 || d < best) { best = d; bi = c; }
-            }
-            const float sx = s_hx[bi], sy = s_hy[bi], ss = s_hs[bi];
-            const float l = s_box[k * 4], t = s_box[k * 4 + 1], r = s_box[k * 4 + 2], bt = s_box[k * 4 + 3];
-            const bool bad = (sx < l) || (sx > r) || (sy < t) || (sy > bt) || (ss < thresh) ||
-                             (best > __fmul_rn(fmaxf(bt - t, r - l), 0.3f));
-            float *d = dets + ((size_t)b * K + k) * D + 5 + 2 * j;
-            d[0] = bad ? rx : sx;
-            d[1] = bad ? ry : sy;
-        }
-        __syncthreads();
+        const float sx = s_hx[bi], sy = s_hy[bi], ss = s_hs[bi];
+        const float l = s_box[k * 4], t = s_box[k * 4 + 1], r = s_box[k * 4 + 2], bt = s_box[k * 4 + 3];
+        const bool bad = (sx < l) || (sx > r) || (sy < t) || (sy > bt) || (ss < thresh) ||
+                         (best > __fmul_rn(fmaxf(bt - t, r - l), 0.3f));
+        float *d = dets + ((size_t)b * K + k) * D + 5 + 2 * j;
+        d[0] = bad ? rx : sx;
+        d[1] = bad ? ry : sy;
     }
 }
 
@@ -470,9 +466,9 @@ extern "C" int h3d_multi_pose_assemble(const float *c_score, const int64_t *c_in
         H3D_FAIL(H3D_ERR_ARG, "multi_pose_assemble: null pointer");
     if (hp_score && (!hp_ind || !hp_y || !hp_x)) H3D_FAIL(H3D_ERR_ARG, "multi_pose_assemble: partial joint top-k");
     if (B <= 0 || J <= 0 || H <= 0 || W <= 0 || K <= 0) H3D_FAIL(H3D_ERR_SHAPE, "multi_pose_assemble: bad shape");
-    const size_t lds = ((size_t)K * 2 * J + (size_t)K * 4 + (size_t)K * 3) * sizeof(float);
-    if (lds > 64 * 1024) H3D_FAIL(H3D_ERR_UNSUPPORTED, "multi_pose_assemble: K*J too large (%d x %d)", K, J);
-    hipLaunchKernelGGL(pose_assemble_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, c_score, c_ind, c_cls, c_y, c_x,
+    const size_t lds = (size_t)K * 9 * sizeof(float);
+    if (lds > 64 * 1024) H3D_FAIL(H3D_ERR_UNSUPPORTED, "multi_pose_assemble: K too large (%d)", K);
+    hipLaunchKernelGGL(pose_assemble_kernel, dim3(B * (J + 1)), dim3(PA_THREADS), lds, (hipStream_t)stream, c_score, c_ind, c_cls, c_y, c_x,
                        hp_score, hp_ind, hp_y, hp_x, wh, hps, reg, hp_offset, J, H * W, K, dets);
     H3D_CHECK_LAUNCH("pose_assemble_kernel");
     return H3D_OK;

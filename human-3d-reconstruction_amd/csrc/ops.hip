@@ -34,6 +34,7 @@ int h3d_launch_dcn(const h3d_op &op, hipStream_t st);
 int h3d_launch_heads(const h3d_op &op, hipStream_t st);
 int h3d_launch_dcn2(const h3d_op &op, hipStream_t st);
 int h3d_launch_dcn3(const h3d_op &op, hipStream_t st);
+int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st);
 
 static int run_one(const h3d_op &op, int i, hipStream_t st);
 
@@ -91,6 +92,7 @@ static int run_one(const h3d_op &op, int i, hipStream_t st)
     switch (op.kind) {
     case H3D_OP_STEM: rc = h3d_launch_stem(op, st); break;
     case H3D_OP_CONV: rc = h3d_launch_conv(op, st); break;
+    case H3D_OP_CONV_STREAM: rc = h3d_launch_conv_stream(op, st); break;
     case H3D_OP_DCN: rc = h3d_launch_dcn2(op, st); break;
     case H3D_OP_DCN_V1: rc = h3d_launch_dcn(op, st); break;
     case H3D_OP_DCN_FUSED: rc = h3d_launch_dcn3(op, st); break;

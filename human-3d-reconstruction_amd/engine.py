@@ -91,6 +91,28 @@ class PackedWeights:
                            bp.contiguous().to(self.device), cout, ci, kh, rows)
         return self.t[key]
 
+    def conv_stream(self, wkey, bkey=None, bn=None):
+        """3x3 filter bank as the stage-major LDS image of csrc/conv2.hip: [Cin/16][G][32 rows][19 slots][8]
+        bf16, slot 2*tap+h = input channels 16*stage + 8h..8h+7 of tap `tap`, slot 18 zero; G = Cout/32
+        row groups padded to a multiple of 4.  -> (image, bias fp32 [32 G], Cout, Cin, rows = 32 G)."""
+        key = ("conv_stream", wkey, bn)
+        if key not in self.t:
+            w, b = self._fold(self.sd[wkey], self.sd[bkey] if bkey else None, bn)
+            co, ci, kh, kw = w.shape
+            assert kh == 3 and kw == 3 and ci % 16 == 0
+            G = ((co + 127) // 128) * 4
+            wp = torch.zeros(G * 32, 9, ci)
+            wp[:co] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
+            img = torch.zeros(ci // 16, G, 32, 19, 8)
+            # [rows][tap][stage][h][8] -> [stage][G][32][tap][h][8]
+            v = wp.reshape(G, 32, 9, ci // 16, 2, 8).permute(3, 0, 1, 2, 4, 5)
+            img[:, :, :, :18] = v.reshape(ci // 16, G, 32, 18, 8)
+            bp = torch.zeros(G * 32)
+            bp[:co] = b
+            self.t[key] = (img.to(torch.bfloat16).contiguous().to(self.device), bp.contiguous().to(self.device),
+                           co, ci, G * 32)
+        return self.t[key]
+
     def stem(self):
         key = ("stem",)
         if key not in self.t:
@@ -164,9 +186,10 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True):
+    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True):
         self.fuse_heads = fuse_heads
         self.fuse_offsets = fuse_offsets
+        self.stream_convs = stream_convs
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -196,6 +219,10 @@ class Plan:
 
     def conv(self, x, wkey, out=None, bkey=None, bn=None, stride=1, relu=True, res=None, out_mode=_lib.OUT_NHWC,
              pad_cout_to=None, out_tensor=None):
+        wshape = self.pw.sd[wkey].shape
+        if (self.stream_convs and self.pw.dtype == "bf16" and stride == 1 and wshape[2] == 3 and wshape[1] % 16 == 0
+                and out_mode == _lib.OUT_NHWC and pad_cout_to is None):
+            return self._conv_stream(x, wkey, out, bkey, bn, relu, res)
         wp, bp, cout, cin, k, rows = self.pw.conv(wkey, bkey, bn, pad_cout_to)
         assert cin == x.C, (wkey, cin, x.C)
         Ho = (x.H + 2 * (k // 2) - k) // stride + 1
@@ -214,6 +241,19 @@ class Plan:
                  bias=bp.data_ptr(), out=optr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs,
                  in2_cs=res.cs if res is not None else 0, Ho=Ho, Wo=Wo, Cout=cout, out_cs=ocs, ksize=k,
                  stride=stride, relu=int(relu), out_mode=out_mode, wrows=rows)
+        return out
+
+    def _conv_stream(self, x, wkey, out, bkey, bn, relu, res):
+        """3x3 s1 conv through the LDS-DMA kernel (csrc/conv2.hip)."""
+        wimg, bp, cout, cin, rows = self.pw.conv_stream(wkey, bkey, bn)
+        assert cin == x.C, (wkey, cin, x.C)
+        if out is None:
+            out = self._alloc(x.H, x.W, cout)
+        assert (out.H, out.W, out.C) == (x.H, x.W, cout), (wkey, out.H, out.W, out.C)
+        self._op(_lib.OP_CONV_STREAM, in_=x.ptr, in2=res.ptr if res is not None else None, w=wimg.data_ptr(),
+                 bias=bp.data_ptr(), out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs,
+                 in2_cs=res.cs if res is not None else 0, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
+                 stride=1, relu=int(relu), out_mode=_lib.OUT_NHWC, wrows=rows)
         return out
 
     def dcn(self, x, om, wkey, bkey, bn, out=None):
@@ -403,13 +443,15 @@ class DLAEngine:
         self.plans = {}
         self.fuse_heads = True          # False: one conv3x3 + conv1x1 launch pair per head (debug/ablation)
         self.fuse_offsets = True        # False: conv_offset_mask as its own launch + dcn2_kernel reading NHWC offsets
+        self.stream_convs = True        # False: 3x3 s1 convs through the register-staged kernel (csrc/conv.hip)
         self.streams = 1                # >1: run that many sub-batches concurrently on their own HIP streams
 
     def plan(self, B, H, W):
         key = (B, H, W)
         if key not in self.plans:
             with torch.cuda.device(self.device):
-                self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets)
+                self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
+                                       stream_convs=self.stream_convs)
         return self.plans[key]
 
     def forward(self, images):
@@ -438,7 +480,8 @@ class DLAEngine:
         key = ("split", B, H, W)
         with torch.cuda.device(self.device):
             if key not in self.plans:
-                plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets)
+                plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
+                              stream_convs=self.stream_convs)
                          for _ in range(n)]
                 full = {h: torch.empty((B,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
                         for h, o in plans[0].outputs.items()}

@@ -76,6 +76,9 @@ enum {
     H3D_OP_COPY = 6,    /* strided NHWC copy (y[i] = x[i].clone(), model.py:480-482)                   */
     H3D_OP_DCN_FUSED = 9, /* DeformConv with conv_offset_mask fused in (csrc/dcn3.hip): in2 = offset/mask filters
                              [32 permuted rows][9][Cin] (same element type as w), bias = [wrows main | 32 offset] */
+    H3D_OP_CONV_STREAM = 10, /* 3x3 s1 p1 conv (bf16) fed by LDS-DMA (csrc/conv2.hip): w = stage-major filter image
+                                [Cin/16][wrows/32][32 rows][19 slots of 8 elements]: slot 2*tap+h = input channels
+                                16*stage + 8h..8h+7 of tap `tap`, slot 18 zero; in2 = optional residual    */
     H3D_OP_DCN_V1 = 8,  /* first-generation DCN kernel (global gather, bf16 weights): kept as an A/B reference */
     H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
                            (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */
