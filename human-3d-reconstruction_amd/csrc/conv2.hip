@@ -27,6 +27,7 @@ struct Conv2Args {
     int B, H, W, Cin, in_cs;
     int Cout, out_cs, res_cs, relu, out_mode;
     int G, tiles_x, tiles_y;
+    int dbg;   // ABLATE builds only (op.reserved >> 16): 1 = no DMA after stage 0, 2 = no fragment reads / MFMA
 };
 
 template <int MT, int WAVES>
@@ -70,7 +71,7 @@ __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, cons
     }
 }
 
-template <int MT, int WAVES, bool FASTEPI>
+template <int MT, int WAVES, int EPI>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h)
 __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 {
     using C = Conv2Cfg<MT, WAVES>;
@@ -120,9 +121,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     for (int s = 0; s < nst; ++s) {
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): my pieces of stage s have landed
         __syncthreads();                          // ... everyone's have; slot (s+1)&1 is no longer being read
-        if (s + 1 < nst)
+        if (s + 1 < nst && !(H3D_DBG(a) & 1))
             conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + ((s + 1) & 1) * C::SLOT, hoff, woff, wv, s + 1, ((s + 1) * a.G + g0) * C::WGRP);
         const char *sl = smem + (s & 1) * C::SLOT;
+        if (H3D_DBG(a) & 2) continue;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
@@ -138,7 +140,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     EpiArgs e;
     e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
-    tile_epilogue<bf16_t, MT, 1, FASTEPI>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    if constexpr (EPI == 2) {
+        static_assert(WAVES * 32 * (64 * MT + 16) <= C::LDS, "epilogue tile");
+        __syncthreads();                          // nobody reads the ring any more
+        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * 32 * (64 * MT + 16));
+    } else {
+        tile_epilogue<bf16_t, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    }
 }
 
 template <int MT, int WAVES>
@@ -151,10 +159,13 @@ static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
     a.tiles_y = cdiv(a.H, C::TH);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     if (h3d_note_kernel("conv2_kernel<%d, %d>", MT, WAVES)) return H3D_OK;
-    if (a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, true>), grid, dim3(C::THREADS), 0, st, a);
+    const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
+    if (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4))
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2>), grid, dim3(C::THREADS), 0, st, a);
+    else if (lean)
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, false>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("conv2_kernel");
     return H3D_OK;
 }
@@ -178,10 +189,24 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
     a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
     a.Cout = op.Cout; a.out_cs = op.out_cs; a.res_cs = op.in2_cs; a.relu = op.relu; a.out_mode = op.out_mode;
     a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0;
+    a.dbg = op.reserved >> 16;
     // workgroups a (th rows x 16 px) x (32*mt channels) tiling produces
     const int gq = cdiv(op.Cout, 32);
     auto nblk = [&](int th, int mt) { return (long)op.B * cdiv(op.W, 16) * cdiv(op.H, th) * cdiv(gq, mt); };
+    if (op.reserved & 0xffff) {   // tuning override (profiling): reserved = MT << 8 | WAVES
+        switch (op.reserved & 0xffff) {
+        case 0x410: return launch_conv2_cfg<4, 16>(a, st);
+        case 0x408: return launch_conv2_cfg<4, 8>(a, st);
+        case 0x404: return launch_conv2_cfg<4, 4>(a, st);
+        case 0x208: return launch_conv2_cfg<2, 8>(a, st);
+        case 0x204: return launch_conv2_cfg<2, 4>(a, st);
+        case 0x108: return launch_conv2_cfg<1, 8>(a, st);
+        case 0x104: return launch_conv2_cfg<1, 4>(a, st);
+        default: H3D_FAIL(H3D_ERR_ARG, "conv_stream: unknown tuning override %#x", op.reserved);
+        }
+    }
     if (gq >= 4) {
+        if (op.H % 32 == 0 && nblk(32, 4) >= 256) return launch_conv2_cfg<4, 16>(a, st);   // 16 waves: 32 x 16 px share one weight stream
         if (nblk(16, 4) >= 256) return launch_conv2_cfg<4, 8>(a, st);
         return launch_conv2_cfg<4, 4>(a, st);
     }

@@ -42,10 +42,12 @@ struct Dcn3Cfg {
     static constexpr int THREADS = 512;
     static constexpr int VPP = CK * SS / 16;
     static constexpr int LDS_H = HH * RBH;
-    static constexpr int LDS = LDS_H + BN * WB;
+    static constexpr int LDS_MAIN = LDS_H + BN * WB;
+    static constexpr int LDS_EPI = 8 * 32 * (64 * MT + 16);   // epilogue.h tile_epilogue_lds regions
+    static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 };
 
-template <typename T, int MT, int CK, int MARGIN, bool FASTEPI = false>
+template <typename T, int MT, int CK, int MARGIN, int EPI = 0>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
 __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
 {
     using C = Dcn3Cfg<T, MT, CK, MARGIN>;
@@ -300,7 +302,12 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     EpiArgs e;
     e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
-    tile_epilogue<T, MT, 1, FASTEPI>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    if constexpr (EPI == 2) {
+        __syncthreads();                          // the apron and the filters are no longer read
+        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * 32 * (64 * MT + 16));
+    } else {
+        tile_epilogue<T, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    }
 }
 
 template <typename T, int MT, int CK, int MARGIN>
@@ -313,10 +320,18 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN)) return H3D_OK;
-    if (a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0)
-        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, true>), grid, dim3(C::THREADS), 0, st, a);
+    const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
+    if constexpr (sizeof(T) == 2 && MT >= 2) {
+        if (lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) {
+            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2>), grid, dim3(C::THREADS), 0, st, a);
+            H3D_CHECK_LAUNCH("dcn3_kernel");
+            return H3D_OK;
+        }
+    }
+    if (lean)
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, false>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("dcn3_kernel");
     return H3D_OK;
 }

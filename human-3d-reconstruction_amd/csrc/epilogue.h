@@ -101,3 +101,60 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[MT][NT], const EpiAr
         }
     }
 }
+
+// LDS-transposed epilogue (bf16 NHWC outputs, Cout % 8 == 0, out_cs % 8 == 0, 16-byte aligned bases).
+// The MFMA C layout gives each lane 4 consecutive channels of one pixel, so a direct store writes 8-byte
+// pieces 2*out_cs bytes apart: 16 partial writes per 128-byte line.  Here every wave first drops its
+// 32 pixels x 32*MT channels (bias, residual, ReLU applied in fp32, then rounded) into its own LDS region
+// [32 px][64*MT + 16 B], then streams them out 16 bytes per lane with the lanes of a pixel adjacent:
+// whole lines per store instruction.  No workgroup barrier: a wave only touches its own region
+// (`lw`, 32 * (64*MT + 16) bytes, which must no longer be read by anyone else).
+template <int MT>
+__device__ __forceinline__ void tile_epilogue_lds(f32x16 (&acc)[MT][1], const EpiArgs &a, int b, int oy0, int ox0,
+                                                  int cout0, int wv, int l, char *lw)
+{
+    constexpr int ROWB = 64 * MT + 16;
+    const int r = l & 31, h = l >> 5;
+    {
+        const int oy = oy0 + 2 * wv + (r >> 4), ox = ox0 + (r & 15);
+        const bool live = oy < a.Ho && ox < a.Wo;
+        const size_t opix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+        const bf16_t *rp = reinterpret_cast<const bf16_t *>(a.res) + opix * a.res_cs + cout0 + 4 * h;
+        const float *bp = a.bias + cout0 + 4 * h;
+        const bool has_res = a.res != nullptr && live;
+        const float lo = a.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = m * 32 + 8 * g;
+                const bool cok = cout0 + co + 4 * h < a.Cout;
+                float4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (cok) bv = *reinterpret_cast<const float4 *>(bp + co);
+                float v0 = acc[m][0][4 * g + 0] + bv.x, v1 = acc[m][0][4 * g + 1] + bv.y;
+                float v2 = acc[m][0][4 * g + 2] + bv.z, v3 = acc[m][0][4 * g + 3] + bv.w;
+                if (has_res && cok) {
+                    float rv[4];
+                    load4<bf16_t>(rp + co, rv);
+                    v0 += rv[0]; v1 += rv[1]; v2 += rv[2]; v3 += rv[3];
+                }
+                const u32x2 pk = {pack_bf16x2(fmaxf(v0, lo), fmaxf(v1, lo)), pack_bf16x2(fmaxf(v2, lo), fmaxf(v3, lo))};
+                *reinterpret_cast<u32x2 *>(lw + r * ROWB + (co + 4 * h) * 2) = pk;
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): my wave's LDS writes are done
+    __builtin_amdgcn_wave_barrier();
+    constexpr int SPP = 4 * MT;                  // 16-byte slots per pixel
+#pragma unroll
+    for (int it = 0; it < SPP / 2; ++it) {
+        const int q = it * 64 + l;
+        const int p = q / SPP, sl = q - p * SPP;
+        const int oy = oy0 + 2 * wv + (p >> 4), ox = ox0 + (p & 15);
+        if (oy < a.Ho && ox < a.Wo && cout0 + sl * 8 < a.Cout) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(lw + p * ROWB + sl * 16);
+            const size_t opix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
+            *reinterpret_cast<u32x4 *>(a.out + (opix * a.out_cs + cout0 + sl * 8) * 2) = v;
+        }
+    }
+}
