@@ -445,6 +445,18 @@ __device__ __forceinline__ u32x4 pack16(const float *o)
     return v;
 }
 
+// 8 floats -> 8 fp16 (clamped to the fp16 range): the input format of csrc/dcn4.hip
+__device__ __forceinline__ u32x4 pack16_f16(const float *o)
+{
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)__builtin_amdgcn_fmed3f(o[2 * i], -65504.f, 65504.f),
+                                               (_Float16)__builtin_amdgcn_fmed3f(o[2 * i + 1], -65504.f, 65504.f)});
+    return v;
+}
+
 // 2x2/2 max pool (floor semantics of nn.MaxPool2d(2, stride=2), model.py:201)
 template <typename T>
 __global__ void maxpool_kernel(const T *__restrict__ in, T *__restrict__ out, int B, int H, int W, int C,
@@ -479,7 +491,7 @@ __global__ void maxpool_kernel(const T *__restrict__ in, T *__restrict__ out, in
 // (IDAUp.forward: layers[i] = up(proj(layers[i])); node(layers[i] + layers[i-1]), model.py:384-390).
 // out[oy][ox][c] = skip + sum over (i,j) with (oy + p - i) % f == 0: w[c][i][j] * in[(oy+p-i)/f][(ox+p-j)/f][c]
 // -> exactly two i and two j per output pixel.  w: fp32 [k*k][C] (tap-major so channel vectors load).
-template <typename T>
+template <typename T, bool F16OUT = false>   // F16OUT: bf16 inputs, fp16 output (H3D_OUT_NHWC_F16)
 __global__ void upadd_kernel(const T *__restrict__ in, const T *__restrict__ skip, const float *__restrict__ w,
                              T *__restrict__ out, int B, int H, int W, int C, int in_cs, int skip_cs, int Ho,
                              int Wo, int out_cs, int f)
@@ -516,7 +528,8 @@ __global__ void upadd_kernel(const T *__restrict__ in, const T *__restrict__ ski
         unpack16<T>(*reinterpret_cast<const u32x4 *>(skip + pix * skip_cs + v * N), x);
 #pragma unroll
         for (int n = 0; n < N; ++n) acc[n] += x[n];
-        *reinterpret_cast<u32x4 *>(out + pix * out_cs + v * N) = pack16<T>(acc);
+        if constexpr (F16OUT) *reinterpret_cast<u32x4 *>(out + pix * out_cs + v * N) = pack16_f16(acc);
+        else *reinterpret_cast<u32x4 *>(out + pix * out_cs + v * N) = pack16<T>(acc);
     }
 }
 
@@ -546,8 +559,10 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
                  op.in_cs, op.out_cs, n);
     const size_t total = (size_t)op.B * op.Ho * op.Wo * (op.Cin / n);
     dim3 grid(ew_grid(total)), blk(256);
-    if (h3d_note_kernel("%s<%s>", op.kind == H3D_OP_MAXPOOL ? "maxpool_kernel" : op.kind == H3D_OP_UPADD ? "upadd_kernel" : "copy_kernel",
-                        es == 2 ? "unsigned short" : "float"))
+    const bool f16out = op.kind == H3D_OP_UPADD && op.out_mode == H3D_OUT_NHWC_F16;
+    if (f16out && es != 2) H3D_FAIL(H3D_ERR_DTYPE, "upadd: fp16 output needs a bf16 plan");
+    if (h3d_note_kernel("%s<%s%s>", op.kind == H3D_OP_MAXPOOL ? "maxpool_kernel" : op.kind == H3D_OP_UPADD ? "upadd_kernel" : "copy_kernel",
+                        es == 2 ? "unsigned short" : "float", op.kind == H3D_OP_UPADD ? (f16out ? ", true" : ", false") : ""))
         return H3D_OK;
     if (op.kind == H3D_OP_MAXPOOL) {
         if (op.Ho != op.H / 2 || op.Wo != op.W / 2) H3D_FAIL(H3D_ERR_SHAPE, "maxpool: output must be floor(H/2) x floor(W/2)");
@@ -563,7 +578,11 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
         if (!op.in2 || !op.w) H3D_FAIL(H3D_ERR_ARG, "upadd: null pointer");
         if (op.ksize != 2 * f || op.Ho != op.H * f || op.Wo != op.W * f || op.in2_cs % n)
             H3D_FAIL(H3D_ERR_SHAPE, "upadd: expects k=2f, out = f*in (k=%d f=%d)", op.ksize, f);
-        if (es == 2)
+        if (f16out)
+            hipLaunchKernelGGL((upadd_kernel<bf16_t, true>), grid, blk, 0, st, (const bf16_t *)op.in, (const bf16_t *)op.in2,
+                               (const float *)op.w, (bf16_t *)op.out, op.B, op.H, op.W, op.Cin, op.in_cs, op.in2_cs, op.Ho,
+                               op.Wo, op.out_cs, f);
+        else if (es == 2)
             hipLaunchKernelGGL(upadd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t *)op.in, (const bf16_t *)op.in2,
                                (const float *)op.w, (bf16_t *)op.out, op.B, op.H, op.W, op.Cin, op.in_cs, op.in2_cs, op.Ho,
                                op.Wo, op.out_cs, f);

@@ -52,7 +52,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 // type does not exist in the host pass, and a lambda capturing one silently drops the kernel's stub)
 template <int MT, int WAVES>
 __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, const char *wimg, int w_bytes, char *base,
-                                            const int *hoff, int woff, int wv, int s, int wsrc)
+                                            const int *hoff, int woff, int wv, int s, int wsrc, int dbg = 0)
 {
     using C = Conv2Cfg<MT, WAVES>;
     // descriptors are rebuilt from wave-uniform scalars at every call (4 SGPRs each, no memory traffic)
@@ -61,12 +61,12 @@ __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, cons
 #pragma unroll
     for (int j = 0; j < C::HP; ++j) {
         const int p = wv + j * WAVES;
-        if (p < C::ROWS) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (lds_void *)(base + p * 1024), 16, hoff[j], s * 32, 0, 0);
+        if (p < C::ROWS && !(dbg & 8)) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (lds_void *)(base + p * 1024), 16, hoff[j], s * 32, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < C::WP; ++j) {
         const int p = wv + j * WAVES;
-        if (p < C::WPIECES)
+        if (p < C::WPIECES && !(dbg & 16))
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void *)(base + C::HALO + p * 1024), 16, woff, wsrc + p * 1024, 0, 0);
     }
 }
@@ -117,12 +117,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
 
-    conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem, hoff, woff, wv, 0, g0 * C::WGRP);
+    conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem, hoff, woff, wv, 0, g0 * C::WGRP, H3D_DBG(a));
     for (int s = 0; s < nst; ++s) {
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): my pieces of stage s have landed
         __syncthreads();                          // ... everyone's have; slot (s+1)&1 is no longer being read
         if (s + 1 < nst && !(H3D_DBG(a) & 1))
-            conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + ((s + 1) & 1) * C::SLOT, hoff, woff, wv, s + 1, ((s + 1) * a.G + g0) * C::WGRP);
+            conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + ((s + 1) & 1) * C::SLOT, hoff, woff, wv, s + 1, ((s + 1) * a.G + g0) * C::WGRP, H3D_DBG(a));
         const char *sl = smem + (s & 1) * C::SLOT;
         if (H3D_DBG(a) & 2) continue;
 #pragma unroll

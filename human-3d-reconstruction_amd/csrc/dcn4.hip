@@ -1,0 +1,307 @@
+// DeformConv with fused offsets, generation 4: 64-channel fp16 input, every operand by LDS-DMA.
+// (reference model.py:346-362 DeformConv -> dcn_v2.py:118-128 DCN.forward; same math as csrc/dcn3.hip,
+//  which keeps the other channel counts, bf16 inputs and the fp32 parity mode.)
+//
+// The five IDAUp `node` layers at the finest level (64 -> 64 channels at H/4 x W/4) are the most
+// expensive launches of the network and their input is produced by the up-sample + add kernel for
+// them alone, so that kernel writes fp16 (H3D_OUT_NHWC_F16) and nothing has to be converted here:
+//   apron   the (16+2+2*MARGIN)^2 pixel neighbourhood of the 16x16 tile with ALL 64 channels is DMA'd
+//           once: [22 rows][4 KiB], pixel stride 144 B (8 data slots + 1 pad slot of 16 B), so both the
+//           plain-conv fragments of the offset convolution and the 4-corner gathers are conflict free
+//           (odd multiple of 16 B between pixels, 0 mod 256 B between rows).  Pixels outside the image
+//           carry an out-of-range buffer offset and arrive as zeros.
+//   filters stream through a two-slot ring in stages of 16 input channels: 4 stages of the 27 (32 rows)
+//           offset/mask filters, then 4 stages of the 32*MT main filters; the host packs both stage-major
+//           in LDS image order (19 slots per row: 2 per tap + 1 pad), so each stage is a linear copy.
+// No staging registers, no ds_write, no address arithmetic inside the loops; one barrier per stage.
+// Phases as in dcn3: A (offset conv) -> geometry (split across half-waves) -> B (gather + fp16 blend +
+// MFMA) -> rare pass 2 for samples whose corners left the apron (global gather).
+#include "common.h"
+#include "epilogue.h"
+#include "dcn_traits.h"
+
+struct Dcn4Args {
+    const char *in;     // fp16 NHWC
+    const char *wimg;   // main filters  [4][G][32][19][8] fp16
+    const char *woff;   // offset filters [4][32][19][8] fp16, rows permuted (engine.offset_conv)
+    const float *bias;  // [wrows] main bias followed by [32] permuted offset bias
+    char *out;          // bf16 NHWC
+    int B, H, W, in_cs;
+    int Cout, out_cs, relu, out_mode, wrows;
+    int G, tiles_x, tiles_y;
+};
+
+template <int MT>
+struct Dcn4Cfg {
+    static constexpr int MARGIN = 2;
+    static constexpr int HH = 16 + 2 + 2 * MARGIN;     // 22
+    static constexpr int PXB = 144, ROWB = 4096;
+    static constexpr int APRON = HH * ROWB;            // 90112
+    static constexpr int WROW = 19 * 16, WGRP = 32 * WROW;
+    static constexpr int WPIECES = (MT * WGRP + 1023) / 1024;
+    static constexpr int WSLOT = WPIECES * 1024;
+    static constexpr int OPIECES = (WGRP + 1023) / 1024;    // offset-filter stage: 10 pieces
+    static constexpr int LDS = APRON + 2 * WSLOT;
+    static constexpr int NSTAGE = 4;                   // 64 input channels / 16
+};
+
+typedef __attribute__((address_space(3))) void lds_void4;
+
+// one filter stage -> ring slot `dst` (linear copy of `pieces` KiB starting at byte `src` of buffer `base`)
+template <int PIECES>
+__device__ __forceinline__ void dcn4_issue_w(const char *base, int bytes, char *dst, int src, int woff, int wv)
+{
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < (PIECES + 7) / 8; ++j) {
+        const int p = wv + 8 * j;
+        if (p < PIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void4 *)(dst + p * 1024), 16, woff, src + p * 1024, 0, 0);
+    }
+}
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
+{
+    using C = Dcn4Cfg<MT>;
+    using X = SE<bf16_t>;
+    __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
+    char *s_ring = smem + C::APRON;
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63, r = l & 31, h = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    const int hy0 = oy0 - 1 - C::MARGIN, hx0 = ox0 - 1 - C::MARGIN;
+    const int g0 = blockIdx.y * MT, cout0 = g0 * 32;
+    const int py = wv * 2 + (r >> 4), px = r & 15;
+    const int oy = oy0 + py, ox = ox0 + px;
+    const bool live = (oy < a.H && ox < a.W);
+    const size_t img_bytes = (size_t)a.H * a.W * a.in_cs * 2;
+    const char *img = a.in + (size_t)b * img_bytes;
+    const int woffl = l * 16;
+    const int off_bytes = C::NSTAGE * C::WGRP, main_bytes = C::NSTAGE * a.G * C::WGRP;
+
+    // ---- apron: 88 pieces (22 rows x 4), wave w takes pieces w, w+8, ...: piece & 3 == w & 3, so a
+    //      lane's pixel column and channel slot are fixed and only the row changes --------------------
+    {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)img_bytes, 0x00020000);
+        const int slot = (wv & 3) * 64 + l;
+        const int ix = slot / 9, sub = slot - 9 * ix;
+        const int gx = hx0 + ix;
+        const bool okx = ix < C::HH && sub < 8 && gx >= 0 && gx < a.W;
+        const int xoff = (gx * a.in_cs + sub * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int q = wv + 8 * j;                 // < 88
+            const int row = q >> 2;
+            const int gy = hy0 + row;
+            const int voff = (okx && gy >= 0 && gy < a.H) ? gy * a.W * a.in_cs * 2 + xoff : 0x7ffffff0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void4 *)(smem + q * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+    dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring, 0, woffl, wv);
+
+    // ================= phase A: offsets/mask = conv3x3(x; 27 filters), 4 stages of 16 channels =========
+    f32x16 aoffs;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aoffs[i] = 0.f;
+    const int bconv = (C::MARGIN + py) * C::ROWB + (C::MARGIN + px) * C::PXB + h * 16;
+    const int aoff = r * C::WROW + h * 16;
+    for (int s = 0; s < C::NSTAGE; ++s) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
+        __syncthreads();
+        if (s + 1 < C::NSTAGE)
+            dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring + ((s + 1) & 1) * C::WSLOT, (s + 1) * C::WGRP, woffl, wv);
+        else
+            dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + ((s + 1) & 1) * C::WSLOT, g0 * C::WGRP, woffl, wv);
+        const char *sw = s_ring + (s & 1) * C::WSLOT;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const typename X::frag fa = X::lds(sw + aoff + tap * 32);
+            const typename X::frag fb = X::lds(smem + bconv + dy * C::ROWB + dx * C::PXB + s * 32);
+            X::mma(aoffs, fa, fb);
+        }
+    }
+    {
+        const float *bo = a.bias + a.wrows;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
+    }
+
+    // ================= geometry (branch free): my taps (h=0: 0..4, h=1: 5..8), cross-half exchange ====
+    int boff[9];
+    typename X::geo geo[9];
+    bool slow = false;
+    {
+        int my_off[5];
+        typename X::geo my_geo[5];
+        const int tb = h ? 5 : 0;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int tap = tb + u;
+            const int ti = tap / 3, tj = tap - ti * 3;
+            const float h_im = (float)(oy - 1 + ti) + aoffs[3 * u];
+            const float w_im = (float)(ox - 1 + tj) + aoffs[3 * u + 1];
+            const bool inside = live && tap < 9 && (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
+            const float fh = floorf(h_im), fw = floorf(w_im);
+            const int ry = (int)fh - hy0, rx = (int)fw - hx0;
+            const bool inap = (unsigned)ry < (unsigned)(C::HH - 1) && (unsigned)rx < (unsigned)(C::HH - 1);
+            const bool use = inside && inap;
+            slow |= inside && !inap;
+            const float lh = h_im - fh, lw = w_im - fw;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+            typename X::geo g = X::make_geo(w4, dcn2_sigmoid(aoffs[3 * u + 2]));
+            g.w01 = use ? g.w01 : 0u;
+            g.w23 = use ? g.w23 : 0u;
+            my_off[u] = use ? ry * C::ROWB + rx * C::PXB : 0;
+            my_geo[u] = g;
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int o_off = __shfl_xor(my_off[u], 32);
+            const typename X::geo o_geo = X::shfl_xor32(my_geo[u]);
+            boff[u] = (h == 0 ? my_off[u] : o_off) + h * 16;
+            geo[u].w01 = (h == 0) ? my_geo[u].w01 : o_geo.w01;
+            geo[u].w23 = (h == 0) ? my_geo[u].w23 : o_geo.w23;
+            if (u < 4) {
+                boff[5 + u] = (h == 1 ? my_off[u] : o_off) + h * 16;
+                geo[5 + u].w01 = (h == 1) ? my_geo[u].w01 : o_geo.w01;
+                geo[5 + u].w23 = (h == 1) ? my_geo[u].w23 : o_geo.w23;
+            }
+        }
+    }
+
+    // ================= phase B: deformable contraction (branch-free, apron samples) ==================
+    f32x16 acc[MT][1];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
+    for (int s = 0; s < C::NSTAGE; ++s) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (s + 1 < C::NSTAGE)
+            dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + ((s + 1) & 1) * C::WSLOT, ((s + 1) * a.G + g0) * C::WGRP, woffl, wv);
+        const char *sw = s_ring + (s & 1) * C::WSLOT;           // global stage 4 + s lives in slot (4 + s) & 1
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const char *p00 = smem + boff[tap] + s * 32;
+            typename X::frag v[4];
+            v[0] = X::lds(p00);
+            v[1] = X::lds(p00 + C::PXB);
+            v[2] = X::lds(p00 + C::ROWB);
+            v[3] = X::lds(p00 + C::ROWB + C::PXB);
+            const typename X::frag fb = X::blend(v, geo[tap]);
+            typename X::frag fa[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) fa[m] = X::lds(sw + aoff + m * C::WGRP + tap * 32);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb);
+        }
+    }
+
+    // ================= pass 2 (rare): samples whose corners left the apron ===========================
+    if (__syncthreads_or(slow ? 1 : 0)) {
+        for (int s = 0; s < C::NSTAGE; ++s) {
+            __syncthreads();
+            dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring, (s * a.G + g0) * C::WGRP, woffl, wv);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ti = tap / 3, tj = tap - ti * 3;
+                const int src = (tap < 5) ? r : r + 32, u = (tap < 5) ? tap : tap - 5;
+                const float d_h = __shfl(aoffs[3 * u], src), d_w = __shfl(aoffs[3 * u + 1], src),
+                            d_m = __shfl(aoffs[3 * u + 2], src);
+                typename X::frag fb = X::zero();
+                bool any = false;
+                const float h_im = (float)(oy - 1 + ti) + d_h;
+                const float w_im = (float)(ox - 1 + tj) + d_w;
+                if (live && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+                    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                    const int ry = hl - hy0, rx = wl - hx0;
+                    if (!((unsigned)ry < (unsigned)(C::HH - 1) && (unsigned)rx < (unsigned)(C::HH - 1))) {
+                        any = true;
+                        const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                        const typename X::geo g = X::make_geo(w4, dcn2_sigmoid(d_m));
+                        const bool okh0 = hl >= 0, okh1 = hl + 1 <= a.H - 1, okw0 = wl >= 0, okw1 = wl + 1 <= a.W - 1;
+                        const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
+                        const int pix[4] = {hl * a.W + wl, hl * a.W + wl + 1, (hl + 1) * a.W + wl, (hl + 1) * a.W + wl + 1};
+                        typename X::frag v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            v[k] = ok[k] ? X::lds(img + ((size_t)pix[k] * a.in_cs + s * 16 + 8 * h) * 2) : X::zero();   // fp16 input: plain 16-byte load
+                        fb = X::blend(v, g);
+                    }
+                }
+                if (!__any(any)) continue;
+                typename X::frag fa[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_ring + aoff + m * C::WGRP + tap * 32);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb);
+            }
+        }
+    }
+
+    EpiArgs e;
+    e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
+    e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
+    if constexpr (EPI == 2) {
+        __syncthreads();
+        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * 32 * (64 * MT + 16));
+    } else {
+        tile_epilogue<bf16_t, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    }
+}
+
+template <int MT>
+static int launch_dcn4_cfg(const Dcn4Args &a0, hipStream_t st)
+{
+    using C = Dcn4Cfg<MT>;
+    static_assert(C::LDS <= 160 * 1024, "LDS budget");
+    Dcn4Args a = a0;
+    a.tiles_x = cdiv(a.W, 16);
+    a.tiles_y = cdiv(a.H, 16);
+    dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
+    if (h3d_note_kernel("dcn4_kernel<%d>", MT)) return H3D_OK;
+    const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
+    if (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0)
+        hipLaunchKernelGGL((dcn4_kernel<MT, 2>), grid, dim3(512), 0, st, a);
+    else if (lean)
+        hipLaunchKernelGGL((dcn4_kernel<MT, 1>), grid, dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((dcn4_kernel<MT, 0>), grid, dim3(512), 0, st, a);
+    H3D_CHECK_LAUNCH("dcn4_kernel");
+    return H3D_OK;
+}
+
+int h3d_launch_dcn4(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.w || !op.bias || !op.out || !op.in2) H3D_FAIL(H3D_ERR_ARG, "dcn_fused_f16: null pointer");
+    if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused_f16: bf16 plans only (dtype %d)", op.dtype);
+    if (op.ksize != 3 || op.stride != 1 || op.Ho != op.H || op.Wo != op.W)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused_f16: covers 3x3 s1 p1 d1 dg1 only (k=%d s=%d)", op.ksize, op.stride);
+    if (op.Cin != 64 || op.in_cs % 8 || op.Cin > op.in_cs) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: Cin=%d (stride %d), 64 expected", op.Cin, op.in_cs);
+    if (op.Cout > 64) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: Cout=%d > 64", op.Cout);
+    if (op.H > 32767 || op.W > 32767 || (size_t)op.H * op.W * op.in_cs * 2 >= 0x7ffffff0ull)
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: image too large");
+    if (op.wrows % 32 || op.wrows < op.Cout) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: packed weight rows %d for Cout %d", op.wrows, op.Cout);
+    if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: out channel stride %d", op.out_cs);
+    Dcn4Args a;
+    a.in = (const char *)op.in; a.wimg = (const char *)op.w; a.woff = (const char *)op.in2; a.bias = op.bias;
+    a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.in_cs = op.in_cs;
+    a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode; a.wrows = op.wrows;
+    a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0;
+    if (op.Cout <= 32) return launch_dcn4_cfg<1>(a, st);
+    return launch_dcn4_cfg<2>(a, st);
+}

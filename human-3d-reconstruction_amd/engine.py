@@ -103,14 +103,40 @@ class PackedWeights:
             G = ((co + 127) // 128) * 4
             wp = torch.zeros(G * 32, 9, ci)
             wp[:co] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
-            img = torch.zeros(ci // 16, G, 32, 19, 8)
-            # [rows][tap][stage][h][8] -> [stage][G][32][tap][h][8]
-            v = wp.reshape(G, 32, 9, ci // 16, 2, 8).permute(3, 0, 1, 2, 4, 5)
-            img[:, :, :, :18] = v.reshape(ci // 16, G, 32, 18, 8)
+            img = self._stage_image(wp)
             bp = torch.zeros(G * 32)
             bp[:co] = b
             self.t[key] = (img.to(torch.bfloat16).contiguous().to(self.device), bp.contiguous().to(self.device),
                            co, ci, G * 32)
+        return self.t[key]
+
+    @staticmethod
+    def _stage_image(wp):
+        """[rows (multiple of 32)][9][Cin] -> stage-major LDS image [Cin/16][rows/32][32][19 slots][8]:
+        slot 2*tap+h = input channels 16*stage + 8h..8h+7 of tap `tap`, slot 18 zero (csrc/conv2.hip, dcn4.hip)."""
+        rows, _, ci = wp.shape
+        G = rows // 32
+        img = torch.zeros(ci // 16, G, 32, 19, 8)
+        v = wp.reshape(G, 32, 9, ci // 16, 2, 8).permute(3, 0, 1, 2, 4, 5)
+        img[:, :, :, :18] = v.reshape(ci // 16, G, 32, 18, 8)
+        return img
+
+    def dcn_stream(self, p):
+        """Fused DeformConv `p` packed for csrc/dcn4.hip (fp16 stage-major images of the main and the
+        offset/mask filters) -> (main image, offset image, bias [rows | 32], Cout, Cin, rows)."""
+        key = ("dcn_stream", p)
+        if key not in self.t:
+            w, b = self._fold(self.sd[p + ".conv.weight"], self.sd[p + ".conv.bias"], p + ".actf.0")
+            co, ci = w.shape[:2]
+            rows = ((co + 127) // 128) * 128
+            wp = torch.zeros(rows, 9, ci)
+            wp[:co] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
+            bp = torch.zeros(rows)
+            bp[:co] = b
+            wo, bo = self.offset_conv(p + ".conv.conv_offset_mask.weight", p + ".conv.conv_offset_mask.bias", rows)
+            self.t[key] = (self._stage_image(wp).to(torch.float16).contiguous().to(self.device),
+                           self._stage_image(wo[:32].float().cpu()).to(torch.float16).contiguous().to(self.device),
+                           torch.cat([bp, bo]).contiguous().to(self.device), co, ci, rows)
         return self.t[key]
 
     def stem(self):
@@ -186,10 +212,11 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True):
+    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True):
         self.fuse_heads = fuse_heads
         self.fuse_offsets = fuse_offsets
         self.stream_convs = stream_convs
+        self.stream_dcn = stream_dcn
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -273,13 +300,15 @@ class Plan:
                  Cout=x.C, out_cs=out.cs, ksize=2, stride=2)
         return out
 
-    def upadd(self, x, skip, wkey):
+    def upadd(self, x, skip, wkey, f16=False):
+        """f16: the sum is written as fp16 (same 2-byte NHWC buffer) for a csrc/dcn4.hip consumer."""
         w, k = self.pw.up(wkey)
         f = k // 2
         out = self._alloc(x.H * f, x.W * f, x.C)
         assert (skip.H, skip.W, skip.C) == (out.H, out.W, out.C), wkey
         self._op(_lib.OP_UPADD, in_=x.ptr, in2=skip.ptr, w=w.data_ptr(), out=out.ptr, H=x.H, W=x.W, Cin=x.C,
-                 in_cs=x.cs, in2_cs=skip.cs, Ho=out.H, Wo=out.W, Cout=x.C, out_cs=out.cs, ksize=k, stride=f)
+                 in_cs=x.cs, in2_cs=skip.cs, Ho=out.H, Wo=out.W, Cout=x.C, out_cs=out.cs, ksize=k, stride=f,
+                 out_mode=_lib.OUT_NHWC_F16 if f16 else _lib.OUT_NHWC)
         return out
 
     # -- network ---------------------------------------------------------------------------------
@@ -316,8 +345,22 @@ class Plan:
         x1 = self._tree1(x, p + ".tree1", cin, cout, 2, False, cat.slice(2 * cout + cin, cout))
         return self._tree1(x1, p + ".tree2", cout, cout, 1, False, out, cat=cat)
 
-    def _deform(self, x, p, out=None):
+    def _dcn_f16_ok(self, p):
+        """node DeformConvs with 64 input and <= 64 output channels run on csrc/dcn4.hip (fp16 input)."""
+        w = self.pw.sd[p + ".conv.weight"]
+        return (self.pw.use_dcn and self.fuse_offsets and self.stream_dcn and self.pw.dtype == "bf16"
+                and w.shape[1] == 64 and w.shape[0] <= 64)
+
+    def _deform(self, x, p, out=None, x_is_f16=False):
         """DeformConv (model.py:346-362): DCN or plain 3x3 conv, then BN + ReLU (folded)."""
+        if x_is_f16:
+            wimg, woimg, bias, cout, cin, rows = self.pw.dcn_stream(p)
+            if out is None:
+                out = self._alloc(x.H, x.W, cout)
+            self._op(_lib.OP_DCN_FUSED_F16, in_=x.ptr, in2=woimg.data_ptr(), w=wimg.data_ptr(), bias=bias.data_ptr(),
+                     out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
+                     stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
+            return out
         if self.pw.use_dcn and self.fuse_offsets:
             wp, bp, cout, cin, k, rows = self.pw.conv(p + ".conv.weight", p + ".conv.bias", p + ".actf.0", as_half=True)
             wo, bo = self.pw.offset_conv(p + ".conv.conv_offset_mask.weight", p + ".conv.conv_offset_mask.bias", rows)
@@ -342,8 +385,9 @@ class Plan:
         for i in range(startp + 1, endp):
             k = i - startp
             y = self._deform(layers[i], "%s.proj_%d" % (p, k))
-            y = self.upadd(y, layers[i - 1], "%s.up_%d.weight" % (p, k))
-            layers[i] = self._deform(y, "%s.node_%d" % (p, k))
+            f16 = self._dcn_f16_ok("%s.node_%d" % (p, k))
+            y = self.upadd(y, layers[i - 1], "%s.up_%d.weight" % (p, k), f16=f16)
+            layers[i] = self._deform(y, "%s.node_%d" % (p, k), x_is_f16=f16)
 
     def _lower(self):
         B, H, W = self.B, self.H, self.W
@@ -444,6 +488,7 @@ class DLAEngine:
         self.fuse_heads = True          # False: one conv3x3 + conv1x1 launch pair per head (debug/ablation)
         self.fuse_offsets = True        # False: conv_offset_mask as its own launch + dcn2_kernel reading NHWC offsets
         self.stream_convs = True        # False: 3x3 s1 convs through the register-staged kernel (csrc/conv.hip)
+        self.stream_dcn = True          # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
         self.streams = 1                # >1: run that many sub-batches concurrently on their own HIP streams
 
     def plan(self, B, H, W):
@@ -451,7 +496,7 @@ class DLAEngine:
         if key not in self.plans:
             with torch.cuda.device(self.device):
                 self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                                       stream_convs=self.stream_convs)
+                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn)
         return self.plans[key]
 
     def forward(self, images):
@@ -481,7 +526,7 @@ class DLAEngine:
         with torch.cuda.device(self.device):
             if key not in self.plans:
                 plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                              stream_convs=self.stream_convs)
+                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn)
                          for _ in range(n)]
                 full = {h: torch.empty((B,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
                         for h, o in plans[0].outputs.items()}

@@ -79,6 +79,8 @@ enum {
     H3D_OP_CONV_STREAM = 10, /* 3x3 s1 p1 conv (bf16) fed by LDS-DMA (csrc/conv2.hip): w = stage-major filter image
                                 [Cin/16][wrows/32][32 rows][19 slots of 8 elements]: slot 2*tap+h = input channels
                                 16*stage + 8h..8h+7 of tap `tap`, slot 18 zero; in2 = optional residual    */
+    H3D_OP_DCN_FUSED_F16 = 11, /* H3D_OP_DCN_FUSED for a 64-channel fp16 input, Cout <= 64 (csrc/dcn4.hip): w and in2 are
+                                  stage-major fp16 filter images [4][wrows/32 | 1][32][19][8] (layout of H3D_OP_CONV_STREAM) */
     H3D_OP_DCN_V1 = 8,  /* first-generation DCN kernel (global gather, bf16 weights): kept as an A/B reference */
     H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
                            (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */
@@ -100,7 +102,8 @@ typedef struct h3d_heads_desc {
         int32_t pad;
     } head[H3D_HEADS_MAX];
 } h3d_heads_desc;
-enum { H3D_OUT_NHWC = 0, H3D_OUT_NCHW_F32 = 1, H3D_OUT_NHWC_F32 = 2 };
+enum { H3D_OUT_NHWC = 0, H3D_OUT_NCHW_F32 = 1, H3D_OUT_NHWC_F32 = 2,
+       H3D_OUT_NHWC_F16 = 3 /* H3D_OP_UPADD in a bf16 plan only: fp16 output, the input of H3D_OP_DCN_FUSED_F16 */ };
 
 typedef struct h3d_op {
     int32_t kind;       /* H3D_OP_*                                                        */

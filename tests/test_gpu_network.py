@@ -200,3 +200,54 @@ def test_stream_split_matches_single_stream():
     eng.streams = 1
     for k in HEADS:
         assert torch.equal(one[k], two[k]), k
+
+
+def _ab(m, xs, flag):
+    """heads with engine flag `flag` on (default) and off, plans rebuilt in between."""
+    eng = m.engine(xs.device)
+    assert getattr(eng, flag)
+    on = {k: v.clone() for k, v in m(xs)[0].items()}
+    setattr(eng, flag, False)
+    eng.plans.clear()
+    off = {k: v.clone() for k, v in m(xs)[0].items()}
+    setattr(eng, flag, True)
+    eng.plans.clear()
+    return on, off
+
+
+def test_streamed_conv_matches_register_staged_kernel():
+    # csrc/conv2.hip (LDS-DMA operands, LDS-transposed stores) vs csrc/conv.hip on every 3x3 s1 layer:
+    # same bf16 operands, same fp32 accumulation -> only the summation order inside an MFMA chain differs
+    m, _ = _net(False, "bf16")
+    xs = torch.from_numpy(synth.synth_images(3, 96, 160, seed=23)).to(DEV)     # ragged tiles on both axes
+    on, off = _ab(m, xs, "stream_convs")
+    kinds = [op.kind for op in m.engine(xs.device).plan(3, 96, 160).ops]
+    from h3d_amd import _lib
+    assert _lib.OP_CONV_STREAM in kinds
+    for k in HEADS:
+        e = float((on[k] - off[k]).abs().max())
+        assert e <= 3e-2, (k, e)
+
+
+@pytest.mark.parametrize("offset_scale,tol", [(0.5, 6e-2), (12.0, 0.25)])
+def test_streamed_dcn_matches_dcn3(offset_scale, tol):
+    # csrc/dcn4.hip (fp16 input written by the up-sample kernel, all operands by LDS-DMA) vs csrc/dcn3.hip;
+    # offset_scale 12 drives many samples out of the apron so the global-gather pass 2 is exercised too.
+    sd = synth.synth_state_dict(arch.state_dict_shapes(HEADS, True), seed=0, offset_scale=offset_scale)
+    m = model.dla_net(HEADS, not_use_dcn=False, dtype="bf16")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=29)).to(DEV)
+    on, off = _ab(m, xs, "stream_dcn")
+    from h3d_amd import _lib
+    kinds = [op.kind for op in m.engine(xs.device).plan(2, 96, 160).ops]
+    assert _lib.OP_DCN_FUSED_F16 in kinds
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(xs.cpu())[0]
+    for k in HEADS:
+        e = float((on[k] - off[k]).abs().max())
+        assert e <= tol, (k, e)
+        # and the streamed path is no further from the fp32 oracle than the bf16 tolerance of this file
+        e_ref = float((on[k].cpu() - ref[k]).abs().max())
+        e_off = float((off[k].cpu() - ref[k]).abs().max())
+        assert e_ref <= max(BF16_TOL, 1.5 * e_off), (k, e_ref, e_off)
