@@ -108,7 +108,9 @@ template <> struct ET<bf16_t> {
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 {
-    return (uint32_t)ET<bf16_t>::from_f32(lo) | ((uint32_t)ET<bf16_t>::from_f32(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));   // one v_cvt_pk_bf16_f32 (RNE)
 }
 
 // store 4 consecutive channels held as floats

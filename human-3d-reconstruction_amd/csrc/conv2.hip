@@ -179,8 +179,8 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
     if (op.Cin % 16 || op.in_cs % 8 || op.Cin > op.in_cs)
         H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: Cin=%d (stride %d) must be a multiple of 16", op.Cin, op.in_cs);
     if ((size_t)op.H * op.W * op.in_cs * 2 >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: image of 2 GiB or more");
-    if (op.wrows % 32 || op.wrows < op.Cout)
-        H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: packed weight rows %d for Cout %d (multiple of 32 expected)", op.wrows, op.Cout);
+    if (op.wrows % 128 || op.wrows < op.Cout)
+        H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: packed weight/bias rows %d for Cout %d (Cout padded to 128 expected)", op.wrows, op.Cout);
     if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
         H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: out channel stride %d", op.out_cs);
     if (op.in2 && (op.in2_cs % 4 || op.Cout > op.in2_cs)) H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: residual stride %d", op.in2_cs);

@@ -294,7 +294,7 @@ int h3d_launch_dcn4(const h3d_op &op, hipStream_t st)
     if (op.Cout > 64) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: Cout=%d > 64", op.Cout);
     if (op.H > 32767 || op.W > 32767 || (size_t)op.H * op.W * op.in_cs * 2 >= 0x7ffffff0ull)
         H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: image too large");
-    if (op.wrows % 32 || op.wrows < op.Cout) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: packed weight rows %d for Cout %d", op.wrows, op.Cout);
+    if (op.wrows % 128 || op.wrows < op.Cout) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: packed weight rows %d for Cout %d", op.wrows, op.Cout);
     if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
         H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_f16: out channel stride %d", op.out_cs);
     Dcn4Args a;

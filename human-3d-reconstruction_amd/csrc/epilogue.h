@@ -35,11 +35,14 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[MT][NT], const EpiAr
             const float *bp = a.bias + cout0 + 4 * h;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
+                float4 bias4[4];       // the packed bias covers every row of the tile (rows are padded): no guards,
+#pragma unroll                         // the four loads of an M-tile in flight together
+                for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const float4 *>(bp + m * 32 + 8 * g);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int co = m * 32 + 8 * g;
                     if (cout0 + co + 4 * h >= a.Cout) continue;
-                    const float4 bv = *reinterpret_cast<const float4 *>(bp + co);
+                    const float4 bv = bias4[g];
                     float v0 = acc[m][n][4 * g + 0] + bv.x, v1 = acc[m][n][4 * g + 1] + bv.y;
                     float v2 = acc[m][n][4 * g + 2] + bv.z, v3 = acc[m][n][4 * g + 3] + bv.w;
                     if (has_res) {
@@ -125,12 +128,14 @@ __device__ __forceinline__ void tile_epilogue_lds(f32x16 (&acc)[MT][1], const Ep
         const float lo = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            float4 bias4[4];           // padded bias rows: unguarded, the four loads of an M-tile in flight together
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const float4 *>(bp + m * 32 + 8 * g);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = m * 32 + 8 * g;
                 const bool cok = cout0 + co + 4 * h < a.Cout;
-                float4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (cok) bv = *reinterpret_cast<const float4 *>(bp + co);
+                const float4 bv = bias4[g];
                 float v0 = acc[m][0][4 * g + 0] + bv.x, v1 = acc[m][0][4 * g + 1] + bv.y;
                 float v2 = acc[m][0][4 * g + 2] + bv.z, v3 = acc[m][0][4 * g + 3] + bv.w;
                 if (has_res && cok) {
