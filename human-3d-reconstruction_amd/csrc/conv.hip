@@ -175,10 +175,11 @@ static int launch_conv_cfg(const ConvArgs &a0, hipStream_t st)
     a.tiles_x = cdiv(a.Wo, C::TW);
     a.tiles_y = cdiv(a.Ho, TH);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
-    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
-                        CK, TH, WAVES))
+    const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
+    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
+                        CK, TH, WAVES, lean ? "true" : "false"))
         return H3D_OK;
-    if (a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0)
+    if (lean)
         hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, true>), grid, dim3(C::THREADS), 0, st, a);
     else
         hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, false>), grid, dim3(C::THREADS), 0, st, a);

@@ -158,11 +158,12 @@ static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, C::TH);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
-    if (h3d_note_kernel("conv2_kernel<%d, %d>", MT, WAVES)) return H3D_OK;
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
-    if (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4))
+    const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4)) ? 2 : lean ? 1 : 0;
+    if (h3d_note_kernel("conv2_kernel<%d, %d, %d>", MT, WAVES, epi)) return H3D_OK;
+    if (epi == 2)
         hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2>), grid, dim3(C::THREADS), 0, st, a);
-    else if (lean)
+    else if (epi == 1)
         hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1>), grid, dim3(C::THREADS), 0, st, a);
     else
         hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0>), grid, dim3(C::THREADS), 0, st, a);

@@ -319,16 +319,17 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
-    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN)) return H3D_OK;
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
+    const int epi = (sizeof(T) == 2 && MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
+    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN, epi)) return H3D_OK;
     if constexpr (sizeof(T) == 2 && MT >= 2) {
-        if (lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) {
+        if (epi == 2) {
             hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2>), grid, dim3(C::THREADS), 0, st, a);
             H3D_CHECK_LAUNCH("dcn3_kernel");
             return H3D_OK;
         }
     }
-    if (lean)
+    if (epi == 1)
         hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1>), grid, dim3(C::THREADS), 0, st, a);
     else
         hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0>), grid, dim3(C::THREADS), 0, st, a);

@@ -272,11 +272,12 @@ static int launch_dcn4_cfg(const Dcn4Args &a0, hipStream_t st)
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
-    if (h3d_note_kernel("dcn4_kernel<%d>", MT)) return H3D_OK;
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
-    if (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0)
+    const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
+    if (h3d_note_kernel("dcn4_kernel<%d, %d>", MT, epi)) return H3D_OK;
+    if (epi == 2)
         hipLaunchKernelGGL((dcn4_kernel<MT, 2>), grid, dim3(512), 0, st, a);
-    else if (lean)
+    else if (epi == 1)
         hipLaunchKernelGGL((dcn4_kernel<MT, 1>), grid, dim3(512), 0, st, a);
     else
         hipLaunchKernelGGL((dcn4_kernel<MT, 0>), grid, dim3(512), 0, st, a);
