@@ -492,41 +492,76 @@ __global__ void maxpool_kernel(const T *__restrict__ in, T *__restrict__ out, in
 // (IDAUp.forward: layers[i] = up(proj(layers[i])); node(layers[i] + layers[i-1]), model.py:384-390).
 // out[oy][ox][c] = skip + sum over (i,j) with (oy + p - i) % f == 0: w[c][i][j] * in[(oy+p-i)/f][(ox+p-j)/f][c]
 // -> exactly two i and two j per output pixel.  w: fp32 [k*k][C] (tap-major so channel vectors load).
-template <typename T, bool F16OUT = false>   // F16OUT: bf16 inputs, fp16 output (H3D_OUT_NHWC_F16)
-__global__ void upadd_kernel(const T *__restrict__ in, const T *__restrict__ skip, const float *__restrict__ w,
-                             T *__restrict__ out, int B, int H, int W, int C, int in_cs, int skip_cs, int Ho,
-                             int Wo, int out_cs, int f)
+// Workgroup = UP_ROWS output rows x a segment of 256/vpc pixels (vpc = 16-byte channel vectors per pixel); the
+// k*k x C tap weights are staged in LDS once per workgroup, so the inner loop has no global weight loads,
+// no integer division, and 5 independent 16-byte loads per thread in flight (4 taps + skip).
+constexpr int UP_ROWS = 8;
+template <typename T, bool F16OUT = false, bool WLDS = true>   // F16OUT: bf16 inputs, fp16 output (H3D_OUT_NHWC_F16)
+__global__ __launch_bounds__(256) void upadd_kernel(const T *__restrict__ in, const T *__restrict__ skip,
+                                                    const float *__restrict__ w, T *__restrict__ out, int B, int H, int W,
+                                                    int C, int in_cs, int skip_cs, int Ho, int Wo, int out_cs, int f)
 {
     constexpr int N = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float s_w[];     // [k*k][C]
     const int vpc = C / N, k = 2 * f, p = f / 2;
-    const size_t total = (size_t)B * Ho * Wo * vpc;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int v = i % vpc;
-        const size_t pix = i / vpc;
-        const int ox = pix % Wo;
-        const size_t q = pix / Wo;
-        const int oy = q % Ho, b = q / Ho;
-        float acc[N], x[N];
+    if constexpr (WLDS) {   // a compile-time choice: a run-time pointer select would turn the ds_reads into flat loads
+        for (int i = threadIdx.x; i < k * k * C / 4; i += 256)
+            *reinterpret_cast<f32x4 *>(s_w + 4 * i) = *reinterpret_cast<const f32x4 *>(w + 4 * i);
+        __syncthreads();
+    }
+    const int ppb = 256 / vpc;                                       // pixels per workgroup row segment
+    const int v = threadIdx.x % vpc, pxl = threadIdx.x / vpc;
+    const int ox = blockIdx.x * ppb + pxl;
+    const int rows_per_img = (Ho + UP_ROWS - 1) / UP_ROWS;
+    const int b = blockIdx.y / rows_per_img, oy0 = (blockIdx.y - b * rows_per_img) * UP_ROWS;
+    if (pxl >= ppb || ox >= Wo) return;
+    // the two contributing input columns and their kernel columns are fixed for this thread
+    const int rx = (ox + p) % f;
+    int ixs[2], kjs[2];
+    bool xok[2];
 #pragma unroll
-        for (int n = 0; n < N; ++n) acc[n] = 0.f;
-        const int ry = (oy + p) % f, rx = (ox + p) % f;
+    for (int c2 = 0; c2 < 2; ++c2) {
+        kjs[c2] = rx + c2 * f;
+        const int num = ox + p - kjs[c2];
+        ixs[c2] = num / f;                       // exact when num >= 0 (multiple of f)
+        xok[c2] = num >= 0 && ixs[c2] < W;
+    }
+    for (int oy = oy0; oy < min(oy0 + UP_ROWS, Ho); ++oy) {
+        const size_t pix = ((size_t)b * Ho + oy) * Wo + ox;
+        const int ry = (oy + p) % f;
+        u32x4 xv[4], sv;
+        bool ok[4];
+        int tap[4];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int ki = ry + a * f;
-            const int iy = (oy + p - ki) / f;  // exact: (oy+p-ki) is a multiple of f (may be negative)
-            if (oy + p - ki < 0 || iy >= H) continue;
+            const int num = oy + p - ki;
+            const int iy = num / f;
+            const bool yok = num >= 0 && iy < H;
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) {
-                const int kj = rx + c2 * f;
-                const int ix = (ox + p - kj) / f;
-                if (ox + p - kj < 0 || ix >= W) continue;
-                unpack16<T>(*reinterpret_cast<const u32x4 *>(in + (((size_t)b * H + iy) * W + ix) * in_cs + v * N), x);
-                const float *wp = w + (size_t)(ki * k + kj) * C + v * N;
-#pragma unroll
-                for (int n = 0; n < N; ++n) acc[n] = fmaf(wp[n], x[n], acc[n]);
+                const int q = a * 2 + c2;
+                ok[q] = yok && xok[c2];
+                tap[q] = ki * k + kjs[c2];
+                xv[q] = u32x4{0u, 0u, 0u, 0u};
+                if (ok[q]) xv[q] = *reinterpret_cast<const u32x4 *>(in + (((size_t)b * H + iy) * W + ixs[c2]) * in_cs + v * N);
             }
         }
-        unpack16<T>(*reinterpret_cast<const u32x4 *>(skip + pix * skip_cs + v * N), x);
+        sv = *reinterpret_cast<const u32x4 *>(skip + pix * skip_cs + v * N);
+        float acc[N], x[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) continue;                // same association order as before: taps (a, c2) ascending
+            unpack16<T>(xv[q], x);
+            const float *wp;
+            if constexpr (WLDS) wp = s_w + tap[q] * C + v * N;
+            else wp = w + tap[q] * C + v * N;
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] = fmaf(wp[n], x[n], acc[n]);
+        }
+        unpack16<T>(sv, x);
 #pragma unroll
         for (int n = 0; n < N; ++n) acc[n] += x[n];
         if constexpr (F16OUT) *reinterpret_cast<u32x4 *>(out + pix * out_cs + v * N) = pack16_f16(acc);
@@ -562,8 +597,13 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
     dim3 grid(ew_grid(total)), blk(256);
     const bool f16out = op.kind == H3D_OP_UPADD && op.out_mode == H3D_OUT_NHWC_F16;
     if (f16out && es != 2) H3D_FAIL(H3D_ERR_DTYPE, "upadd: fp16 output needs a bf16 plan");
-    if (h3d_note_kernel("%s<%s%s>", op.kind == H3D_OP_MAXPOOL ? "maxpool_kernel" : op.kind == H3D_OP_UPADD ? "upadd_kernel" : "copy_kernel",
-                        es == 2 ? "unsigned short" : "float", op.kind == H3D_OP_UPADD ? (f16out ? ", true" : ", false") : ""))
+    // tap table in LDS only while staging it is cheap next to the workgroup's 8 rows (measured: 4 KiB wins by 33 %,
+    // 8 KiB and more lose); tuning override: reserved 1 = never, 2 = whenever it fits 64 KiB
+    const size_t up_wbytes = (size_t)op.ksize * op.ksize * op.Cin * sizeof(float);
+    const bool up_wlds = op.reserved == 1 ? false : op.reserved == 2 ? up_wbytes <= 64 * 1024 : up_wbytes <= 4096;
+    if (h3d_note_kernel("%s<%s%s%s>", op.kind == H3D_OP_MAXPOOL ? "maxpool_kernel" : op.kind == H3D_OP_UPADD ? "upadd_kernel" : "copy_kernel",
+                        es == 2 ? "unsigned short" : "float", op.kind == H3D_OP_UPADD ? (f16out ? ", true" : ", false") : "",
+                        op.kind == H3D_OP_UPADD ? (up_wlds ? ", true" : ", false") : ""))
         return H3D_OK;
     if (op.kind == H3D_OP_MAXPOOL) {
         if (op.Ho != op.H / 2 || op.Wo != op.W / 2) H3D_FAIL(H3D_ERR_SHAPE, "maxpool: output must be floor(H/2) x floor(W/2)");
@@ -579,18 +619,28 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
         if (!op.in2 || !op.w) H3D_FAIL(H3D_ERR_ARG, "upadd: null pointer");
         if (op.ksize != 2 * f || op.Ho != op.H * f || op.Wo != op.W * f || op.in2_cs % n)
             H3D_FAIL(H3D_ERR_SHAPE, "upadd: expects k=2f, out = f*in (k=%d f=%d)", op.ksize, f);
-        if (f16out)
-            hipLaunchKernelGGL((upadd_kernel<bf16_t, true>), grid, blk, 0, st, (const bf16_t *)op.in, (const bf16_t *)op.in2,
-                               (const float *)op.w, (bf16_t *)op.out, op.B, op.H, op.W, op.Cin, op.in_cs, op.in2_cs, op.Ho,
-                               op.Wo, op.out_cs, f);
-        else if (es == 2)
-            hipLaunchKernelGGL(upadd_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t *)op.in, (const bf16_t *)op.in2,
-                               (const float *)op.w, (bf16_t *)op.out, op.B, op.H, op.W, op.Cin, op.in_cs, op.in2_cs, op.Ho,
-                               op.Wo, op.out_cs, f);
-        else
-            hipLaunchKernelGGL(upadd_kernel<float>, grid, blk, 0, st, (const float *)op.in, (const float *)op.in2,
-                               (const float *)op.w, (float *)op.out, op.B, op.H, op.W, op.Cin, op.in_cs, op.in2_cs, op.Ho,
-                               op.Wo, op.out_cs, f);
+        const int vpc = op.Cin / n;
+        if (vpc > 256) H3D_FAIL(H3D_ERR_UNSUPPORTED, "upadd: C=%d", op.Cin);
+        const size_t wfl = (size_t)op.ksize * op.ksize * op.Cin;
+        // tap table in LDS when it fits the default 64 KiB (tuning override: reserved 1 = never, 2 = always)
+        const bool wlds = up_wlds;
+        const size_t lds = wlds ? wfl * sizeof(float) : 0;
+        const dim3 ugrid(cdiv(op.Wo, 256 / vpc), op.B * cdiv(op.Ho, UP_ROWS));
+#define H3D_UPADD_LAUNCH(K, TT)                                                                                              \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL(K, ugrid, blk, lds, st, (const TT *)op.in, (const TT *)op.in2, (const float *)op.w, (TT *)op.out, \
+                           op.B, op.H, op.W, op.Cin, op.in_cs, op.in2_cs, op.Ho, op.Wo, op.out_cs, f);                        \
+    } while (0)
+        if (wlds) {
+            if (f16out) H3D_UPADD_LAUNCH((upadd_kernel<bf16_t, true, true>), bf16_t);
+            else if (es == 2) H3D_UPADD_LAUNCH((upadd_kernel<bf16_t, false, true>), bf16_t);
+            else H3D_UPADD_LAUNCH((upadd_kernel<float, false, true>), float);
+        } else {
+            if (f16out) H3D_UPADD_LAUNCH((upadd_kernel<bf16_t, true, false>), bf16_t);
+            else if (es == 2) H3D_UPADD_LAUNCH((upadd_kernel<bf16_t, false, false>), bf16_t);
+            else H3D_UPADD_LAUNCH((upadd_kernel<float, false, false>), float);
+        }
+#undef H3D_UPADD_LAUNCH
         H3D_CHECK_LAUNCH("upadd_kernel");
     } else {
         if (op.Ho != op.H || op.Wo != op.W) H3D_FAIL(H3D_ERR_SHAPE, "copy: shape");
