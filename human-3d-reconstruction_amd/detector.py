@@ -92,6 +92,15 @@ class MultiPoseDetector:
         return res
 
 
+def run_frames(detector, frames):
+    """Raw uint8 BGR frames [B,h,w,3] on the device -> `MultiPoseDetector.run` results with `results` in
+    original-image pixels: pre-process (datasets/coco_hp.py:151-212 val branch, csrc/preprocess.hip) ->
+    network -> decode -> post-process, the order of the reference's demo / test loop."""
+    from . import preprocess
+    inp, c, s = preprocess.pre_process(frames, input_res=detector.opt.input_h)
+    return detector.run(inp, meta={"c": c, "s": s})
+
+
 def multi_pose_post_process(dets, c, s, h, w):
     """reference utils/post_process.py:41-52 on the device: dets [B,K,40], c [B,2], s [B] ->
     [B,K,39] (bbox, score, 17 keypoints in original-image pixels)."""

@@ -197,6 +197,13 @@ int h3d_ctdet_assemble(const float *c_score, const int64_t *c_ind, const int32_t
                        int B, int C, int H, int W, int K, int cat_spec_wh, float *dets,
                        void *stream);
 
+/* Pre-process, val branch of datasets/coco_hp.py:151-212: images [B,h,w,3] uint8 (BGR, rows of
+ * row_bytes) -> out [B,3,res_h,res_w] fp32 = ((warpAffine(img, M, INTER_LINEAR, border 0) / 255) - mean) / std.
+ * minv [B,6] double = the INVERSE (dst -> src) 2x3 affine of get_affine_transform(c, s, 0, [res,res])
+ * (utils/image.py:27-62); OpenCV's fixed-point bilinear scheme, see csrc/preprocess.hip. */
+int h3d_preprocess(const uint8_t *images, int B, int h, int w, int row_bytes, const double *minv,
+                   const float *mean, const float *stdv, int res_h, int res_w, float *out, void *stream);
+
 /* multi_pose_post_process (utils/post_process.py:41-52 + utils/image.py:19-68, inv affine with
  * rot = 0): dets [B,K,40] (output-res px) + c [B,2], s [B] -> out [B,K,39] image px. */
 int h3d_multi_pose_post_process(const float *dets, const float *c, const float *s, int B, int K,
