@@ -141,9 +141,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2) {
-        static_assert(WAVES * 32 * (64 * MT + 16) <= C::LDS, "epilogue tile");
+        static_assert(WAVES * epi_lds_stride<MT>() <= C::LDS, "epilogue tile");
         __syncthreads();                          // nobody reads the ring any more
-        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * 32 * (64 * MT + 16));
+        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
     } else {
         tile_epilogue<bf16_t, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }

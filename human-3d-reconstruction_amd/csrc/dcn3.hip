@@ -43,7 +43,7 @@ struct Dcn3Cfg {
     static constexpr int VPP = CK * SS / 16;
     static constexpr int LDS_H = HH * RBH;
     static constexpr int LDS_MAIN = LDS_H + BN * WB;
-    static constexpr int LDS_EPI = 8 * 32 * (64 * MT + 16);   // epilogue.h tile_epilogue_lds regions
+    static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // epilogue.h tile_epilogue_lds regions
     static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 };
 
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2) {
         __syncthreads();                          // the apron and the filters are no longer read
-        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * 32 * (64 * MT + 16));
+        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
     } else {
         tile_epilogue<T, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }
