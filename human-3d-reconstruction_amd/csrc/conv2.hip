@@ -25,15 +25,19 @@ struct Conv2Args {
     const char *res;
     char *out;
     int B, H, W, Cin, in_cs;
-    int Cout, out_cs, res_cs, relu, out_mode;
+    int Ho, Wo, Cout, out_cs, res_cs, relu, out_mode;
     int G, tiles_x, tiles_y;
     int dbg;   // ABLATE builds only (op.reserved >> 16): 1 = no DMA after stage 0, 2 = no fragment reads / MFMA
 };
 
-template <int MT, int WAVES>
+template <int MT, int WAVES, int S = 1>
 struct Conv2Cfg {
     static constexpr int TH = 2 * WAVES;
-    static constexpr int ROWS = TH + 2;                 // halo rows = DMA pieces of the halo image
+    static constexpr int HROWS = (TH - 1) * S + 3;      // halo rows
+    static constexpr int HCOLS = 15 * S + 3;            // halo pixels per row: 18 (stride 1) / 33 (stride 2)
+    static constexpr int PPR = S;                       // 1 KiB DMA pieces per halo row (3 slots per pixel)
+    static constexpr int ROWB = PPR * 1024;
+    static constexpr int ROWS = HROWS * PPR;            // DMA pieces of the halo image
     static constexpr int HALO = ROWS * 1024;
     static constexpr int WROW = 19 * 16;                // 304 B
     static constexpr int WGRP = 32 * WROW;              // one 32-row group: 9728 B
@@ -50,11 +54,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 // LDS-DMA of one stage into the ring slot at `base` (a plain function of plain arguments: the buffer-descriptor
 // type does not exist in the host pass, and a lambda capturing one silently drops the kernel's stub)
-template <int MT, int WAVES>
+template <int MT, int WAVES, int S>
 __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, const char *wimg, int w_bytes, char *base,
                                             const int *hoff, int woff, int wv, int s, int wsrc, int dbg = 0)
 {
-    using C = Conv2Cfg<MT, WAVES>;
+    using C = Conv2Cfg<MT, WAVES, S>;
     // descriptors are rebuilt from wave-uniform scalars at every call (4 SGPRs each, no memory traffic)
     const auto r_in = __builtin_amdgcn_make_buffer_rsrc((void *)in_b, 0, in_bytes, 0x00020000);
     const auto r_w = __builtin_amdgcn_make_buffer_rsrc((void *)wimg, 0, w_bytes, 0x00020000);
@@ -71,10 +75,10 @@ __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, cons
     }
 }
 
-template <int MT, int WAVES, int EPI>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h)
+template <int MT, int WAVES, int EPI, int S = 1>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
 __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 {
-    using C = Conv2Cfg<MT, WAVES>;
+    using C = Conv2Cfg<MT, WAVES, S>;
     using E = ET<bf16_t>;
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
 
@@ -98,17 +102,18 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     int hoff[C::HP];
 #pragma unroll
     for (int j = 0; j < C::HP; ++j) {
-        const int iy = wv + j * WAVES;                            // halo row = piece
-        const int ix = l / 3, sub = l - 3 * ix;
-        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
-        const bool ok = iy < C::ROWS && ix < 18 && sub < 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const int pc = wv + j * WAVES;                            // DMA piece: halo row pc / PPR, slots (pc % PPR) * 64 ...
+        const int iy = pc / C::PPR, slot = (pc - iy * C::PPR) * 64 + l;
+        const int ix = slot / 3, sub = slot - 3 * ix;
+        const int gy = oy0 * S - 1 + iy, gx = ox0 * S - 1 + ix;
+        const bool ok = pc < C::ROWS && ix < C::HCOLS && sub < 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         hoff[j] = ok ? ((gy * a.W + gx) * a.in_cs + sub * 8) * 2 : 0x7ffffff0;
     }
     const int woff = l * 16;
 
     // fragment offsets inside a slot
     const int py = 2 * wv + (r >> 4), px = r & 15;
-    const int boff = py * 1024 + px * 48 + h * 16;
+    const int boff = py * S * C::ROWB + px * S * 48 + h * 16;
     const int aoff = C::HALO + r * C::WROW + h * 16;
 
     f32x16 acc[MT][1];
@@ -117,18 +122,18 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
 
-    conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem, hoff, woff, wv, 0, g0 * C::WGRP, H3D_DBG(a));
+    conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem, hoff, woff, wv, 0, g0 * C::WGRP, H3D_DBG(a));
     for (int s = 0; s < nst; ++s) {
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): my pieces of stage s have landed
         __syncthreads();                          // ... everyone's have; slot (s+1)&1 is no longer being read
         if (s + 1 < nst && !(H3D_DBG(a) & 1))
-            conv2_issue<MT, WAVES>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + ((s + 1) & 1) * C::SLOT, hoff, woff, wv, s + 1, ((s + 1) * a.G + g0) * C::WGRP, H3D_DBG(a));
+            conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + ((s + 1) & 1) * C::SLOT, hoff, woff, wv, s + 1, ((s + 1) * a.G + g0) * C::WGRP, H3D_DBG(a));
         const char *sl = smem + (s & 1) * C::SLOT;
         if (H3D_DBG(a) & 2) continue;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
-            const typename E::frag fb = E::lds_frag(sl + boff + dy * 1024 + dx * 48);
+            const typename E::frag fb = E::lds_frag(sl + boff + dy * C::ROWB + dx * 48);
             typename E::frag fa[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) fa[m] = E::lds_frag(sl + aoff + m * C::WGRP + tap * 32);
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     }
 
     EpiArgs e;
-    e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
+    e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2) {
         static_assert(WAVES * epi_lds_stride<MT>() <= C::LDS, "epilogue tile");
@@ -149,24 +154,24 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     }
 }
 
-template <int MT, int WAVES>
+template <int MT, int WAVES, int S = 1>
 static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
 {
-    using C = Conv2Cfg<MT, WAVES>;
+    using C = Conv2Cfg<MT, WAVES, S>;
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     Conv2Args a = a0;
-    a.tiles_x = cdiv(a.W, 16);
-    a.tiles_y = cdiv(a.H, C::TH);
+    a.tiles_x = cdiv(a.Wo, 16);
+    a.tiles_y = cdiv(a.Ho, C::TH);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4)) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("conv2_kernel<%d, %d, %d>", MT, WAVES, epi)) return H3D_OK;
+    if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d>", MT, WAVES, epi, S)) return H3D_OK;
     if (epi == 2)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S>), grid, dim3(C::THREADS), 0, st, a);
     else if (epi == 1)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1, S>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0, S>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("conv2_kernel");
     return H3D_OK;
 }
@@ -175,8 +180,9 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "conv_stream: null pointer");
     if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "conv_stream: bf16 only (dtype %d)", op.dtype);
-    if (op.ksize != 3 || op.stride != 1 || op.Ho != op.H || op.Wo != op.W)
-        H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv_stream: covers 3x3 s1 p1 only (k=%d s=%d)", op.ksize, op.stride);
+    if (op.ksize != 3 || (op.stride != 1 && op.stride != 2) || op.Ho != (op.H - 1) / op.stride + 1 || op.Wo != (op.W - 1) / op.stride + 1)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv_stream: covers 3x3 p1 with stride 1 or 2 (k=%d s=%d, %dx%d -> %dx%d)", op.ksize, op.stride,
+                 op.H, op.W, op.Ho, op.Wo);
     if (op.Cin % 16 || op.in_cs % 8 || op.Cin > op.in_cs)
         H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: Cin=%d (stride %d) must be a multiple of 16", op.Cin, op.in_cs);
     if ((size_t)op.H * op.W * op.in_cs * 2 >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "conv_stream: image of 2 GiB or more");
@@ -188,12 +194,17 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
     Conv2Args a;
     a.in = (const char *)op.in; a.wimg = (const char *)op.w; a.bias = op.bias; a.res = (const char *)op.in2;
     a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
-    a.Cout = op.Cout; a.out_cs = op.out_cs; a.res_cs = op.in2_cs; a.relu = op.relu; a.out_mode = op.out_mode;
+    a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.out_cs = op.out_cs; a.res_cs = op.in2_cs; a.relu = op.relu; a.out_mode = op.out_mode;
     a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0;
     a.dbg = op.reserved >> 16;
     // workgroups a (th rows x 16 px) x (32*mt channels) tiling produces
     const int gq = cdiv(op.Cout, 32);
-    auto nblk = [&](int th, int mt) { return (long)op.B * cdiv(op.W, 16) * cdiv(op.H, th) * cdiv(gq, mt); };
+    auto nblk = [&](int th, int mt) { return (long)op.B * cdiv(op.Wo, 16) * cdiv(op.Ho, th) * cdiv(gq, mt); };
+    if (op.stride == 2) {          // the stride-2 halo is (2 TH + 1) x 33 pixels: 4-wave tiles are what fits twice in the LDS
+        if (gq >= 4) return launch_conv2_cfg<4, 4, 2>(a, st);
+        if (gq >= 2) return launch_conv2_cfg<2, 4, 2>(a, st);
+        return launch_conv2_cfg<1, 4, 2>(a, st);
+    }
     if (op.reserved & 0xffff) {   // tuning override (profiling): reserved = MT << 8 | WAVES
         switch (op.reserved & 0xffff) {
         case 0x410: return launch_conv2_cfg<4, 16>(a, st);
@@ -203,11 +214,12 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
         case 0x204: return launch_conv2_cfg<2, 4>(a, st);
         case 0x108: return launch_conv2_cfg<1, 8>(a, st);
         case 0x104: return launch_conv2_cfg<1, 4>(a, st);
+        case 0x1: break;           // 1 = auto configuration (used with the ablation bits)
         default: H3D_FAIL(H3D_ERR_ARG, "conv_stream: unknown tuning override %#x", op.reserved);
         }
     }
     if (gq >= 4) {
-        if (op.H % 32 == 0 && nblk(32, 4) >= 256) return launch_conv2_cfg<4, 16>(a, st);   // 16 waves: 32 x 16 px share one weight stream
+        if (op.Ho % 32 == 0 && nblk(32, 4) >= 256) return launch_conv2_cfg<4, 16>(a, st);   // 16 waves: 32 x 16 px share one weight stream
         if (nblk(16, 4) >= 256) return launch_conv2_cfg<4, 8>(a, st);
         return launch_conv2_cfg<4, 4>(a, st);
     }

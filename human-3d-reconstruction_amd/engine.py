@@ -212,11 +212,12 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True):
+    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True, stream_s2=True):
         self.fuse_heads = fuse_heads
         self.fuse_offsets = fuse_offsets
         self.stream_convs = stream_convs
         self.stream_dcn = stream_dcn
+        self.stream_s2 = stream_s2
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -247,9 +248,10 @@ class Plan:
     def conv(self, x, wkey, out=None, bkey=None, bn=None, stride=1, relu=True, res=None, out_mode=_lib.OUT_NHWC,
              pad_cout_to=None, out_tensor=None):
         wshape = self.pw.sd[wkey].shape
-        if (self.stream_convs and self.pw.dtype == "bf16" and stride == 1 and wshape[2] == 3 and wshape[1] % 16 == 0
+        if (self.stream_convs and self.pw.dtype == "bf16" and wshape[2] == 3 and wshape[1] % 16 == 0
+                and (stride == 1 or (stride == 2 and wshape[1] >= 64 and self.stream_s2))
                 and out_mode == _lib.OUT_NHWC and pad_cout_to is None):
-            return self._conv_stream(x, wkey, out, bkey, bn, relu, res)
+            return self._conv_stream(x, wkey, out, bkey, bn, relu, res, stride)
         wp, bp, cout, cin, k, rows = self.pw.conv(wkey, bkey, bn, pad_cout_to)
         assert cin == x.C, (wkey, cin, x.C)
         Ho = (x.H + 2 * (k // 2) - k) // stride + 1
@@ -270,17 +272,18 @@ class Plan:
                  stride=stride, relu=int(relu), out_mode=out_mode, wrows=rows)
         return out
 
-    def _conv_stream(self, x, wkey, out, bkey, bn, relu, res):
-        """3x3 s1 conv through the LDS-DMA kernel (csrc/conv2.hip)."""
+    def _conv_stream(self, x, wkey, out, bkey, bn, relu, res, stride=1):
+        """3x3 conv (stride 1 or 2) through the LDS-DMA kernel (csrc/conv2.hip)."""
         wimg, bp, cout, cin, rows = self.pw.conv_stream(wkey, bkey, bn)
         assert cin == x.C, (wkey, cin, x.C)
+        Ho, Wo = (x.H - 1) // stride + 1, (x.W - 1) // stride + 1
         if out is None:
-            out = self._alloc(x.H, x.W, cout)
-        assert (out.H, out.W, out.C) == (x.H, x.W, cout), (wkey, out.H, out.W, out.C)
+            out = self._alloc(Ho, Wo, cout)
+        assert (out.H, out.W, out.C) == (Ho, Wo, cout), (wkey, out.H, out.W, out.C)
         self._op(_lib.OP_CONV_STREAM, in_=x.ptr, in2=res.ptr if res is not None else None, w=wimg.data_ptr(),
                  bias=bp.data_ptr(), out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs,
-                 in2_cs=res.cs if res is not None else 0, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
-                 stride=1, relu=int(relu), out_mode=_lib.OUT_NHWC, wrows=rows)
+                 in2_cs=res.cs if res is not None else 0, Ho=Ho, Wo=Wo, Cout=cout, out_cs=out.cs, ksize=3,
+                 stride=stride, relu=int(relu), out_mode=_lib.OUT_NHWC, wrows=rows)
         return out
 
     def dcn(self, x, om, wkey, bkey, bn, out=None):
@@ -489,6 +492,7 @@ class DLAEngine:
         self.fuse_offsets = True        # False: conv_offset_mask as its own launch + dcn2_kernel reading NHWC offsets
         self.stream_convs = True        # False: 3x3 s1 convs through the register-staged kernel (csrc/conv.hip)
         self.stream_dcn = True          # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
+        self.stream_s2 = True           # False: stride-2 3x3 convs (Cin >= 64) through csrc/conv.hip
         self.streams = 1                # >1: run that many sub-batches concurrently on their own HIP streams
 
     def plan(self, B, H, W):
@@ -496,7 +500,7 @@ class DLAEngine:
         if key not in self.plans:
             with torch.cuda.device(self.device):
                 self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn)
+                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2)
         return self.plans[key]
 
     def forward(self, images):
@@ -526,7 +530,7 @@ class DLAEngine:
         with torch.cuda.device(self.device):
             if key not in self.plans:
                 plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn)
+                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2)
                          for _ in range(n)]
                 full = {h: torch.empty((B,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
                         for h, o in plans[0].outputs.items()}
