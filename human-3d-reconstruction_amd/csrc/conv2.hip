@@ -30,7 +30,7 @@ struct Conv2Args {
     int dbg;   // ABLATE builds only (op.reserved >> 16): 1 = no DMA after stage 0, 2 = no fragment reads / MFMA
 };
 
-template <int MT, int WAVES, int S = 1>
+template <int MT, int WAVES, int S = 1, int SLOTS = 2>
 struct Conv2Cfg {
     static constexpr int TH = 2 * WAVES;
     static constexpr int HROWS = (TH - 1) * S + 3;      // halo rows
@@ -44,7 +44,9 @@ struct Conv2Cfg {
     static constexpr int WPIECES = (MT * WGRP + 1023) / 1024;
     static constexpr int WALLOC = WPIECES * 1024;
     static constexpr int SLOT = HALO + WALLOC;
-    static constexpr int LDS = 2 * SLOT;
+    static constexpr int LDS_EPI = WAVES * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // tile_epilogue_lds regions
+    static constexpr int LDS_RING = SLOTS * SLOT;   // SLOTS = 1: single-stage layers (Cin = 16) keep more workgroups per CU
+    static constexpr int LDS = LDS_RING > LDS_EPI ? LDS_RING : LDS_EPI;
     static constexpr int THREADS = 64 * WAVES;
     static constexpr int HP = (ROWS + WAVES - 1) / WAVES;       // halo pieces per wave
     static constexpr int WP = (WPIECES + WAVES - 1) / WAVES;    // weight pieces per wave
@@ -75,10 +77,10 @@ __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, cons
     }
 }
 
-template <int MT, int WAVES, int EPI, int S = 1>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
+template <int MT, int WAVES, int EPI, int S = 1, int SLOTS = 2>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
 __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 {
-    using C = Conv2Cfg<MT, WAVES, S>;
+    using C = Conv2Cfg<MT, WAVES, S, SLOTS>;
     using E = ET<bf16_t>;
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
 
@@ -126,9 +128,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     for (int s = 0; s < nst; ++s) {
         __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): my pieces of stage s have landed
         __syncthreads();                          // ... everyone's have; slot (s+1)&1 is no longer being read
-        if (s + 1 < nst && !(H3D_DBG(a) & 1))
+        if (SLOTS > 1 && s + 1 < nst && !(H3D_DBG(a) & 1))
             conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + ((s + 1) & 1) * C::SLOT, hoff, woff, wv, s + 1, ((s + 1) * a.G + g0) * C::WGRP, H3D_DBG(a));
-        const char *sl = smem + (s & 1) * C::SLOT;
+        const char *sl = smem + (SLOTS > 1 ? (s & 1) : 0) * C::SLOT;
         if (H3D_DBG(a) & 2) continue;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -146,7 +148,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2) {
-        static_assert(WAVES * epi_lds_stride<MT>() <= C::LDS, "epilogue tile");
         __syncthreads();                          // nobody reads the ring any more
         tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
     } else {
@@ -154,10 +155,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     }
 }
 
-template <int MT, int WAVES, int S = 1>
+template <int MT, int WAVES, int S = 1, int SLOTS = 2>
 static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
 {
-    using C = Conv2Cfg<MT, WAVES, S>;
+    using C = Conv2Cfg<MT, WAVES, S, SLOTS>;
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     Conv2Args a = a0;
     a.tiles_x = cdiv(a.Wo, 16);
@@ -165,13 +166,13 @@ static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4)) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d>", MT, WAVES, epi, S)) return H3D_OK;
+    if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d, %d>", MT, WAVES, epi, S, SLOTS)) return H3D_OK;
     if (epi == 2)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S, SLOTS>), grid, dim3(C::THREADS), 0, st, a);
     else if (epi == 1)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1, S>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1, S, SLOTS>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0, S>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0, S, SLOTS>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("conv2_kernel");
     return H3D_OK;
 }
@@ -227,6 +228,7 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
         if (nblk(16, 2) >= 256) return launch_conv2_cfg<2, 8>(a, st);
         return launch_conv2_cfg<2, 4>(a, st);
     }
+    if (op.Cin == 16 && nblk(16, 1) >= 256) return launch_conv2_cfg<1, 8, 1, 1>(a, st);   // one stage: no ring
     if (nblk(16, 1) >= 256) return launch_conv2_cfg<1, 8>(a, st);
     return launch_conv2_cfg<1, 4>(a, st);
 }
