@@ -4,7 +4,8 @@
         profiles/r01_pmc_sq_summary.json
 
 Per kernel (mean over its dispatches):
-  mfma_util  = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)   (MFMA pipe busy share, all SIMDs)
+  mfma_util  = SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 1024 SIMDs), cycles = GRBM_GUI_ACTIVE / 8 (the counter is summed
+               over the 8 XCDs: 24.5M for a 1.40 ms launch = 8 x 2.19 GHz)   (MFMA pipe busy share, all SIMDs)
   wait_any / wait_inst / active = share of SQ_WAVE_CYCLES a wave is parked (s_waitcnt, barrier) / stalled at
                issue / issuing (MI355X_MICROARCH.md 'rocprofv3 PMC slots': the three are disjoint)
   valu_per_mfma, lds_per_mfma = instruction mix; lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
@@ -36,7 +37,7 @@ def main():
             continue
         x, y = a.get(k, {}), b.get(k, {})
         wc = x.get("SQ_WAVE_CYCLES", 0.0) or 1.0
-        gui = x.get("GRBM_GUI_ACTIVE", 0.0) or 1.0
+        gui = (x.get("GRBM_GUI_ACTIVE", 0.0) / 8.0) or 1.0
         mf = y.get("SQ_INSTS_MFMA", 0.0)
         res[k] = {
             "gpu_cycles": round(gui),
