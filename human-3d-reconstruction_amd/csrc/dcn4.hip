@@ -13,7 +13,7 @@
 //   filters stream through a two-slot ring in stages of 16 input channels: 4 stages of the 27 (32 rows)
 //           offset/mask filters, then 4 stages of the 32*MT main filters; the host packs both stage-major
 //           in LDS image order (19 slots per row: 2 per tap + 1 pad), so each stage is a linear copy.
-// No staging registers, no ds_write, no address arithmetic inside the loops; one barrier per stage.
+// No staging registers, no ds_write, no address arithmetic inside the loops; six barriers per tile.
 // Phases as in dcn3: A (offset conv) -> geometry (split across half-waves) -> B (gather + fp16 blend +
 // MFMA) -> rare pass 2 for samples whose corners left the apron (global gather).
 #include "common.h"
@@ -41,7 +41,10 @@ struct Dcn4Cfg {
     static constexpr int WPIECES = (MT * WGRP + 1023) / 1024;
     static constexpr int WSLOT = WPIECES * 1024;
     static constexpr int OPIECES = (WGRP + 1023) / 1024;    // offset-filter stage: 10 pieces
-    static constexpr int LDS = APRON + 2 * WSLOT;
+    static constexpr int NSLOT = 3;                    // main-filter ring: stage s+2 is in flight while stage s is consumed
+    static constexpr int OALL = (4 * WGRP + 1023) / 1024;   // all four offset-filter stages at once: 38 pieces
+    static constexpr int RING = (NSLOT * WSLOT > OALL * 1024) ? NSLOT * WSLOT : OALL * 1024;
+    static constexpr int LDS = APRON + RING;
     static constexpr int NSTAGE = 4;                   // 64 input channels / 16
 };
 
@@ -103,22 +106,25 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void4 *)(smem + q * 1024), 16, voff, 0, 0, 0);
         }
     }
-    dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring, 0, woffl, wv);
+    // all four offset-filter stages land in the (still idle) main-filter ring together with the apron: phase A
+    // then runs its 36 MFMAs per wave without a single wait (staged one by one, each 9-MFMA stage exposed a full
+    // DMA round trip: the SQ counters showed the waves parked 52 % of the time)
+    dcn4_issue_w<C::OALL>(a.woff, off_bytes, s_ring, 0, woffl, wv);
 
-    // ================= phase A: offsets/mask = conv3x3(x; 27 filters), 4 stages of 16 channels =========
-    f32x16 aoffs;
+    // ================= phase A: offsets/mask = conv3x3(x; 27 filters) ==================================
+    f32x16 aoffs;                                 // accumulators start at the (permuted) offset bias: its loads retire with the
+    {                                             // apron, not between the main-filter DMAs and their first use
+        const float *bo = a.bias + a.wrows;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) aoffs[i] = 0.f;
+        for (int i = 0; i < 16; ++i) aoffs[i] = bo[(i & 3) + 8 * (i >> 2) + 4 * h];
+    }
     const int bconv = (C::MARGIN + py) * C::ROWB + (C::MARGIN + px) * C::PXB + h * 16;
     const int aoff = r * C::WROW + h * 16;
+    __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0)
+    __syncthreads();
+#pragma unroll
     for (int s = 0; s < C::NSTAGE; ++s) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0)
-        __syncthreads();
-        if (s + 1 < C::NSTAGE)
-            dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring + ((s + 1) & 1) * C::WSLOT, (s + 1) * C::WGRP, woffl, wv);
-        else
-            dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + ((s + 1) & 1) * C::WSLOT, g0 * C::WGRP, woffl, wv);
-        const char *sw = s_ring + (s & 1) * C::WSLOT;
+        const char *sw = s_ring + s * C::WGRP;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
@@ -127,11 +133,9 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
             X::mma(aoffs, fa, fb);
         }
     }
-    {
-        const float *bo = a.bias + a.wrows;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
-    }
+    __syncthreads();                              // the ring is free: main stages 0 and 1 fly while the geometry is computed
+    dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring, g0 * C::WGRP, woffl, wv);
+    dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + C::WSLOT, (a.G + g0) * C::WGRP, woffl, wv);
 
     // ================= geometry (branch free): my taps (h=0: 0..4, h=1: 5..8), cross-half exchange ====
     int boff[9];
@@ -183,26 +187,38 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
+#pragma unroll
     for (int s = 0; s < C::NSTAGE; ++s) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);
+        // stage s has landed once at most the pieces of stage s+1 are outstanding: every wave issues at least
+        // PMIN pieces per stage and vmcnt retires in order, so vmcnt(PMIN) is safe for all waves
+        constexpr int PMIN = C::WPIECES / 8;
+        static_assert(PMIN >= 1 && PMIN <= 15, "vmcnt immediate");
+        if (s + 1 < C::NSTAGE) __builtin_amdgcn_s_waitcnt(0x0f70 | PMIN);
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
-        if (s + 1 < C::NSTAGE)
-            dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + ((s + 1) & 1) * C::WSLOT, ((s + 1) * a.G + g0) * C::WGRP, woffl, wv);
-        const char *sw = s_ring + (s & 1) * C::WSLOT;           // global stage 4 + s lives in slot (4 + s) & 1
+        if (s + 2 < C::NSTAGE)
+            dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + ((s + 2) % C::NSLOT) * C::WSLOT, ((s + 2) * a.G + g0) * C::WGRP, woffl, wv);
+        const char *sw = s_ring + (s % C::NSLOT) * C::WSLOT;
+        // software pipeline: tap t+1's four corner fragments and filter fragments are in flight while tap t is
+        // blended and multiplied (2 waves per SIMD cannot hide the LDS latency by themselves: the SQ counters
+        // showed the waves parked on s_waitcnt half of the time)
+        typename X::frag v[2][4], fa[2][MT];
+        auto gather = [&](int tap, int buf) {
+            const char *p00 = smem + boff[tap] + s * 32;
+            v[buf][0] = X::lds(p00);
+            v[buf][1] = X::lds(p00 + C::PXB);
+            v[buf][2] = X::lds(p00 + C::ROWB);
+            v[buf][3] = X::lds(p00 + C::ROWB + C::PXB);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) fa[buf][m] = X::lds(sw + aoff + m * C::WGRP + tap * 32);
+        };
+        gather(0, 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const char *p00 = smem + boff[tap] + s * 32;
-            typename X::frag v[4];
-            v[0] = X::lds(p00);
-            v[1] = X::lds(p00 + C::PXB);
-            v[2] = X::lds(p00 + C::ROWB);
-            v[3] = X::lds(p00 + C::ROWB + C::PXB);
-            const typename X::frag fb = X::blend(v, geo[tap]);
-            typename X::frag fa[MT];
+            if (tap + 1 < 9) gather(tap + 1, (tap + 1) & 1);
+            const typename X::frag fb = X::blend(v[tap & 1], geo[tap]);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) fa[m] = X::lds(sw + aoff + m * C::WGRP + tap * 32);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb);
+            for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[tap & 1][m], fb);
         }
     }
 
