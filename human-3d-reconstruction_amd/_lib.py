@@ -46,6 +46,8 @@ class H3dHeadsDesc(ctypes.Structure):
 # name -> argtypes (restype is int unless noted); also the export list the CPU test checks
 SIGNATURES = {
     "h3d_dcn_v2_forward": [c_vp] * 6 + [c_i] * 14 + [c_vp],
+    "h3d_smpl_coef_pack": [c_vp, c_vp, c_i, c_i, c_vp, c_vp],
+    "h3d_smpl_verts3": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],
     "h3d_preprocess": [c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "h3d_run_ops": [ctypes.POINTER(H3dOp), c_i, c_vp],
     "h3d_run_ops_timed": [ctypes.POINTER(H3dOp), c_i, c_vp, c_vp],

@@ -124,13 +124,27 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
 
-    conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem, hoff, woff, wv, 0, g0 * C::WGRP, H3D_DBG(a));
+    // ring of SLOTS stages: stage s + SLOTS - 1 is issued when stage s starts, so a stage has SLOTS - 1 stages of
+    // MFMA time to land (with 2 slots the SQ counters showed the waves parked ~48 % of the time)
+    constexpr int AHEAD = SLOTS > 1 ? SLOTS - 1 : 1;
+    constexpr int PMIN = C::ROWS / WAVES + C::WPIECES / WAVES;     // fewest DMA instructions any wave issues per stage
+    static_assert(AHEAD <= 2 && PMIN <= 63, "counted vmcnt wait");
+    constexpr int WAIT_PMIN = 0x0f70 | (PMIN & 15) | ((PMIN >> 4) << 14);     // s_waitcnt vmcnt(PMIN): 6-bit field, split
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j)
+        if (j < nst && (SLOTS > 1 || j == 0))
+            conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + j * C::SLOT, hoff, woff, wv, j, (j * a.G + g0) * C::WGRP, H3D_DBG(a));
+    int cslot = 0, pslot = AHEAD % SLOTS;          // slot consumed by stage s / filled with stage s + AHEAD
     for (int s = 0; s < nst; ++s) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): my pieces of stage s have landed
-        __syncthreads();                          // ... everyone's have; slot (s+1)&1 is no longer being read
-        if (SLOTS > 1 && s + 1 < nst && !(H3D_DBG(a) & 1))
-            conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + ((s + 1) & 1) * C::SLOT, hoff, woff, wv, s + 1, ((s + 1) * a.G + g0) * C::WGRP, H3D_DBG(a));
-        const char *sl = smem + (SLOTS > 1 ? (s & 1) : 0) * C::SLOT;
+        // my pieces of stage s have landed once only stage s+1's may be outstanding (vmcnt retires in order)
+        if (AHEAD == 2 && s + 1 < nst) __builtin_amdgcn_s_waitcnt(WAIT_PMIN);
+        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();                          // ... everyone's have; the slot of stage s-1 is no longer being read
+        if (SLOTS > 1 && s + AHEAD < nst && !(H3D_DBG(a) & 1))
+            conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + pslot * C::SLOT, hoff, woff, wv, s + AHEAD, ((s + AHEAD) * a.G + g0) * C::WGRP, H3D_DBG(a));
+        const char *sl = smem + cslot * C::SLOT;
+        cslot = cslot + 1 == SLOTS ? 0 : cslot + 1;
+        pslot = pslot + 1 == SLOTS ? 0 : pslot + 1;
         if (H3D_DBG(a) & 2) continue;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -215,6 +229,9 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
         case 0x204: return launch_conv2_cfg<2, 4>(a, st);
         case 0x108: return launch_conv2_cfg<1, 8>(a, st);
         case 0x104: return launch_conv2_cfg<1, 4>(a, st);
+        case 0x3208: return launch_conv2_cfg<2, 8, 1, 3>(a, st);      // 0x3...: three ring slots
+        case 0x3108: return launch_conv2_cfg<1, 8, 1, 3>(a, st);
+        case 0x3404: return launch_conv2_cfg<4, 4, 1, 3>(a, st);
         case 0x1: break;           // 1 = auto configuration (used with the ablation bits)
         default: H3D_FAIL(H3D_ERR_ARG, "conv_stream: unknown tuning override %#x", op.reserved);
         }

@@ -403,3 +403,252 @@ extern "C" int h3d_smpl_verts(const float *betas, const float *pose_feat, const 
     H3D_CHECK_LAUNCH("smpl_verts_kernel");
     return H3D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Generation 3 of the vertex kernel: the blend-shape contraction on the matrix cores.
+// Gen 2 runs its 57 GFLOP (batch 6400) on the vector ALU at ~40 % of the packed-FMA peak.  The fp32 matrix
+// instruction has the same peak as the vector ALU (64 FLOP/clk/SIMD: a first version on v_mfma_f32_32x32x2_f32
+// took 1.0 ms against gen 2's 0.9), so the [3*V x 217] x [217 x P] product runs on the bf16 pipe (16x that
+// rate) with every fp32 operand split into three bf16 terms x = h + m + l (exact to 24 significant bits) and the
+// six products that matter (hh, hm, mh, mm, hl, lh; the dropped ones are <= 2^-24 relative) accumulated in fp32:
+// fp32-level accuracy (tests: 2e-6 against gen 2, 1e-4 against the fp64 oracle) at 6/16 of the fp32 cost.
+//   operands   K padded to 224 = 14 steps of 16; per row and step the three bf16 terms sit side by side
+//              ([16 h][16 m][16 l] = 96 B): dirsK3 [3][Vpad][14][3][16] (host pack), coefK3 [Ppad][14][3][16]
+//              (h3d_smpl_coef_pack).  One step per stage streams through a 2-slot LDS ring by LDS-DMA; row stride
+//              112 B (96 + 16 pad: odd multiple of 16 B, conflict-free ds_read_b128); one barrier per 36 MFMAs.
+//   workgroup  64 vertices x 128 persons, wave w = persons [32w, 32w+32) x 64 vertices x 3 coordinates
+//              (6 accumulator tiles).
+//   skinning   gen 2's 4-sparse LBS with lane = vertex: the accumulators (lane = person in the MFMA C layout)
+//              are transposed through LDS 8 persons at a time (person stride 193 dwords), so the transforms are
+//              broadcast-friendly reads and every person's 64 vertices leave as one contiguous 768-byte run.
+//              70 KB of LDS: two workgroups per CU, one's skinning overlaps the other's MFMAs.
+constexpr int S3_KP = 224, S3_NST = S3_KP / 16, S3_VT = 64, S3_PB = 128;
+constexpr int S3_SPR = 7;                                     // 16-byte slots per row and stage: 6 data + 1 pad
+constexpr int S3_ROWB = S3_SPR * 16;                          // 112
+constexpr int S3_GROW = S3_NST * 96;                          // bytes of a row in global memory: 1344
+constexpr int S3_APIECES = 3 * S3_VT * S3_SPR / 64;           // 21 KiB pieces of direction rows
+constexpr int S3_BPIECES = S3_PB * S3_SPR / 64;               // 14 of coefficient rows
+constexpr int S3_SLOT = (S3_APIECES + S3_BPIECES) * 1024;     // 35840
+constexpr int S3_RP = 8;                                      // persons per skinning round and wave
+constexpr int S3_TSTRIDE = 193 * 4;                           // transposed tile: bytes per person (64 v x 3 floats + 1)
+constexpr int S3_LBS = 4 * S3_RP * S3_TSTRIDE + 4 * S3_RP * SMPL_J * 12 * 4;   // 24704 + 36864
+constexpr int S3_LDS = 2 * S3_SLOT > S3_LBS ? 2 * S3_SLOT : S3_LBS;
+
+__device__ __forceinline__ void s3_issue(const char *dirsK, int dbytes, const char *coefK, int cbytes, char *slot,
+                                         const int *aoff, const int *boff, int wv, int st)
+{
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc((void *)dirsK, 0, dbytes, 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void *)coefK, 0, cbytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < (S3_APIECES + 3) / 4; ++j) {
+        const int p = wv + 4 * j;
+        if (p < S3_APIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void *)(slot + p * 1024), 16, aoff[j], st * 96,
+                                                     0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < (S3_BPIECES + 3) / 4; ++j) {
+        const int p = wv + 4 * j;
+        if (p < S3_BPIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(slot + (S3_APIECES + p) * 1024), 16,
+                                                     boff[j], st * 96, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restrict__ coefK3, const float *__restrict__ A,
+                                                          const float *__restrict__ v_template,
+                                                          const bf16_t *__restrict__ dirsK3, const int32_t *__restrict__ lbs_idx,
+                                                          const float *__restrict__ lbs_w, int nnz, int P, int Ppad, int V,
+                                                          int Vpad, float *__restrict__ verts)
+{
+    using E = ET<bf16_t>;
+    __shared__ __attribute__((aligned(1024))) char smem[S3_LDS];
+    const int tid = threadIdx.x, l = tid & 63, r = l & 31, h = l >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int v0 = blockIdx.x * S3_VT, p0 = blockIdx.y * S3_PB;
+
+    // per-lane DMA source offsets (stage 0) of my pieces: slot q -> row q / 7, 16-byte column q % 7 (6 = pad)
+    int aoff[(S3_APIECES + 3) / 4], boff[(S3_BPIECES + 3) / 4];
+#pragma unroll
+    for (int j = 0; j < (S3_APIECES + 3) / 4; ++j) {
+        const int q = (wv + 4 * j) * 64 + l;
+        const int row = q / S3_SPR, sub = q - S3_SPR * row;           // row = c * 64 + v
+        const int c = row >> 6, v = row & 63;
+        aoff[j] = (sub < S3_SPR - 1 && row < 3 * S3_VT) ? (c * Vpad + v0 + v) * S3_GROW + sub * 16 : 0x7ffffff0;
+    }
+#pragma unroll
+    for (int j = 0; j < (S3_BPIECES + 3) / 4; ++j) {
+        const int q = (wv + 4 * j) * 64 + l;
+        const int row = q / S3_SPR, sub = q - S3_SPR * row;           // row = person inside the workgroup
+        boff[j] = (sub < S3_SPR - 1 && row < S3_PB) ? (p0 + row) * S3_GROW + sub * 16 : 0x7ffffff0;
+    }
+    const int dbytes = 3 * Vpad * S3_GROW, cbytes = Ppad * S3_GROW;
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[c][t][i] = 0.f;
+
+    s3_issue((const char *)dirsK3, dbytes, (const char *)coefK3, cbytes, smem, aoff, boff, wv, 0);
+    const int fa_off = r * S3_ROWB + h * 16;                                   // + (c * 64 + t * 32) rows, + part * 32
+    const int fb_off = S3_APIECES * 1024 + (wv * 32 + r) * S3_ROWB + h * 16;
+    for (int st = 0; st < S3_NST; ++st) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (st + 1 < S3_NST)
+            s3_issue((const char *)dirsK3, dbytes, (const char *)coefK3, cbytes, smem + ((st + 1) & 1) * S3_SLOT, aoff, boff, wv, st + 1);
+        const char *sl = smem + (st & 1) * S3_SLOT;
+        const E::frag bh = E::lds_frag(sl + fb_off), bm = E::lds_frag(sl + fb_off + 32), bl = E::lds_frag(sl + fb_off + 64);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const char *ap = sl + fa_off + (c * 64 + t * 32) * S3_ROWB;
+                const E::frag ah = E::lds_frag(ap), am = E::lds_frag(ap + 32), al = E::lds_frag(ap + 64);
+                E::mma(acc[c][t], al, bh);          // smallest terms first
+                E::mma(acc[c][t], ah, bl);
+                E::mma(acc[c][t], am, bm);
+                E::mma(acc[c][t], am, bh);
+                E::mma(acc[c][t], ah, bm);
+                E::mma(acc[c][t], ah, bh);
+            }
+    }
+    __syncthreads();                                   // the ring is free: it becomes the transpose + transform staging area
+#ifdef H3D_ABLATE
+    if (nnz & 0x100) {      // ablation: contraction only
+        if (acc[0][0][0] == 12345.678f) verts[0] = acc[1][1][3] + acc[2][0][5] + acc[0][1][7] + acc[1][0][2] + acc[2][1][9];
+        return;
+    }
+    nnz &= 0xff;
+#endif
+
+    // ---- skinning, lane = vertex (as gen 2): four rounds of 8 persons per wave -------------------------
+    const int v = v0 + l;
+    const int vc = v < V ? v : V - 1;
+    int jidx[4];
+    float jw[4];
+#pragma unroll
+    for (int sI = 0; sI < 4; ++sI) {
+        jidx[sI] = sI < nnz ? lbs_idx[(size_t)vc * nnz + sI] : 0;
+        jw[sI] = sI < nnz ? lbs_w[(size_t)vc * nnz + sI] : 0.f;
+    }
+    const float t0 = v_template[vc], t1 = v_template[Vpad + vc], t2 = v_template[2 * Vpad + vc];
+    char *sT = smem + wv * (S3_RP * S3_TSTRIDE);                                // [8 persons][64 v][3] (+1)
+    float *sA = reinterpret_cast<float *>(smem + 4 * S3_RP * S3_TSTRIDE) + wv * (S3_RP * SMPL_J * 12);
+#pragma unroll
+    for (int rnd = 0; rnd < 32 / S3_RP; ++rnd) {
+        if (rnd) __syncthreads();
+        // (a) my accumulators of persons [8 rnd, 8 rnd + 8): C layout row = vertex, column = person
+        if ((r / S3_RP) == rnd) {
+            const int pl = r % S3_RP;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int vl = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        *reinterpret_cast<float *>(sT + pl * S3_TSTRIDE + (vl * 3 + c) * 4) = acc[c][t][i];
+                    }
+        }
+        // (b) the 3x4 transforms of those 8 persons: [8][288] floats = 576 float4, 9 per lane
+        for (int i = l; i < S3_RP * SMPL_J * 3; i += 64) {
+            const int q = i / (SMPL_J * 3), rr = i - q * (SMPL_J * 3);
+            const int p = p0 + wv * 32 + rnd * S3_RP + q;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (p < P) val = *reinterpret_cast<const f32x4 *>(A + (size_t)p * SMPL_J * 12 + 4 * rr);
+            *reinterpret_cast<f32x4 *>(sA + q * SMPL_J * 12 + 4 * rr) = val;
+        }
+        __syncthreads();
+        // (c) lane = vertex
+#pragma unroll 4
+        for (int q = 0; q < S3_RP; ++q) {
+            const int p = p0 + wv * 32 + rnd * S3_RP + q;
+            float T[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = 0.f;
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) {
+                const float *Ap = sA + q * SMPL_J * 12 + jidx[sI] * 12;
+#pragma unroll
+                for (int i4 = 0; i4 < 3; ++i4) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(Ap + 4 * i4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) T[4 * i4 + e] = fmaf(jw[sI], a4[e], T[4 * i4 + e]);
+                }
+            }
+            const float *xyz = reinterpret_cast<const float *>(sT + q * S3_TSTRIDE + l * 12);
+            const float x = t0 + xyz[0], y = t1 + xyz[1], z = t2 + xyz[2];
+            if (v < V && p < P) {
+                typedef __attribute__((ext_vector_type(3))) float f32x3;     // one 12-byte store per lane
+                const f32x3 o3 = {T[0] * x + T[1] * y + T[2] * z + T[3], T[4] * x + T[5] * y + T[6] * z + T[7],
+                                  T[8] * x + T[9] * y + T[10] * z + T[11]};
+                __builtin_memcpy(verts + ((size_t)p * V + v) * 3, &o3, 12);
+            }
+        }
+    }
+}
+
+// three-term bf16 split of an fp32 value: x = h + m + l up to 2^-24 relative (round-to-nearest-even at each step)
+__device__ __forceinline__ void split3(float x, bf16_t &hh, bf16_t &mm, bf16_t &ll)
+{
+    hh = ET<bf16_t>::from_f32(x);
+    const float r1 = x - ET<bf16_t>::to_f32(hh);
+    mm = ET<bf16_t>::from_f32(r1);
+    const float r2 = r1 - ET<bf16_t>::to_f32(mm);
+    ll = ET<bf16_t>::from_f32(r2);
+}
+
+// coefK3 [Ppad][14][3][16] bf16: per person and K step the h / m / l terms of [beta | pose_feat | 0]; zero rows for p >= P
+__global__ void smpl_coef_pack_kernel(const float *__restrict__ betas, const float *__restrict__ pose_feat, int P, int Ppad,
+                                      bf16_t *__restrict__ coefK3)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Ppad * S3_KP) return;
+    const int p = (int)(i / S3_KP), k = (int)(i - (size_t)p * S3_KP);
+    float v = 0.f;
+    if (p < P) {
+        if (k < SMPL_NB) v = betas[(size_t)p * SMPL_NB + k];
+        else if (k < SMPL_NB + SMPL_PF) v = pose_feat[(size_t)p * SMPL_PF + (k - SMPL_NB)];
+    }
+    bf16_t hh, mm, ll;
+    split3(v, hh, mm, ll);
+    bf16_t *o = coefK3 + ((size_t)p * S3_NST + (k >> 4)) * 48 + (k & 15);
+    o[0] = hh; o[16] = mm; o[32] = ll;
+}
+
+extern "C" int h3d_smpl_coef_pack(const float *betas, const float *pose_feat, int P, int Ppad, void *coefK3, void *stream)
+{
+    if (!betas || !pose_feat || !coefK3) H3D_FAIL(H3D_ERR_ARG, "smpl_coef_pack: null pointer");
+    if (P <= 0 || Ppad < P || Ppad % S3_PB) H3D_FAIL(H3D_ERR_SHAPE, "smpl_coef_pack: P=%d Ppad=%d (multiple of %d)", P, Ppad, S3_PB);
+    const size_t n = (size_t)Ppad * S3_KP;
+    hipLaunchKernelGGL(smpl_coef_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, betas, pose_feat, P,
+                       Ppad, (bf16_t *)coefK3);
+    H3D_CHECK_LAUNCH("smpl_coef_pack_kernel");
+    return H3D_OK;
+}
+
+extern "C" int h3d_smpl_verts3(const void *coefK3, const float *A, const float *v_template, const void *dirsK3,
+                               const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad,
+                               float *verts, void *stream)
+{
+    if (!coefK3 || !A || !v_template || !dirsK3 || !lbs_idx || !lbs_w || !verts) H3D_FAIL(H3D_ERR_ARG, "smpl_verts3: null pointer");
+#ifdef H3D_ABLATE
+    const int nnz_flags = getenv("H3D_SMPL_ABLATE") ? 0x100 : 0;
+#else
+    const int nnz_flags = 0;
+#endif
+    if (P <= 0 || V <= 0 || nnz <= 0 || nnz > 4 || Ppad % S3_PB || Ppad < P || Vpad % S3_VT || Vpad < V)
+        H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts3: P=%d (pad %d, multiple of %d) V=%d (pad %d, multiple of %d) nnz=%d (<= 4)", P, Ppad,
+                 S3_PB, V, Vpad, S3_VT, nnz);
+    if ((size_t)3 * Vpad * S3_GROW >= 0x7ffffff0ull || (size_t)Ppad * S3_GROW >= 0x7ffffff0ull)
+        H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts3: operand of 2 GiB or more");
+    dim3 grid(Vpad / S3_VT, Ppad / S3_PB);
+    hipLaunchKernelGGL(smpl_verts3_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)coefK3, A, v_template,
+                       (const bf16_t *)dirsK3, lbs_idx, lbs_w, nnz | nnz_flags, P, Ppad, V, Vpad, verts);
+    H3D_CHECK_LAUNCH("smpl_verts3_kernel");
+    return H3D_OK;
+}

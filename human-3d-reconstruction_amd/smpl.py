@@ -100,13 +100,32 @@ def _device_pack(model, device, nnz=None):
         "j_shapedirs": to(j_dirs.reshape(NUM_JOINTS * 3, NUM_BETAS)),
         "parents": to(model.parents.astype(np.int32)),
         "lbs_idx": to(order), "lbs_w": to(wsel),
+        # generation 3 (MFMA): K-contiguous direction rows [10 shape | 207 pose | 0], each value as three bf16 terms
+        "dirsK3": _dirs_k3(model, Vpad, device),
     }
+
+
+def _dirs_k3(model, Vpad, device, KP=224):
+    """[3][Vpad][KP/16][3 terms][16] bf16: x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)
+    (round-to-nearest-even; exact to 24 significant bits) -- the operand format of csrc/smpl.hip smpl_verts3."""
+    import torch
+    V = model.v_template.shape[0]
+    d = np.zeros((3, Vpad, KP), np.float32)
+    d[:, :V, :NUM_BETAS] = model.shapedirs.transpose(1, 0, 2)                      # [V,3,10] -> [3,V,10]
+    d[:, :V, NUM_BETAS:NUM_BETAS + NUM_POSE_FEAT] = model.posedirs.transpose(1, 0, 2)
+    x = torch.from_numpy(d)
+    h = x.to(torch.bfloat16)
+    r1 = x - h.float()
+    m = r1.to(torch.bfloat16)
+    lo = (r1 - m.float()).to(torch.bfloat16)
+    out = torch.stack([t.reshape(3, Vpad, KP // 16, 16) for t in (h, m, lo)], dim=3)     # [3][Vpad][14][3][16]
+    return out.contiguous().to(device)
 
 
 def lbs(model, betas, thetas, return_joints=False, kernel="auto"):
     """betas [P,10], thetas [P,72] (CUDA fp32) -> vertices [P,V,3] (and posed joints [P,24,3]).
-    kernel: "gen2" = LDS-streamed kernel (needs <= 4 skinning weights per vertex), "gen1" = register
-    kernel, "auto" = gen2 when applicable and P >= 64."""
+    kernel: "gen3" = blend shapes on the matrix cores (3-term bf16 split, fp32-level accuracy), "gen2" = LDS-streamed vector kernel (both need
+    <= 4 skinning weights per vertex), "gen1" = register kernel, "auto" = gen3 when applicable and P >= 64."""
     import torch
     from . import _lib
     _lib.require_cuda(betas, thetas)
@@ -122,14 +141,21 @@ def lbs(model, betas, thetas, return_joints=False, kernel="auto"):
     joints = torch.empty(P, NUM_JOINTS, 3, dtype=torch.float32, device=dev)
     verts = torch.empty(P, d["V"], 3, dtype=torch.float32, device=dev)
     L, st = _lib.lib(), _lib.stream_ptr()
-    gen2 = kernel == "gen2" or (kernel == "auto" and d["nnz"] <= 4 and P >= 64)
+    gen3 = kernel == "gen3" or (kernel == "auto" and d["nnz"] <= 4 and P >= 64)
+    gen2 = kernel == "gen2"
     Ppad = ((P + 127) // 128) * 128
     coefT = torch.zeros(NUM_BETAS + NUM_POSE_FEAT, Ppad, dtype=torch.float32, device=dev) if gen2 else None
     with torch.cuda.device(dev):
         _lib.check(L.h3d_smpl_pose(_lib.ptr(betas), _lib.ptr(thetas), _lib.ptr(d["j_template"]),
                                    _lib.ptr(d["j_shapedirs"]), _lib.ptr(d["parents"]), P, _lib.ptr(pf),
                                    _lib.ptr(A), _lib.ptr(joints), _lib.ptr(coefT), Ppad, st), "smpl_pose")
-        if gen2:
+        if gen3:
+            coefK = torch.empty(Ppad, 14, 3, 16, dtype=torch.bfloat16, device=dev)
+            _lib.check(L.h3d_smpl_coef_pack(_lib.ptr(betas), _lib.ptr(pf), P, Ppad, _lib.ptr(coefK), st), "smpl_coef_pack")
+            _lib.check(L.h3d_smpl_verts3(_lib.ptr(coefK), _lib.ptr(A), _lib.ptr(d["v_template"]), _lib.ptr(d["dirsK3"]),
+                                         _lib.ptr(d["lbs_idx"]), _lib.ptr(d["lbs_w"]), d["nnz"], P, Ppad, d["V"], d["Vpad"],
+                                         _lib.ptr(verts), st), "smpl_verts3")
+        elif gen2:
             _lib.check(L.h3d_smpl_verts2(_lib.ptr(coefT), _lib.ptr(A), _lib.ptr(d["v_template"]),
                                          _lib.ptr(d["shapedirsT"]), _lib.ptr(d["posedirsT"]), _lib.ptr(d["lbs_idx"]),
                                          _lib.ptr(d["lbs_w"]), d["nnz"], P, Ppad, d["V"], d["Vpad"], _lib.ptr(verts), st),

@@ -222,6 +222,15 @@ int h3d_multi_pose_post_process(const float *dets, const float *c, const float *
 int h3d_smpl_pose(const float *betas, const float *thetas, const float *j_template,
                   const float *j_shapedirs, const int32_t *parents, int P,
                   float *pose_feat, float *A, float *joints, float *coefT, int Ppad, void *stream);
+/* generation 3: blend shapes on the bf16 matrix cores with every fp32 operand split into three bf16 terms
+ * (fp32-level accuracy, csrc/smpl.hip).  coefK3 [Ppad][14][3][16] bf16 = per person and K step of 16 the h/m/l terms
+ * of [beta | pose_feat | 0] (h3d_smpl_coef_pack; Ppad multiple of 128), dirsK3 [3][Vpad][14][3][16] bf16 = the same
+ * split of the K-contiguous direction rows (10 shape + 207 pose, zero padded to 224; Vpad multiple of 64;
+ * h3d_amd/smpl.py: _dirs_k3), A from h3d_smpl_pose, <= 4 skinning weights per vertex. */
+int h3d_smpl_coef_pack(const float *betas, const float *pose_feat, int P, int Ppad, void *coefK3, void *stream);
+int h3d_smpl_verts3(const void *coefK3, const float *A, const float *v_template, const void *dirsK3,
+                    const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad,
+                    float *verts, void *stream);
 /* blend shapes + LBS: verts [P,V,3].  Model tensors struct-of-arrays with row stride Vpad:
  * v_template [3][Vpad], shapedirsT [10][3][Vpad], posedirsT [207][3][Vpad]. */
 int h3d_smpl_verts(const float *betas, const float *pose_feat, const float *A,

@@ -22,7 +22,7 @@ for rep in range(2):
     for cfg in cfgs:
         for i in idx:
             op = plan.ops[i]
-            mt = (cfg & 0xffff) >> 8
+            mt = ((cfg & 0xfff) >> 8)
             plan.op_array[i].reserved = cfg if (cfg == 0 or (op.Cout + 31) // 32 >= mt) else 0
         tot = np.zeros(n)
         for _ in range(3):
