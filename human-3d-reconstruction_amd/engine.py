@@ -212,12 +212,13 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True, stream_s2=True):
+    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True, stream_s2=True, wide_heads_m2=0):
         self.fuse_heads = fuse_heads
         self.fuse_offsets = fuse_offsets
         self.stream_convs = stream_convs
         self.stream_dcn = stream_dcn
         self.stream_s2 = stream_s2
+        self.wide_heads_m2 = wide_heads_m2
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -424,7 +425,8 @@ class Plan:
             # narrow heads do not inherit the register footprint of the 72-channel pose head
             groups = {}
             for head, c in self.pw.heads.items():
-                groups.setdefault((c + 31) // 32, []).append(head)
+                m2 = (c + 31) // 32
+                groups.setdefault(1 if m2 == 1 else self.wide_heads_m2 or m2, []).append(head)
             for m2 in sorted(groups):
                 w1, b1, per = self.pw.fused_heads(tuple(groups[m2]))
                 desc = _lib.H3dHeadsDesc()
@@ -493,6 +495,7 @@ class DLAEngine:
         self.stream_convs = True        # False: 3x3 s1 convs through the register-staged kernel (csrc/conv.hip)
         self.stream_dcn = True          # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
         self.stream_s2 = True           # False: stride-2 3x3 convs (Cin >= 64) through csrc/conv.hip
+        self.wide_heads_m2 = 0          # 3: heads wider than 32 channels share one launch (3 output row tiles each)
         self.streams = 1                # >1: run that many sub-batches concurrently on their own HIP streams
 
     def plan(self, B, H, W):
@@ -500,7 +503,7 @@ class DLAEngine:
         if key not in self.plans:
             with torch.cuda.device(self.device):
                 self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2)
+                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2)
         return self.plans[key]
 
     def forward(self, images):
@@ -530,7 +533,7 @@ class DLAEngine:
         with torch.cuda.device(self.device):
             if key not in self.plans:
                 plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2)
+                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2)
                          for _ in range(n)]
                 full = {h: torch.empty((B,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
                         for h, o in plans[0].outputs.items()}
