@@ -54,7 +54,8 @@ struct HeadsCfg {
     static constexpr int SLOT = TAPS * HC_SLAB * RBW; // ring slot bytes
     static constexpr int LDS_IN = IN_H * RB;
     static constexpr int LDS_W2 = 32 * HC_MT2 * RBW;  // 96 rows
-    static constexpr int LDS = LDS_IN + 2 * SLOT + LDS_W2;
+    static constexpr int LDS_BIAS = 1024 + 1024;      // per head: b1 (<= 256 floats) + b2 (96 floats; its DMA piece writes a whole KiB), two heads in flight
+    static constexpr int LDS = LDS_IN + 2 * SLOT + LDS_W2 + 2 * LDS_BIAS;
     static constexpr int RPI = 1024 / RBW;            // weight rows per LDS-DMA wave-instruction
     static constexpr int VPR = HC_IN * ES / 16;       // 16-byte vectors per halo pixel
 };
@@ -65,12 +66,26 @@ __device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base)
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// Biases of one head -> LDS by LDS-DMA (wave 0: b1[head_conv] <= 1 KiB, wave 1: b2[96]); lanes past the end of either
+// array carry offsets outside the buffer and write zeros.  Reading them from global memory where they are used put
+// a full memory round trip at the end of every slab and before every group of output stores.
+__device__ __forceinline__ void heads_issue_bias(const float *b1, int hc, const float *b2, char *dst, int wv, int l)
+{
+    if (wv == 0) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)b1, 0, hc * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, l * 16, 0, 0, 0);
+    } else if (wv == 1) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)b2, 0, 96 * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + 1024), 16, l * 16 < 512 ? l * 16 : 0x7ffffff0, 0, 0, 0);
+    }
+}
+
 // Second contraction of a head: acc2[m2] += W2[rows of tile m2][slab K] . ReLU(acc + b1), then acc = 0.
 // The accumulator registers 8s..8s+7 of a 32x32 tile are K-step s of the B operand (lane = pixel);
 // the matching A fragment (K in accumulator-row order) sits at K offset m*32 + h*16 + s*8 of the
 // host-permuted W2 row (swizzled LDS image, see HeadsCfg).
 template <typename T, int TH, int NT, int M2>
-__device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][NT], const float *__restrict__ b1,
+__device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][NT], const char *s_b1 /* LDS: this slab's 64 b1 */,
                                       const char *s_w2, int r, int h, int sw)
 {
     using C = HeadsCfg<T, TH>;
@@ -81,12 +96,10 @@ __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][N
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
             typename E::frag fb[NT];
-            float bias[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = 8 * sb + j;
-                bias[j] = b1[m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
-            }
+            // accumulator registers 8sb..8sb+7 hold channels m*32 + 16sb + 4h + {0..3} and + 8 + {0..3}
+            const f32x4 b_lo = *reinterpret_cast<const f32x4 *>(s_b1 + (m * 32 + 16 * sb + 4 * h) * 4);
+            const f32x4 b_hi = *reinterpret_cast<const f32x4 *>(s_b1 + (m * 32 + 16 * sb + 4 * h + 8) * 4);
+            const float bias[8] = {b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 float x[8];
@@ -126,6 +139,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     char *s_in = smem;
     char *s_ring = smem + C::LDS_IN;
     char *s_w2 = s_ring + 2 * C::SLOT;
+    char *s_bias = s_w2 + C::LDS_W2;
 
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
@@ -174,6 +188,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 
     // ---- prologue: stage 0 weights in flight, halo tile (all 64 channels, zero outside the image) -----
     issue_w1(0);
+    heads_issue_bias(a.b1, a.head_conv, a.b2[0], s_bias, __builtin_amdgcn_readfirstlane(wv), l);
     {
         const size_t in_img = (size_t)b * a.H * a.W;
         constexpr int NHV = C::IN_H * C::IN_W * C::VPR;
@@ -210,6 +225,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 
     int s = 0;
     for (int head = 0; head < a.nheads; ++head) {
+        const char *s_b = s_bias + (head & 1) * C::LDS_BIAS;
         f32x16 acc[2][NT], acc2[M2][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -228,6 +244,9 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
             for (int tr = 0; tr < C::TRS; ++tr, ++s) {
                 if (s + 1 < nstages) issue_w1(s + 1);          // slot (s+1)&1 was last read in stage s-1
                 if (tr == (C::TRS > 1 ? 1 : 0)) issue_w2(head, slab);   // after the barrier that follows the previous gemm2
+                if (slab == 0 && tr == C::TRS - 1 && head + 1 < a.nheads)   // next head's biases: their slot was last read in the
+                    heads_issue_bias(a.b1 + (head + 1) * a.head_conv, a.head_conv, a.b2[head + 1],   // previous head's epilogue, at least one barrier ago
+                                     s_bias + ((head + 1) & 1) * C::LDS_BIAS, __builtin_amdgcn_readfirstlane(wv), l);
                 const char *slot = s_ring + (s & 1) * C::SLOT;
 #pragma unroll
                 for (int tp = 0; tp < C::TAPS; ++tp) {
@@ -254,12 +273,11 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                 __syncthreads();   // vmcnt(0) + barrier: next stage's weights (and the 1x1 slice) have landed
             }
             // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 ------------
-            gemm2<T, TH, NT, M2>(acc, acc2, a.b1 + head * a.head_conv + slab * HC_SLAB, s_w2, r, h, sw);
+            gemm2<T, TH, NT, M2>(acc, acc2, s_b + slab * HC_SLAB * 4, s_w2, r, h, sw);
             if (C::TRS == 1) __syncthreads();   // (f32 path) s_w2 is rewritten in the very next stage
         }
         // ---- head done: z = acc2 + b2 -> NCHW fp32 (lane = pixel: coalesced rows) ------------------------
         const int C_head = a.C[head];
-        const float *b2 = a.b2[head];
         float *out = a.out[head];
         const size_t cstride = (size_t)a.H * a.W;
 #pragma unroll
@@ -273,9 +291,10 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                     for (int g = 0; g < 4; ++g) {
                         const int c = m2 * 32 + 8 * g + 4 * h;
                         float *p = op + (size_t)(m2 * 32 + 8 * g) * cstride;
+                        const f32x4 b2v = *reinterpret_cast<const f32x4 *>(s_b + 1024 + c * 4);
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (c + i < C_head) p[i * cstride] = acc2[m2][n][4 * g + i] + b2[c + i];
+                            if (c + i < C_head) p[i * cstride] = acc2[m2][n][4 * g + i] + b2v[i];
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -293,7 +312,8 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
     const int es = op.dtype == H3D_BF16 ? 2 : 4;
     if (op.Cin != HC_IN || op.in_cs % (16 / es) || op.in_cs < HC_IN)
         H3D_FAIL(H3D_ERR_SHAPE, "heads: input must have %d channels (got %d, stride %d)", HC_IN, op.Cin, op.in_cs);
-    if (op.Cout <= 0 || op.Cout % HC_SLAB) H3D_FAIL(H3D_ERR_SHAPE, "heads: head_conv %d must be a multiple of %d", op.Cout, HC_SLAB);
+    if (op.Cout <= 0 || op.Cout % HC_SLAB || op.Cout > 256)
+        H3D_FAIL(H3D_ERR_SHAPE, "heads: head_conv %d must be a multiple of %d, at most 256", op.Cout, HC_SLAB);
     if (d->nheads <= 0 || d->nheads > HEADS_MAX) H3D_FAIL(H3D_ERR_SHAPE, "heads: %d heads (max %d)", d->nheads, HEADS_MAX);
     HeadsArgs a;
     a.in = (const char *)op.in; a.w1 = (const char *)op.w; a.b1 = op.bias;
