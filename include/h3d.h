@@ -76,7 +76,7 @@ enum {
     H3D_OP_COPY = 6,    /* strided NHWC copy (y[i] = x[i].clone(), model.py:480-482)                   */
     H3D_OP_DCN_FUSED = 9, /* DeformConv with conv_offset_mask fused in (csrc/dcn3.hip): in2 = offset/mask filters
                              [32 permuted rows][9][Cin] (same element type as w), bias = [wrows main | 32 offset] */
-    H3D_OP_CONV_STREAM = 10, /* 3x3 s1 p1 conv (bf16) fed by LDS-DMA (csrc/conv2.hip): w = stage-major filter image
+    H3D_OP_CONV_STREAM = 10, /* 3x3 p1 conv, stride 1 or 2 (bf16), fed by LDS-DMA (csrc/conv2.hip): w = stage-major filter image
                                 [Cin/16][wrows/32][32 rows][19 slots of 8 elements]: slot 2*tap+h = input channels
                                 16*stage + 8h..8h+7 of tap `tap`, slot 18 zero; in2 = optional residual    */
     H3D_OP_DCN_FUSED_F16 = 11, /* H3D_OP_DCN_FUSED for a 64-channel fp16 input, Cout <= 64 (csrc/dcn4.hip): w and in2 are
@@ -123,7 +123,9 @@ typedef struct h3d_op {
     int32_t relu;       /* 1: ReLU epilogue                                                */
     int32_t out_mode;   /* H3D_OUT_*                                                       */
     int32_t wrows;      /* rows of the packed weight buffer (>= Cout, multiple of 128)     */
-    int32_t reserved;
+    int32_t reserved;   /* 0 in production.  Profiling only: a per-kind tuning override (CONV_STREAM: MT << 8 | WAVES;
+                           UPADD: 1 = tap table from global memory, 2 = from LDS) and, in `make ABLATE=1` builds,
+                           ablation switches in the high bits (tools/ab_*.py)                              */
 } h3d_op;
 
 /* Launch ops[0..n) in order on `stream`.  Returns H3D_OK or the first error (index in the
