@@ -40,7 +40,7 @@ def op_flops(op):
     px = op.B * op.Ho * op.Wo
     if op.kind in (_lib.OP_CONV, _lib.OP_CONV_STREAM, _lib.OP_DCN, _lib.OP_STEM):
         return 2.0 * px * op.Cout * op.Cin * op.ksize * op.ksize
-    if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_F16):
+    if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_F16, _lib.OP_DCN_FUSED_STREAM):
         return 2.0 * px * (op.Cout + 27) * op.Cin * 9
     if op.kind == _lib.OP_UPADD:
         return 2.0 * px * op.Cout * 4

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libh3d_hip.so")
 
 H3D_F32, H3D_BF16 = 0, 1
 OP_STEM, OP_CONV, OP_DCN, OP_MAXPOOL, OP_UPADD, OP_COPY, OP_HEADS, OP_DCN_V1, OP_DCN_FUSED = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OP_CONV_STREAM, OP_DCN_FUSED_F16 = 10, 11
+OP_CONV_STREAM, OP_DCN_FUSED_F16, OP_DCN_FUSED_STREAM = 10, 11, 12
 HEADS_MAX = 16
 OUT_NHWC, OUT_NCHW_F32, OUT_NHWC_F32, OUT_NHWC_F16 = 0, 1, 2, 3
 ABI_VERSION = 1
@@ -46,6 +46,7 @@ class H3dHeadsDesc(ctypes.Structure):
 # name -> argtypes (restype is int unless noted); also the export list the CPU test checks
 SIGNATURES = {
     "h3d_dcn_v2_forward": [c_vp] * 6 + [c_i] * 14 + [c_vp],
+    "h3d_dcn_fused_ck": [c_i, c_i],
     "h3d_smpl_coef_pack": [c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "h3d_smpl_verts3": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],
     "h3d_preprocess": [c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp],

@@ -27,9 +27,10 @@ struct Dcn3Args {
     int Cout, out_cs, relu, out_mode, wrows;
     int tiles_x, tiles_y;
     int dbg;   // profiling ablation (h3d_op.reserved): 1 no phase-A MFMA, 2 no gather/blend, 4 no phase-B MFMA, 8 stage once
+    int G;     // WDMA: 32-row groups of the main filter image
 };
 
-template <typename T, int MT, int CK, int MARGIN>
+template <typename T, int MT, int CK, int MARGIN, bool WDMA = false>
 struct Dcn3Cfg {
     static constexpr int ES = sizeof(T);
     static constexpr int SS = SE<T>::SS;
@@ -42,15 +43,33 @@ struct Dcn3Cfg {
     static constexpr int THREADS = 512;
     static constexpr int VPP = CK * SS / 16;
     static constexpr int LDS_H = HH * RBH;
-    static constexpr int LDS_MAIN = LDS_H + BN * WB;
+    static constexpr int WGRP = 32 * WB;                               // one 32-row group of a filter stage
+    static constexpr int WPIECES = (MT * WGRP + 1023) / 1024;          // WDMA: KiB pieces of a main-filter stage
+    static constexpr int OPIECES = (WGRP + 1023) / 1024;               //       ... of an offset-filter stage
+    static constexpr int WSLOT = WDMA ? WPIECES * 1024 : BN * WB;
+    static constexpr int LDS_MAIN = LDS_H + (WDMA ? 2 : 1) * WSLOT;
     static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // epilogue.h tile_epilogue_lds regions
     static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 };
 
-template <typename T, int MT, int CK, int MARGIN, int EPI = 0>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
+// WDMA (bf16 plans): the filters are stage-major fp16 LDS images (H3D_OP_DCN_FUSED_STREAM) copied by LDS-DMA into a
+// two-slot ring one stage ahead; only the apron (which must be converted) still goes through registers.
+template <int PIECES>
+__device__ __forceinline__ void dcn3_issue_w(const char *base, int bytes, char *dst, int src, int lane16, int wv)
+{
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < (PIECES + 7) / 8; ++j) {
+        const int p = wv + 8 * j;
+        if (p < PIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + p * 1024), 16, lane16, src + p * 1024, 0, 0);
+    }
+}
+
+template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
 __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
 {
-    using C = Dcn3Cfg<T, MT, CK, MARGIN>;
+    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA>;
     using X = SE<T>;
     constexpr int ES = C::ES, SS = C::SS;
     __shared__ __attribute__((aligned(16))) char smem[C::LDS];
@@ -72,11 +91,21 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     const char *img = a.in + (size_t)b * a.H * a.W * a.in_cs * ES;
     const int aoff = r * C::WB + 8 * h * SS;
     const int nchunks = a.Cin / CK;
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const int off_bytes = nchunks * C::WGRP, main_bytes = nchunks * a.G * C::WGRP;
+    // WDMA: filters of stage s -> ring slot s & 1
+    auto issue_w = [&](int s) {
+        if constexpr (WDMA) {
+            char *dst = s_w + (s & 1) * C::WSLOT;
+            if (s < nchunks) dcn3_issue_w<C::OPIECES>(a.woff, off_bytes, dst, s * C::WGRP, l * 16, wvu);
+            else dcn3_issue_w<C::WPIECES>(a.w, main_bytes, dst, ((s - nchunks) * a.G + (int)blockIdx.y * MT) * C::WGRP, l * 16, wvu);
+        }
+    };
 
     // ---- one staging pipeline for both phases: stage s < nchunks = (apron chunk s, offset filters),
     //      stage s >= nchunks = (apron chunk s - nchunks, main filters) ---------------------------------
     constexpr int WV = 9 * C::VPP;
-    constexpr int NH = C::HH * C::HH * C::VPP, NW = C::BN * WV;
+    constexpr int NH = C::HH * C::HH * C::VPP, NW = WDMA ? 0 : C::BN * WV;
     constexpr int NV = (NH + NW + C::THREADS - 1) / C::THREADS;
     u32x4 stg[NV];
     auto load_stage = [&](int s) {
@@ -129,12 +158,16 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) aoffs[i] = 0.f;
     const int bconv = (MARGIN + py) * C::RBH + (MARGIN + px) * C::SBH + 8 * h * SS;   // tap (0,0) of the plain conv
+    issue_w(0);
     load_stage(0);
     for (int s = 0; s < nchunks; ++s) {
         if (s) __syncthreads();
         store_stage(s);
+        if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // the filters of stage s have landed too
         __syncthreads();
+        issue_w(s + 1);
         load_stage(s + 1);                       // s + 1 == nchunks is phase B's first stage
+        const char *s_w = smem + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
@@ -208,8 +241,10 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     for (int s = nchunks; s < 2 * nchunks; ++s) {
         __syncthreads();
         store_stage(s);
+        if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
-        if (s + 1 < 2 * nchunks) load_stage(s + 1);
+        if (s + 1 < 2 * nchunks) { issue_w(s + 1); load_stage(s + 1); }
+        const char *s_w = smem + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             typename X::frag fb[CK / 16];
@@ -244,11 +279,16 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     if (__syncthreads_or(slow ? 1 : 0)) {
         for (int c0 = 0; c0 < a.Cin; c0 += CK) {
             __syncthreads();
-            for (int i = tid; i < C::BN * WV; i += C::THREADS) {
-                const int row = i / WV, q = i - row * WV;
-                const int tap = q / C::VPP, v = q - tap * C::VPP;
-                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = *reinterpret_cast<const u32x4 *>(
-                    a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+            if constexpr (WDMA) {
+                dcn3_issue_w<C::WPIECES>(a.w, main_bytes, s_w, ((c0 / CK) * a.G + (int)blockIdx.y * MT) * C::WGRP, l * 16, wvu);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+            } else {
+                for (int i = tid; i < C::BN * WV; i += C::THREADS) {
+                    const int row = i / WV, q = i - row * WV;
+                    const int tap = q / C::VPP, v = q - tap * C::VPP;
+                    *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = *reinterpret_cast<const u32x4 *>(
+                        a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -310,10 +350,10 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     }
 }
 
-template <typename T, int MT, int CK, int MARGIN>
+template <typename T, int MT, int CK, int MARGIN, bool WDMA = false>
 static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
 {
-    using C = Dcn3Cfg<T, MT, CK, MARGIN>;
+    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA>;
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     Dcn3Args a = a0;
     a.tiles_x = cdiv(a.W, 16);
@@ -321,24 +361,32 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (sizeof(T) == 2 && MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN, epi)) return H3D_OK;
+    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d, %d, %s>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN, epi,
+                        WDMA ? "true" : "false"))
+        return H3D_OK;
     if constexpr (sizeof(T) == 2 && MT >= 2) {
         if (epi == 2) {
-            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2>), grid, dim3(C::THREADS), 0, st, a);
+            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2, WDMA>), grid, dim3(C::THREADS), 0, st, a);
             H3D_CHECK_LAUNCH("dcn3_kernel");
             return H3D_OK;
         }
     }
     if (epi == 1)
-        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1, WDMA>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0, WDMA>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("dcn3_kernel");
     return H3D_OK;
 }
 
+// channels per filter stage the fused kernel uses for a layer: hosts pack the stage-major images of
+// H3D_OP_DCN_FUSED_STREAM with this CK (32 for <= 64 output channels and Cin % 32 == 0, else 16)
+extern "C" int h3d_dcn_fused_ck(int Cin, int Cout) { return (Cin % 32 == 0 && Cout <= 64) ? 32 : 16; }
+
 int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
 {
+    const bool wdma = op.kind == H3D_OP_DCN_FUSED_STREAM;
+    if (wdma && op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused_stream: bf16 plans only");
     if (!op.in || !op.w || !op.bias || !op.out || !op.in2) H3D_FAIL(H3D_ERR_ARG, "dcn_fused: null pointer");
     const int es = op.dtype == H3D_BF16 ? 2 : 4;
     if (op.ksize != 3 || op.stride != 1 || op.Ho != op.H || op.Wo != op.W)
@@ -356,6 +404,16 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode; a.wrows = op.wrows;
     a.tiles_x = a.tiles_y = 0;
     a.dbg = op.reserved;
+    a.G = op.wrows / 32;
+    if (wdma) {
+        if (op.Cin % 32 == 0 && op.Cout <= 64) {
+            if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 32, 2, true>(a, st);
+            return launch_dcn3_cfg<bf16_t, 2, 32, 2, true>(a, st);
+        }
+        if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 2, true>(a, st);
+        if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 2, true>(a, st);
+        return launch_dcn3_cfg<bf16_t, 4, 16, 2, true>(a, st);
+    }
     if (op.dtype == H3D_BF16) {
         if (op.Cin % 32 == 0 && op.Cout <= 64) {
             if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 32, 2>(a, st);

@@ -96,7 +96,8 @@ static int run_one(const h3d_op &op, int i, hipStream_t st)
     case H3D_OP_CONV_STREAM: rc = h3d_launch_conv_stream(op, st); break;
     case H3D_OP_DCN: rc = h3d_launch_dcn2(op, st); break;
     case H3D_OP_DCN_V1: rc = h3d_launch_dcn(op, st); break;
-    case H3D_OP_DCN_FUSED: rc = h3d_launch_dcn3(op, st); break;
+    case H3D_OP_DCN_FUSED:
+    case H3D_OP_DCN_FUSED_STREAM: rc = h3d_launch_dcn3(op, st); break;
     case H3D_OP_DCN_FUSED_F16: rc = h3d_launch_dcn4(op, st); break;
     case H3D_OP_HEADS: rc = h3d_launch_heads(op, st); break;
     case H3D_OP_MAXPOOL:

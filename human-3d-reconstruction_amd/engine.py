@@ -111,20 +111,22 @@ class PackedWeights:
         return self.t[key]
 
     @staticmethod
-    def _stage_image(wp):
-        """[rows (multiple of 32)][9][Cin] -> stage-major LDS image [Cin/16][rows/32][32][19 slots][8]:
-        slot 2*tap+h = input channels 16*stage + 8h..8h+7 of tap `tap`, slot 18 zero (csrc/conv2.hip, dcn4.hip)."""
+    def _stage_image(wp, ck=16):
+        """[rows (multiple of 32)][9][Cin] -> stage-major LDS image [Cin/ck][rows/32][32][9*ck/8 + 1 slots][8]:
+        slot tap*ck/8 + j = input channels ck*stage + 8j..8j+7 of tap `tap`, last slot zero (csrc/conv2.hip and
+        dcn4.hip: ck = 16; csrc/dcn3.hip WDMA: ck = h3d_dcn_fused_ck)."""
         rows, _, ci = wp.shape
-        G = rows // 32
-        img = torch.zeros(ci // 16, G, 32, 19, 8)
-        v = wp.reshape(G, 32, 9, ci // 16, 2, 8).permute(3, 0, 1, 2, 4, 5)
-        img[:, :, :, :18] = v.reshape(ci // 16, G, 32, 18, 8)
+        G, spt = rows // 32, ck // 8
+        img = torch.zeros(ci // ck, G, 32, 9 * spt + 1, 8)
+        v = wp.reshape(G, 32, 9, ci // ck, spt, 8).permute(3, 0, 1, 2, 4, 5)
+        img[:, :, :, :9 * spt] = v.reshape(ci // ck, G, 32, 9 * spt, 8)
         return img
 
-    def dcn_stream(self, p):
-        """Fused DeformConv `p` packed for csrc/dcn4.hip (fp16 stage-major images of the main and the
-        offset/mask filters) -> (main image, offset image, bias [rows | 32], Cout, Cin, rows)."""
-        key = ("dcn_stream", p)
+    def dcn_stream(self, p, ck=16):
+        """Fused DeformConv `p` packed as fp16 stage-major images of the main and the offset/mask filters, `ck`
+        channels per stage (csrc/dcn4.hip: 16; csrc/dcn3.hip WDMA: h3d_dcn_fused_ck)
+        -> (main image, offset image, bias [rows | 32], Cout, Cin, rows)."""
+        key = ("dcn_stream", p, ck)
         if key not in self.t:
             w, b = self._fold(self.sd[p + ".conv.weight"], self.sd[p + ".conv.bias"], p + ".actf.0")
             co, ci = w.shape[:2]
@@ -134,8 +136,8 @@ class PackedWeights:
             bp = torch.zeros(rows)
             bp[:co] = b
             wo, bo = self.offset_conv(p + ".conv.conv_offset_mask.weight", p + ".conv.conv_offset_mask.bias", rows)
-            self.t[key] = (self._stage_image(wp).to(torch.float16).contiguous().to(self.device),
-                           self._stage_image(wo[:32].float().cpu()).to(torch.float16).contiguous().to(self.device),
+            self.t[key] = (self._stage_image(wp, ck).to(torch.float16).contiguous().to(self.device),
+                           self._stage_image(wo[:32].float().cpu(), ck).to(torch.float16).contiguous().to(self.device),
                            torch.cat([bp, bo]).contiguous().to(self.device), co, ci, rows)
         return self.t[key]
 
@@ -212,13 +214,14 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True, stream_s2=True, wide_heads_m2=0):
+    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True, stream_s2=True, wide_heads_m2=0, stream_dcn3=False):
         self.fuse_heads = fuse_heads
         self.fuse_offsets = fuse_offsets
         self.stream_convs = stream_convs
         self.stream_dcn = stream_dcn
         self.stream_s2 = stream_s2
         self.wide_heads_m2 = wide_heads_m2
+        self.stream_dcn3 = stream_dcn3
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -365,6 +368,16 @@ class Plan:
                      out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
                      stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
             return out
+        if self.pw.use_dcn and self.fuse_offsets and self.stream_dcn3 and self.pw.dtype == "bf16":
+            w = self.pw.sd[p + ".conv.weight"]
+            ck = int(_lib.lib().h3d_dcn_fused_ck(int(w.shape[1]), int(w.shape[0])))
+            wimg, woimg, bias, cout, cin, rows = self.pw.dcn_stream(p, ck)
+            if out is None:
+                out = self._alloc(x.H, x.W, cout)
+            self._op(_lib.OP_DCN_FUSED_STREAM, in_=x.ptr, in2=woimg.data_ptr(), w=wimg.data_ptr(), bias=bias.data_ptr(),
+                     out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
+                     stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
+            return out
         if self.pw.use_dcn and self.fuse_offsets:
             wp, bp, cout, cin, k, rows = self.pw.conv(p + ".conv.weight", p + ".conv.bias", p + ".actf.0", as_half=True)
             wo, bo = self.pw.offset_conv(p + ".conv.conv_offset_mask.weight", p + ".conv.conv_offset_mask.bias", rows)
@@ -495,6 +508,7 @@ class DLAEngine:
         self.stream_convs = True        # False: 3x3 s1 convs through the register-staged kernel (csrc/conv.hip)
         self.stream_dcn = True          # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
         self.stream_s2 = True           # False: stride-2 3x3 convs (Cin >= 64) through csrc/conv.hip
+        self.stream_dcn3 = False        # True: the remaining fused DeformConvs take their filters by LDS-DMA as well (measured: no gain)
         self.wide_heads_m2 = 0          # 3: heads wider than 32 channels share one launch (3 output row tiles each)
         self.streams = 1                # >1: run that many sub-batches concurrently on their own HIP streams
 
@@ -503,7 +517,7 @@ class DLAEngine:
         if key not in self.plans:
             with torch.cuda.device(self.device):
                 self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2)
+                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2, stream_dcn3=self.stream_dcn3)
         return self.plans[key]
 
     def forward(self, images):
@@ -533,7 +547,7 @@ class DLAEngine:
         with torch.cuda.device(self.device):
             if key not in self.plans:
                 plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2)
+                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2, stream_dcn3=self.stream_dcn3)
                          for _ in range(n)]
                 full = {h: torch.empty((B,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
                         for h, o in plans[0].outputs.items()}

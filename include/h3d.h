@@ -81,6 +81,9 @@ enum {
                                 16*stage + 8h..8h+7 of tap `tap`, slot 18 zero; in2 = optional residual    */
     H3D_OP_DCN_FUSED_F16 = 11, /* H3D_OP_DCN_FUSED for a 64-channel fp16 input, Cout <= 64 (csrc/dcn4.hip): w and in2 are
                                   stage-major fp16 filter images [4][wrows/32 | 1][32][19][8] (layout of H3D_OP_CONV_STREAM) */
+    H3D_OP_DCN_FUSED_STREAM = 12, /* H3D_OP_DCN_FUSED (bf16 input) with w / in2 as stage-major fp16 filter images of
+                                     CK = h3d_dcn_fused_ck(Cin, Cout) channels per stage: [Cin/CK][wrows/32 | 1][32 rows]
+                                     [9*CK/8 + 1 slots][8]: slot tap*CK/8 + j = channels CK*stage + 8j.. of tap `tap` */
     H3D_OP_DCN_V1 = 8,  /* first-generation DCN kernel (global gather, bf16 weights): kept as an A/B reference */
     H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
                            (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */
@@ -127,6 +130,9 @@ typedef struct h3d_op {
                            UPADD: 1 = tap table from global memory, 2 = from LDS) and, in `make ABLATE=1` builds,
                            ablation switches in the high bits (tools/ab_*.py)                              */
 } h3d_op;
+
+/* channels per filter stage H3D_OP_DCN_FUSED_STREAM expects for a layer (32 or 16) */
+int h3d_dcn_fused_ck(int Cin, int Cout);
 
 /* Launch ops[0..n) in order on `stream`.  Returns H3D_OK or the first error (index in the
  * message). */

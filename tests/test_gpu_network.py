@@ -251,3 +251,23 @@ def test_streamed_dcn_matches_dcn3(offset_scale, tol):
         e_ref = float((on[k].cpu() - ref[k]).abs().max())
         e_off = float((off[k].cpu() - ref[k]).abs().max())
         assert e_ref <= max(BF16_TOL, 1.5 * e_off), (k, e_ref, e_off)
+
+
+@pytest.mark.parametrize("offset_scale,tol", [(0.5, 6e-2), (12.0, 0.25)])
+def test_dma_filter_dcn3_matches_register_staged(offset_scale, tol):
+    # csrc/dcn3.hip with the filters as stage-major images copied by LDS-DMA (H3D_OP_DCN_FUSED_STREAM) vs the
+    # register-staged filters (H3D_OP_DCN_FUSED): identical arithmetic, so the outputs agree to bf16 noise
+    sd = synth.synth_state_dict(arch.state_dict_shapes(HEADS, True), seed=0, offset_scale=offset_scale)
+    m = model.dla_net(HEADS, not_use_dcn=False, dtype="bf16")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=31)).to(DEV)
+    eng = m.engine(xs.device)
+    eng.stream_dcn3 = True            # off by default (no speed-up measured); _ab leaves it on
+    eng.plans.clear()
+    on, off = _ab(m, xs, "stream_dcn3")
+    from h3d_amd import _lib
+    assert _lib.OP_DCN_FUSED_STREAM in [op.kind for op in eng.plan(2, 96, 160).ops]
+    for k in HEADS:
+        e = float((on[k] - off[k]).abs().max())
+        assert e <= tol, (k, e)
