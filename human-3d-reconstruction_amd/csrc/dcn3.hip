@@ -47,7 +47,10 @@ struct Dcn3Cfg {
     static constexpr int WPIECES = (MT * WGRP + 1023) / 1024;          // WDMA: KiB pieces of a main-filter stage
     static constexpr int OPIECES = (WGRP + 1023) / 1024;               //       ... of an offset-filter stage
     static constexpr int WSLOT = WDMA ? WPIECES * 1024 : BN * WB;
-    static constexpr int LDS_MAIN = LDS_H + (WDMA ? 2 : 1) * WSLOT;
+    // register-staged path: apron and filters are double buffered (stage s+1 is written while stage s is read), which
+    // halves the barriers: the SQ counters showed these kernels parked ~43 % of the time on two barriers per stage
+    static constexpr int STAGE = LDS_H + WSLOT;                        // one stage buffer (non-WDMA)
+    static constexpr int LDS_MAIN = WDMA ? LDS_H + 2 * WSLOT : 2 * STAGE;
     static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // epilogue.h tile_epilogue_lds regions
     static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
 };
@@ -73,8 +76,7 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     using X = SE<T>;
     constexpr int ES = C::ES, SS = C::SS;
     __shared__ __attribute__((aligned(16))) char smem[C::LDS];
-    char *s_h = smem;
-    char *s_w = smem + C::LDS_H;
+    char *s_w = smem + C::LDS_H;       // filters of stage buffer 0 (pass 2) / of the WDMA ring
 
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
@@ -137,6 +139,8 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     };
     auto store_stage = [&](int s) {
         if ((H3D_DBG(a) & 8) && s > 0) return;
+        char *s_h = smem + (WDMA ? 0 : (s & 1) * C::STAGE);
+        char *s_w = s_h + C::LDS_H;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int i = tid + j * C::THREADS;
@@ -161,13 +165,14 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
     issue_w(0);
     load_stage(0);
     for (int s = 0; s < nchunks; ++s) {
-        if (s) __syncthreads();
+        if (WDMA && s) __syncthreads();          // (single apron buffer)
         store_stage(s);
         if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // the filters of stage s have landed too
         __syncthreads();
         issue_w(s + 1);
         load_stage(s + 1);                       // s + 1 == nchunks is phase B's first stage
-        const char *s_w = smem + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
+        const char *s_h = smem + (WDMA ? 0 : (s & 1) * C::STAGE);
+        const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
@@ -239,12 +244,13 @@ __global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
     for (int s = nchunks; s < 2 * nchunks; ++s) {
-        __syncthreads();
+        if (WDMA) __syncthreads();
         store_stage(s);
         if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
         if (s + 1 < 2 * nchunks) { issue_w(s + 1); load_stage(s + 1); }
-        const char *s_w = smem + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
+        const char *s_h = smem + (WDMA ? 0 : (s & 1) * C::STAGE);
+        const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             typename X::frag fb[CK / 16];
