@@ -36,6 +36,7 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st);
 int h3d_launch_dcn3(const h3d_op &op, hipStream_t st);
 int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st);
 int h3d_launch_dcn4(const h3d_op &op, hipStream_t st);
+int h3d_launch_stem3(const h3d_op &op, hipStream_t st);
 
 static int run_one(const h3d_op &op, int i, hipStream_t st);
 
@@ -92,6 +93,7 @@ static int run_one(const h3d_op &op, int i, hipStream_t st)
     }
     switch (op.kind) {
     case H3D_OP_STEM: rc = h3d_launch_stem(op, st); break;
+    case H3D_OP_STEM3: rc = h3d_launch_stem3(op, st); break;
     case H3D_OP_CONV: rc = h3d_launch_conv(op, st); break;
     case H3D_OP_CONV_STREAM: rc = h3d_launch_conv_stream(op, st); break;
     case H3D_OP_DCN: rc = h3d_launch_dcn2(op, st); break;

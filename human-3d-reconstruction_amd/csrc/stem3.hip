@@ -1,0 +1,221 @@
+// base_layer + level0 + level1 of DLA-34 in one kernel (bf16 plans):
+//   7x7 3->16 (BN, ReLU) -> 3x3 16->16 (BN, ReLU) -> 3x3 stride 2 16->32 (BN, ReLU)       (model.py:231-249)
+// The two 16-channel full-resolution maps are the fattest tensors of the network (537 MB each at batch 64 and
+// 512x512) and nothing else reads them (DLAUp starts at level 2), so they never leave the chip here: the kernel reads
+// the fp32 NCHW images and writes the level1 map.
+//
+// One workgroup (8 waves) = 8 x 16 level1 pixels.  It needs the 17 x 33 level0 pixels under them, those need the
+// 19 x 35 stem pixels around them, those the 25 x 41 image pixels: every stage recomputes its halo (1.3x / 1.1x).
+//   P0  image patch -> LDS as interleaved pixels of 4 bf16 (c0, c1, c2, 0): a 7-tap row of the stem is a contiguous
+//       K = 28 (+4 zero-weight) run
+//   P1  stem on v_mfma_f32_16x16x32_bf16: one K step per tap row, 7 MFMAs per 16 pixels (as csrc/conv.hip
+//       stem_mfma_kernel); bias + ReLU -> bf16 -> LDS tile S (pixel stride 48 B); pixels outside the image are
+//       written as ZERO: they are level0's zero padding, not the stem of a padded image
+//   P2  level0 on the same instruction: K = 32 is a PAIR of taps x 16 channels, 5 K steps (the 10th tap has zero
+//       weights); bias + ReLU -> bf16 -> LDS tile L0, zero outside the image
+//   P3  level1 (stride 2, 32 channels) on v_mfma_f32_32x32x16_bf16: one K step per tap, waves 0-3 take 32 pixels each
+// All filters live in registers (7 + 5 + 9 fragments per lane).  76 KB of LDS: two workgroups per CU.
+// Intermediates are rounded to bf16 exactly where the unfused kernels round them.
+#include "common.h"
+#include "epilogue.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_s3;
+
+struct Stem3Args {
+    const float *img;      // [B,3,H,W] fp32
+    const bf16_t *w;       // [16][7][32] stem (k = dx*4 + c) | [5][16][32] level0 (k = tapsel*16 + c) | [32][9][16] level1
+    const float *bias;     // [16 | 16 | 32]
+    bf16_t *out;           // [B,Ho,Wo,out_cs] level1
+    int B, H, W, Ho, Wo, out_cs;
+    int tiles_x, tiles_y;
+    int dbg;               // ABLATE builds: stop after phase dbg (1..3)
+};
+
+constexpr int S3K_TPB = 8;                           // consecutive tiles per workgroup (image patch prefetched one tile ahead)
+constexpr int S3K_IW = 56, S3K_IH = 25;              // image patch (uint2 per pixel)
+constexpr int S3K_ROWB = 1792, S3K_PXB = 48;         // S and L0 tiles: 48 B per pixel, rows 0 mod 256 B
+constexpr int S3K_SH = 19, S3K_SW = 35, S3K_LH = 17, S3K_LW = 33;
+constexpr int S3K_LDS_I = S3K_IH * S3K_IW * 8, S3K_LDS_S = S3K_SH * S3K_ROWB, S3K_LDS_L = S3K_LH * S3K_ROWB;
+constexpr int S3K_LDS = S3K_LDS_I + S3K_LDS_S + S3K_LDS_L + 4096;     // + slack: masked lanes of the last groups read past a row
+
+__global__ __launch_bounds__(512) void stem3_kernel(Stem3Args a)
+{
+    __shared__ __attribute__((aligned(16))) char smem[S3K_LDS];
+    uint2 *s_i = reinterpret_cast<uint2 *>(smem);
+    char *s_s = smem + S3K_LDS_I;
+    char *s_l = s_s + S3K_LDS_S;
+
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, p = l & 15, q = l >> 4;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int ntile = a.B * tiles;
+    const int t_first = blockIdx.x * S3K_TPB;
+    const size_t plane = (size_t)a.H * a.W;
+
+    // ---- P0 (software pipelined over the S3K_TPB tiles of this workgroup): the image patch of tile i+1 is fetched into
+    //      registers while tile i computes -- with one patch per workgroup every workgroup paid a full memory round
+    //      trip before its first MFMA, 40 % of the kernel (tools/ablate_stem3.py).
+    //      The tile origin is a multiple of 32 pixels, so the patch starts 5 pixels left of a 16-byte boundary: rows are
+    //      fetched as aligned float4 (columns ix0 - 3 .. ix0 + 56, 15 vectors per row and plane; W % 4 == 0 makes every
+    //      vector entirely inside or outside the image), one (row, 4-pixel group) item per thread.
+    constexpr int VPRW = 15, NITEM = S3K_IH * VPRW;       // 375 items
+    f32x4 pc0, pc1, pc2;
+    auto load_patch = [&](int ti) {
+        pc0 = f32x4{0.f, 0.f, 0.f, 0.f}; pc1 = pc0; pc2 = pc0;
+        if (tid < NITEM && ti < ntile) {
+            const int pb = ti / tiles, pt = ti - pb * tiles;
+            const int pty = pt / a.tiles_x, ptx = pt - pty * a.tiles_x;
+            const int iy = tid / VPRW, j = tid - iy * VPRW;
+            const int gy = 16 * pty - 5 + iy, gx = 32 * ptx - 5 - 3 + 4 * j;
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                const float *im = a.img + (size_t)pb * 3 * plane + (size_t)gy * a.W + gx;
+                pc0 = *reinterpret_cast<const f32x4 *>(im);
+                pc1 = *reinterpret_cast<const f32x4 *>(im + plane);
+                pc2 = *reinterpret_cast<const f32x4 *>(im + 2 * plane);
+            }
+        }
+    };
+    auto store_patch = [&]() {
+        if (tid < NITEM) {
+            const int iy = tid / VPRW, j = tid - iy * VPRW;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ix = 4 * j - 3 + e;
+                if (ix >= 0 && ix < S3K_IW) s_i[iy * S3K_IW + ix] = uint2{pack_bf16x2(pc0[e], pc1[e]), pack_bf16x2(pc2[e], 0.f)};
+            }
+        }
+    };
+    load_patch(t_first);
+    store_patch();
+    // filters of P1 / P2 (16x16x32 A operand: row = p, K = 8q..8q+7)
+    u32x4 fa0[7], fa1[5];
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy) fa0[dy] = *reinterpret_cast<const u32x4 *>(a.w + (p * 7 + dy) * 32 + 8 * q);
+    const bf16_t *w1 = a.w + 16 * 7 * 32;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) fa1[ks] = *reinterpret_cast<const u32x4 *>(w1 + (ks * 16 + p) * 32 + 8 * q);
+    float b0[4], b1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b0[i] = a.bias[4 * q + i]; b1[i] = a.bias[16 + 4 * q + i]; }
+
+    for (int ti = t_first; ti < min(t_first + S3K_TPB, ntile); ++ti) {
+    const int b = ti / tiles;
+    const int t = ti - b * tiles;
+    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+    const int oy1 = ty * 8, ox1 = tx * 16;                   // level1 tile origin
+    const int ly0 = 2 * oy1 - 1, lx0 = 2 * ox1 - 1;          // level0 region origin (full-resolution coordinates)
+    const int sy0 = ly0 - 1, sx0 = lx0 - 1;                  // stem region origin
+    __syncthreads();                                         // this tile's patch is in LDS; the previous tile is done with S / L0
+    if (H3D_DBG(a) == 1) return;
+    if (ti + 1 < t_first + S3K_TPB) load_patch(ti + 1);      // (zeros past the last tile)
+
+    // ---- P1: stem -> S --------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int gi = wv; gi < S3K_SH * 3; gi += 8) {
+        const int sy = gi / 3, sx = (gi - sy * 3) * 16 + p;
+        f32x4_s3 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy) {
+            const uint2 lo = s_i[(sy + dy) * S3K_IW + sx + 2 * q], hi = s_i[(sy + dy) * S3K_IW + sx + 2 * q + 1];
+            const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa0[dy]), __builtin_bit_cast(bf16x8_t, fb), acc,
+                                                          0, 0, 0);
+        }
+        if (sx < S3K_SW) {
+            const int gy = sy0 + sy, gx = sx0 + sx;
+            const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            u32x2 v = {0u, 0u};
+            if (in) v = u32x2{pack_bf16x2(fmaxf(acc[0] + b0[0], 0.f), fmaxf(acc[1] + b0[1], 0.f)),
+                              pack_bf16x2(fmaxf(acc[2] + b0[2], 0.f), fmaxf(acc[3] + b0[3], 0.f))};
+            *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = v;
+        }
+    }
+    __syncthreads();
+    if (H3D_DBG(a) == 2) return;
+
+    // ---- P2: level0 -> L0 (K step = taps 2ks, 2ks+1 x 16 channels; lane group q: tap 2ks + (q >> 1), channels 8(q & 1)..) ----
+    int toff[5];
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        const int tap = min(2 * ks + (q >> 1), 8);          // the 10th "tap" has zero weights: read tap 8 again
+        toff[ks] = (tap / 3) * S3K_ROWB + (tap % 3) * S3K_PXB + (q & 1) * 16;
+    }
+    // two groups per iteration: two independent MFMA chains and their loads in flight
+#pragma unroll 1
+    for (int g0i = wv; g0i < S3K_LH * 3; g0i += 16) {
+        f32x4_s3 acc[2];
+        int lyv[2], lxv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int gi = min(g0i + 8 * u, S3K_LH * 3 - 1);      // (a duplicate of the last group when there is no second one)
+            lyv[u] = gi / 3;
+            lxv[u] = (gi - lyv[u] * 3) * 16 + p;
+            acc[u] = f32x4_s3{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32x4 fb = *reinterpret_cast<const u32x4 *>(s_s + lyv[u] * S3K_ROWB + lxv[u] * S3K_PXB + toff[ks]);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa1[ks]), __builtin_bit_cast(bf16x8_t, fb),
+                                                                 acc[u], 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && g0i + 8 >= S3K_LH * 3) break;
+            const int ly = lyv[u], lx = lxv[u];
+            if (lx < S3K_LW) {
+                const int gy = ly0 + ly, gx = lx0 + lx;
+                const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                u32x2 v = {0u, 0u};
+                if (in) v = u32x2{pack_bf16x2(fmaxf(acc[u][0] + b1[0], 0.f), fmaxf(acc[u][1] + b1[1], 0.f)),
+                                  pack_bf16x2(fmaxf(acc[u][2] + b1[2], 0.f), fmaxf(acc[u][3] + b1[3], 0.f))};
+                *reinterpret_cast<u32x2 *>(s_l + ly * S3K_ROWB + lx * S3K_PXB + q * 8) = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (H3D_DBG(a) == 3) return;
+    store_patch();                                           // the patch area was last read in P1
+
+    // ---- P3: level1 (3x3 stride 2, 32 channels): waves 0..3, one 32-pixel N tile each -------------------------
+    if (wv < 4) {
+        const int r = l & 31, h = l >> 5;
+        const bf16_t *w2 = a.w + 16 * 7 * 32 + 5 * 16 * 32;
+        const int py = 2 * wv + (r >> 4), px = r & 15;
+        const char *base = s_l + (2 * py) * S3K_ROWB + (2 * px) * S3K_PXB + h * 16;
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][0][i] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const u32x4 fa = *reinterpret_cast<const u32x4 *>(w2 + (r * 9 + tap) * 16 + 8 * h);
+            const u32x4 fb = *reinterpret_cast<const u32x4 *>(base + (tap / 3) * S3K_ROWB + (tap % 3) * S3K_PXB);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb),
+                                                                acc[0][0], 0, 0, 0);
+        }
+        EpiArgs e;
+        e.bias = a.bias + 32; e.res = nullptr; e.out = (char *)a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = 32;
+        e.out_cs = a.out_cs; e.res_cs = 0; e.relu = 1; e.out_mode = H3D_OUT_NHWC;
+        tile_epilogue<bf16_t, 1, 1, true>(acc, e, b, oy1, ox1, 0, wv, r, h);
+    }
+    }   // tiles of this workgroup
+}
+
+int h3d_launch_stem3(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "stem3: null pointer");
+    if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "stem3: bf16 plans only (dtype %d)", op.dtype);
+    if (op.Cin != 3 || op.Cout != 32 || op.Ho != (op.H - 1) / 2 + 1 || op.Wo != (op.W - 1) / 2 + 1 || op.out_cs % 4 || op.out_cs < 32)
+        H3D_FAIL(H3D_ERR_SHAPE, "stem3: expects 3 -> 16 -> 16 -> 32 channels, output %dx%d (got %d -> %d, %dx%d)", (op.H - 1) / 2 + 1,
+                 (op.W - 1) / 2 + 1, op.Cin, op.Cout, op.Ho, op.Wo);
+    if (((uintptr_t)op.bias & 15) || ((uintptr_t)op.w & 15)) H3D_FAIL(H3D_ERR_ARG, "stem3: weights / bias must be 16-byte aligned");
+    Stem3Args a;
+    a.img = (const float *)op.in; a.w = (const bf16_t *)op.w; a.bias = op.bias; a.out = (bf16_t *)op.out;
+    a.B = op.B; a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo; a.out_cs = op.out_cs;
+    a.tiles_x = cdiv(op.Wo, 16); a.tiles_y = cdiv(op.Ho, 8);
+    a.dbg = op.reserved;
+    if (h3d_note_kernel("stem3_kernel")) return H3D_OK;
+    hipLaunchKernelGGL(stem3_kernel, dim3(cdiv(op.B * a.tiles_x * a.tiles_y, S3K_TPB)), dim3(512), 0, st, a);
+    H3D_CHECK_LAUNCH("stem3_kernel");
+    return H3D_OK;
+}

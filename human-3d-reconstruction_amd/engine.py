@@ -153,6 +153,24 @@ class PackedWeights:
             self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
         return self.t[key]
 
+    def stem3(self):
+        """base_layer + level0 + level1 packed for csrc/stem3.hip: bf16 [16][7][32] | [5][16][32] | [32][9][16] and
+        fp32 biases [16 | 16 | 32] (BatchNorm folded)."""
+        key = ("stem3",)
+        if key not in self.t:
+            w0, b0 = self.stem()
+            w1, b1 = self._fold(self.sd["base.level0.0.weight"], None, "base.level0.1")       # [16,16,3,3]
+            w2, b2 = self._fold(self.sd["base.level1.0.weight"], None, "base.level1.1")       # [32,16,3,3]
+            t1 = torch.zeros(5, 16, 2, 16)
+            w1t = w1.permute(0, 2, 3, 1).reshape(16, 9, 16)                                    # [o][tap][c]
+            for tap in range(9):
+                t1[tap // 2, :, tap % 2, :] = w1t[:, tap, :]
+            w2t = w2.permute(0, 2, 3, 1).reshape(32, 9, 16)
+            flat = torch.cat([w0.cpu().float().reshape(-1), t1.reshape(-1), w2t.reshape(-1)]).to(torch.bfloat16)
+            bias = torch.cat([b0.cpu().float(), b1.float(), b2.float()])
+            self.t[key] = (flat.contiguous().to(self.device), bias.contiguous().to(self.device))
+        return self.t[key]
+
     def offset_conv(self, wkey, bkey, main_rows):
         """conv_offset_mask packed for the fused DeformConv kernel (csrc/dcn3.hip): the 27 filters are
         spread over 32 MFMA rows so that accumulator half h of a pixel owns whole (dh, dw, mask)
@@ -214,7 +232,7 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True, stream_s2=True, wide_heads_m2=0, stream_dcn3=False):
+    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True, stream_s2=True, wide_heads_m2=0, stream_dcn3=False, fuse_stem=True):
         self.fuse_heads = fuse_heads
         self.fuse_offsets = fuse_offsets
         self.stream_convs = stream_convs
@@ -222,6 +240,7 @@ class Plan:
         self.stream_s2 = stream_s2
         self.wide_heads_m2 = wide_heads_m2
         self.stream_dcn3 = stream_dcn3
+        self.fuse_stem = fuse_stem
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -409,12 +428,21 @@ class Plan:
     def _lower(self):
         B, H, W = self.B, self.H, self.W
         C = arch.CHANNELS
-        w, b = self.pw.stem()
-        x = self._alloc(H, W, C[0])
-        self._op(_lib.OP_STEM, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=x.ptr, H=H, W=W,
-                 Cin=3, in_cs=3, Ho=H, Wo=W, Cout=C[0], out_cs=x.cs, ksize=7, stride=1, relu=1)
-        y0 = self.conv(x, "base.level0.0.weight", bn="base.level0.1")
-        y1 = self.conv(y0, "base.level1.0.weight", bn="base.level1.1", stride=2)
+        if self.fuse_stem and self.pw.dtype == "bf16" and C[0] == 16 and C[1] == 32:
+            # base_layer + level0 + level1 in one launch: the two full-resolution maps never reach HBM (nothing else
+            # reads them: DLAUp starts at level 2)
+            w, b = self.pw.stem3()
+            y0 = None
+            y1 = self._alloc((H - 1) // 2 + 1, (W - 1) // 2 + 1, C[1])
+            self._op(_lib.OP_STEM3, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=y1.ptr, H=H, W=W,
+                     Cin=3, in_cs=3, Ho=y1.H, Wo=y1.W, Cout=C[1], out_cs=y1.cs, ksize=7, stride=2, relu=1)
+        else:
+            w, b = self.pw.stem()
+            x = self._alloc(H, W, C[0])
+            self._op(_lib.OP_STEM, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=x.ptr, H=H, W=W,
+                     Cin=3, in_cs=3, Ho=H, Wo=W, Cout=C[0], out_cs=x.cs, ksize=7, stride=1, relu=1)
+            y0 = self.conv(x, "base.level0.0.weight", bn="base.level0.1")
+            y1 = self.conv(y0, "base.level1.0.weight", bn="base.level1.1", stride=2)
         y2 = self._tree1(y1, "base.level2", C[1], C[2], 2, False, None)
         y3 = self._tree2(y2, "base.level3", C[2], C[3], None)
         y4 = self._tree2(y3, "base.level4", C[3], C[4], None)
@@ -509,6 +537,7 @@ class DLAEngine:
         self.stream_dcn = True          # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
         self.stream_s2 = True           # False: stride-2 3x3 convs (Cin >= 64) through csrc/conv.hip
         self.stream_dcn3 = False        # True: the remaining fused DeformConvs take their filters by LDS-DMA as well (measured: no gain)
+        self.fuse_stem = True           # False: base_layer, level0 and level1 as three launches
         self.wide_heads_m2 = 0          # 3: heads wider than 32 channels share one launch (3 output row tiles each)
         self.streams = 1                # >1: run that many sub-batches concurrently on their own HIP streams
 
@@ -517,7 +546,7 @@ class DLAEngine:
         if key not in self.plans:
             with torch.cuda.device(self.device):
                 self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2, stream_dcn3=self.stream_dcn3)
+                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2, stream_dcn3=self.stream_dcn3, fuse_stem=self.fuse_stem)
         return self.plans[key]
 
     def forward(self, images):
@@ -547,7 +576,7 @@ class DLAEngine:
         with torch.cuda.device(self.device):
             if key not in self.plans:
                 plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2, stream_dcn3=self.stream_dcn3)
+                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2, stream_dcn3=self.stream_dcn3, fuse_stem=self.fuse_stem)
                          for _ in range(n)]
                 full = {h: torch.empty((B,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
                         for h, o in plans[0].outputs.items()}

@@ -84,6 +84,9 @@ enum {
     H3D_OP_DCN_FUSED_STREAM = 12, /* H3D_OP_DCN_FUSED (bf16 input) with w / in2 as stage-major fp16 filter images of
                                      CK = h3d_dcn_fused_ck(Cin, Cout) channels per stage: [Cin/CK][wrows/32 | 1][32 rows]
                                      [9*CK/8 + 1 slots][8]: slot tap*CK/8 + j = channels CK*stage + 8j.. of tap `tap` */
+    H3D_OP_STEM3 = 13,  /* base_layer + level0 + level1 fused (bf16, csrc/stem3.hip): in = NCHW fp32 images, out = level1 map
+                           [B,Ho,Wo,32]; w = bf16 [16][7][32] stem (k = dx*4+c) | [5][16][32] level0 (k = (tap&1)*16+c of tap pair)
+                           | [32][9][16] level1; bias = fp32 [16 | 16 | 32]; Cin = 3, Cout = 32                          */
     H3D_OP_DCN_V1 = 8,  /* first-generation DCN kernel (global gather, bf16 weights): kept as an A/B reference */
     H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
                            (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */

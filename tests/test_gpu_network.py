@@ -271,3 +271,22 @@ def test_dma_filter_dcn3_matches_register_staged(offset_scale, tol):
     for k in HEADS:
         e = float((on[k] - off[k]).abs().max())
         assert e <= tol, (k, e)
+
+
+def test_fused_stem_levels_match_three_launches():
+    # csrc/stem3.hip (base_layer + level0 + level1 in one kernel, intermediates in LDS) vs the three separate
+    # launches: the same bf16 rounding points, only the fp32 summation order inside the MFMA chains differs
+    m, _ = _net(False, "bf16")
+    xs = torch.from_numpy(synth.synth_images(3, 96, 160, seed=37)).to(DEV)      # ragged 8x16 tiles on both axes
+    on, off = _ab(m, xs, "fuse_stem")
+    from h3d_amd import _lib
+    assert _lib.OP_STEM3 in [op.kind for op in m.engine(xs.device).plan(3, 96, 160).ops]
+    for k in HEADS:
+        e = float((on[k] - off[k]).abs().max())
+        assert e <= 3e-2, (k, e)
+    # a single tile row / narrow image
+    xs = torch.from_numpy(synth.synth_images(1, 32, 224, seed=41)).to(DEV)
+    on, off = _ab(m, xs, "fuse_stem")
+    for k in HEADS:
+        e = float((on[k] - off[k]).abs().max())
+        assert e <= 3e-2, (k, e)
