@@ -238,6 +238,7 @@ class Plan:
         self.stream_convs = stream_convs
         self.stream_dcn = stream_dcn
         self.stream_s2 = stream_s2
+        self.stream_s2_min_cin = 64     # measured: the 32-channel stride-2 layer is faster on csrc/conv.hip (0.136 vs 0.165 ms)
         self.wide_heads_m2 = wide_heads_m2
         self.stream_dcn3 = stream_dcn3
         self.fuse_stem = fuse_stem
@@ -272,7 +273,7 @@ class Plan:
              pad_cout_to=None, out_tensor=None):
         wshape = self.pw.sd[wkey].shape
         if (self.stream_convs and self.pw.dtype == "bf16" and wshape[2] == 3 and wshape[1] % 16 == 0
-                and (stride == 1 or (stride == 2 and wshape[1] >= 64 and self.stream_s2))
+                and (stride == 1 or (stride == 2 and wshape[1] >= self.stream_s2_min_cin and self.stream_s2))
                 and out_mode == _lib.OUT_NHWC and pad_cout_to is None):
             return self._conv_stream(x, wkey, out, bkey, bn, relu, res, stride)
         wp, bp, cout, cin, k, rows = self.pw.conv(wkey, bkey, bn, pad_cout_to)
