@@ -46,10 +46,13 @@ struct ConvCfg {
     static constexpr int VPP = CK * ES / 16;  // 16-byte vectors per pixel per chunk
     static constexpr int LDS_IN = IN_H * RB;
     static constexpr int LDS_W = BN * WB;
-    static constexpr int LDS = LDS_IN + LDS_W;
+    static constexpr int LDS_MAIN = LDS_IN + LDS_W;
+    static constexpr int LDS_EPI = sizeof(T) == 2 ? WAVES * ((NT * 32 * (64 * MT + 16) + 1023) / 1024 * 1024) : 0;   // tile_epilogue_lds
+    static constexpr int LDS = (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) <= 160 * 1024 ? (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) : LDS_MAIN;
+    static constexpr bool EPI_LDS_OK = sizeof(T) == 2 && MT >= 2 && LDS_EPI <= LDS;
 };
 
-template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4, bool FASTEPI = false>
+template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4, int EPI = 0>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed
 __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
 {
     using C = ConvCfg<T, KS, STRIDE, MT, CK, TH, WAVES>;
@@ -163,7 +166,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
     EpiArgs e;
     e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
-    tile_epilogue<T, MT, C::NT, FASTEPI>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    if constexpr (EPI == 2 && C::EPI_LDS_OK) {
+        __syncthreads();                          // halo and filters are no longer read
+        tile_epilogue_lds<MT, C::NT>(acc, e, b, oy0, ox0, cout0, __builtin_amdgcn_readfirstlane(wv), l, smem + wv * epi_lds_stride<MT, C::NT>());
+    } else {
+        tile_epilogue<T, MT, C::NT, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    }
 }
 
 template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4>
@@ -176,13 +184,23 @@ static int launch_conv_cfg(const ConvArgs &a0, hipStream_t st)
     a.tiles_y = cdiv(a.Ho, TH);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
-    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d, %d, %s>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
-                        CK, TH, WAVES, lean ? "true" : "false"))
+    const int epi = (C::EPI_LDS_OK && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 &&
+                     (!a.res || (a.res_cs % 8 == 0 && ((uintptr_t)a.res & 15) == 0)))
+                        ? 2 : lean ? 1 : 0;
+    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
+                        CK, TH, WAVES, epi))
         return H3D_OK;
-    if (lean)
-        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, true>), grid, dim3(C::THREADS), 0, st, a);
+    if constexpr (C::EPI_LDS_OK) {
+        if (epi == 2) {
+            hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, 2>), grid, dim3(C::THREADS), 0, st, a);
+            H3D_CHECK_LAUNCH("conv_kernel");
+            return H3D_OK;
+        }
+    }
+    if (epi == 1)
+        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, 1>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, false>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv_kernel<T, KS, STRIDE, MT, CK, TH, WAVES, 0>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("conv_kernel");
     return H3D_OK;
 }

@@ -111,30 +111,31 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[MT][NT], const EpiAr
 // 32 pixels x 32*MT channels (bias, residual, ReLU applied in fp32, then rounded) into its own LDS region
 // [32 px][64*MT + 16 B], then streams them out 16 bytes per lane with the lanes of a pixel adjacent:
 // whole lines per store instruction.  No workgroup barrier: a wave only touches its own region
-// (`lw`, epi_lds_stride<MT>() bytes = 32 * (64*MT + 16) rounded up to whole KiB for the residual DMA; it must
+// (`lw`, epi_lds_stride<MT, NT>() bytes = NT * 32 * (64*MT + 16) rounded up to whole KiB for the residual DMA; it must
 // no longer be read by anyone else).  Residual images must be smaller than 2 GiB (buffer offsets).
-template <int MT> constexpr int epi_lds_stride() { return (32 * (64 * MT + 16) + 1023) / 1024 * 1024; }
+template <int MT, int NT = 1> constexpr int epi_lds_stride() { return (NT * 32 * (64 * MT + 16) + 1023) / 1024 * 1024; }
 
-template <int MT, bool HASRES>
-__device__ __forceinline__ void tile_epilogue_lds_impl(f32x16 (&acc)[MT][1], const EpiArgs &a, int b, int oy0, int ox0,
+template <int MT, int NT, bool HASRES>
+__device__ __forceinline__ void tile_epilogue_lds_impl(f32x16 (&acc)[MT][NT], const EpiArgs &a, int b, int oy0, int ox0,
                                                        int cout0, int wv, int l, char *lw)
 {
     constexpr int ROWB = 64 * MT + 16;
     constexpr int SPP = 4 * MT;                  // 16-byte slots per pixel
+    constexpr int NPX = 32 * NT;                 // pixels of this wave: rows wv*2NT .. +2NT-1 of the tile, 16 wide
     const int r = l & 31, h = l >> 5;
     if constexpr (HASRES) {
         // residual tile: LDS-DMA straight into this wave's region in the layout the result will have
-        // ([32 px][SPP data slots + 1 pad slot]); pad slots, pixels outside the image and channels past Cout
+        // ([NPX px][SPP data slots + 1 pad slot]); pad slots, pixels outside the image and channels past Cout
         // carry an out-of-range offset (zeros, no traffic).  Whole lines per request, no registers.
         const size_t img_bytes = (size_t)a.Ho * a.Wo * a.res_cs * 2;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res + (size_t)b * img_bytes), 0, (int)img_bytes, 0x00020000);
-        constexpr int PIECES = (32 * ROWB + 1023) / 1024;
+        constexpr int PIECES = (NPX * ROWB + 1023) / 1024;
 #pragma unroll
         for (int pc = 0; pc < PIECES; ++pc) {
             const int q = pc * 64 + l;
             const int p = q / (SPP + 1), sl = q - p * (SPP + 1);
-            const int oy = oy0 + 2 * wv + (p >> 4), ox = ox0 + (p & 15);
-            const bool ok = p < 32 && sl < SPP && oy < a.Ho && ox < a.Wo && cout0 + sl * 8 < a.Cout;
+            const int oy = oy0 + 2 * NT * wv + (p >> 4), ox = ox0 + (p & 15);
+            const bool ok = p < NPX && sl < SPP && oy < a.Ho && ox < a.Wo && cout0 + sl * 8 < a.Cout;
             const int voff = ok ? ((oy * a.Wo + ox) * a.res_cs + cout0 + sl * 8) * 2 : 0x7ffffff0;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(lw + pc * 1024), 16, voff, 0, 0, 0);
         }
@@ -150,29 +151,31 @@ __device__ __forceinline__ void tile_epilogue_lds_impl(f32x16 (&acc)[MT][1], con
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const float4 *>(bp + m * 32 + 8 * g);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = m * 32 + 8 * g;
-                const float4 bv = bias4[g];
-                float v0 = acc[m][0][4 * g + 0] + bv.x, v1 = acc[m][0][4 * g + 1] + bv.y;
-                float v2 = acc[m][0][4 * g + 2] + bv.z, v3 = acc[m][0][4 * g + 3] + bv.w;
-                char *slot = lw + r * ROWB + (co + 4 * h) * 2;      // this lane's 4 channels of its pixel
-                if constexpr (HASRES) {
-                    const u32x2 rr = *reinterpret_cast<const u32x2 *>(slot);
-                    v0 += __uint_as_float(rr[0] << 16); v1 += __uint_as_float(rr[0] & 0xffff0000u);
-                    v2 += __uint_as_float(rr[1] << 16); v3 += __uint_as_float(rr[1] & 0xffff0000u);
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = m * 32 + 8 * g;
+                    const float4 bv = bias4[g];
+                    float v0 = acc[m][n][4 * g + 0] + bv.x, v1 = acc[m][n][4 * g + 1] + bv.y;
+                    float v2 = acc[m][n][4 * g + 2] + bv.z, v3 = acc[m][n][4 * g + 3] + bv.w;
+                    char *slot = lw + (n * 32 + r) * ROWB + (co + 4 * h) * 2;      // this lane's 4 channels of its pixel
+                    if constexpr (HASRES) {
+                        const u32x2 rr = *reinterpret_cast<const u32x2 *>(slot);
+                        v0 += __uint_as_float(rr[0] << 16); v1 += __uint_as_float(rr[0] & 0xffff0000u);
+                        v2 += __uint_as_float(rr[1] << 16); v3 += __uint_as_float(rr[1] & 0xffff0000u);
+                    }
+                    const u32x2 pk = {pack_bf16x2(fmaxf(v0, lo), fmaxf(v1, lo)), pack_bf16x2(fmaxf(v2, lo), fmaxf(v3, lo))};
+                    *reinterpret_cast<u32x2 *>(slot) = pk;
                 }
-                const u32x2 pk = {pack_bf16x2(fmaxf(v0, lo), fmaxf(v1, lo)), pack_bf16x2(fmaxf(v2, lo), fmaxf(v3, lo))};
-                *reinterpret_cast<u32x2 *>(slot) = pk;
-            }
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): my wave's LDS writes are done
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < SPP / 2; ++it) {
+    for (int it = 0; it < NT * SPP / 2; ++it) {
         const int q = it * 64 + l;
         const int p = q / SPP, sl = q - p * SPP;
-        const int oy = oy0 + 2 * wv + (p >> 4), ox = ox0 + (p & 15);
+        const int oy = oy0 + 2 * NT * wv + (p >> 4), ox = ox0 + (p & 15);
         if (oy < a.Ho && ox < a.Wo && cout0 + sl * 8 < a.Cout) {
             const u32x4 v = *reinterpret_cast<const u32x4 *>(lw + p * ROWB + sl * 16);
             const size_t opix = ((size_t)b * a.Ho + oy) * a.Wo + ox;
@@ -181,10 +184,10 @@ __device__ __forceinline__ void tile_epilogue_lds_impl(f32x16 (&acc)[MT][1], con
     }
 }
 
-template <int MT>
-__device__ __forceinline__ void tile_epilogue_lds(f32x16 (&acc)[MT][1], const EpiArgs &a, int b, int oy0, int ox0,
+template <int MT, int NT = 1>
+__device__ __forceinline__ void tile_epilogue_lds(f32x16 (&acc)[MT][NT], const EpiArgs &a, int b, int oy0, int ox0,
                                                   int cout0, int wv, int l, char *lw)
 {
-    if (a.res) tile_epilogue_lds_impl<MT, true>(acc, a, b, oy0, ox0, cout0, wv, l, lw);     // wave-uniform
-    else tile_epilogue_lds_impl<MT, false>(acc, a, b, oy0, ox0, cout0, wv, l, lw);
+    if (a.res) tile_epilogue_lds_impl<MT, NT, true>(acc, a, b, oy0, ox0, cout0, wv, l, lw);     // wave-uniform
+    else tile_epilogue_lds_impl<MT, NT, false>(acc, a, b, oy0, ox0, cout0, wv, l, lw);
 }
