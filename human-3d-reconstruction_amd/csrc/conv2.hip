@@ -30,9 +30,9 @@ struct Conv2Args {
     int dbg;   // ABLATE builds only (op.reserved >> 16): 1 = no DMA after stage 0, 2 = no fragment reads / MFMA
 };
 
-template <int MT, int WAVES, int S = 1, int SLOTS = 2>
+template <int MT, int WAVES, int S = 1, int SLOTS = 2, int NT = 1>
 struct Conv2Cfg {
-    static constexpr int TH = 2 * WAVES;
+    static constexpr int TH = 2 * WAVES * NT;           // a wave owns NT N-tiles (2 rows x 16 px each): filter fragments are reused NT times
     static constexpr int HROWS = (TH - 1) * S + 3;      // halo rows
     static constexpr int HCOLS = 15 * S + 3;            // halo pixels per row: 18 (stride 1) / 33 (stride 2)
     static constexpr int PPR = S;                       // 1 KiB DMA pieces per halo row (3 slots per pixel)
@@ -44,7 +44,7 @@ struct Conv2Cfg {
     static constexpr int WPIECES = (MT * WGRP + 1023) / 1024;
     static constexpr int WALLOC = WPIECES * 1024;
     static constexpr int SLOT = HALO + WALLOC;
-    static constexpr int LDS_EPI = WAVES * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // tile_epilogue_lds regions
+    static constexpr int LDS_EPI = WAVES * ((NT * 32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // tile_epilogue_lds regions
     static constexpr int LDS_RING = SLOTS * SLOT;   // SLOTS = 1: single-stage layers (Cin = 16) keep more workgroups per CU
     static constexpr int LDS = LDS_RING > LDS_EPI ? LDS_RING : LDS_EPI;
     static constexpr int THREADS = 64 * WAVES;
@@ -56,11 +56,11 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 // LDS-DMA of one stage into the ring slot at `base` (a plain function of plain arguments: the buffer-descriptor
 // type does not exist in the host pass, and a lambda capturing one silently drops the kernel's stub)
-template <int MT, int WAVES, int S>
+template <int MT, int WAVES, int S, int NT>
 __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, const char *wimg, int w_bytes, char *base,
                                             const int *hoff, int woff, int wv, int s, int wsrc, int dbg = 0)
 {
-    using C = Conv2Cfg<MT, WAVES, S>;
+    using C = Conv2Cfg<MT, WAVES, S, 2, NT>;
     // descriptors are rebuilt from wave-uniform scalars at every call (4 SGPRs each, no memory traffic)
     const auto r_in = __builtin_amdgcn_make_buffer_rsrc((void *)in_b, 0, in_bytes, 0x00020000);
     const auto r_w = __builtin_amdgcn_make_buffer_rsrc((void *)wimg, 0, w_bytes, 0x00020000);
@@ -77,10 +77,10 @@ __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, cons
     }
 }
 
-template <int MT, int WAVES, int EPI, int S = 1, int SLOTS = 2>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
+template <int MT, int WAVES, int EPI, int S = 1, int SLOTS = 2, int NT = 1>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
 __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 {
-    using C = Conv2Cfg<MT, WAVES, S, SLOTS>;
+    using C = Conv2Cfg<MT, WAVES, S, SLOTS, NT>;
     using E = ET<bf16_t>;
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
 
@@ -114,15 +114,17 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     const int woff = l * 16;
 
     // fragment offsets inside a slot
-    const int py = 2 * wv + (r >> 4), px = r & 15;
+    const int py = 2 * NT * wv + (r >> 4), px = r & 15;      // N-tile n adds 2 rows
     const int boff = py * S * C::ROWB + px * S * 48 + h * 16;
     const int aoff = C::HALO + r * C::WROW + h * 16;
 
-    f32x16 acc[MT][1];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
     // ring of SLOTS stages: stage s + SLOTS - 1 is issued when stage s starts, so a stage has SLOTS - 1 stages of
     // MFMA time to land (with 2 slots the SQ counters showed the waves parked ~48 % of the time)
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 #pragma unroll
     for (int j = 0; j < AHEAD; ++j)
         if (j < nst && (SLOTS > 1 || j == 0))
-            conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + j * C::SLOT, hoff, woff, wv, j, (j * a.G + g0) * C::WGRP, H3D_DBG(a));
+            conv2_issue<MT, WAVES, S, NT>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + j * C::SLOT, hoff, woff, wv, j, (j * a.G + g0) * C::WGRP, H3D_DBG(a));
     int cslot = 0, pslot = AHEAD % SLOTS;          // slot consumed by stage s / filled with stage s + AHEAD
     for (int s = 0; s < nst; ++s) {
         // my pieces of stage s have landed once only stage s+1's may be outstanding (vmcnt retires in order)
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
         else __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();                          // ... everyone's have; the slot of stage s-1 is no longer being read
         if (SLOTS > 1 && s + AHEAD < nst && !(H3D_DBG(a) & 1))
-            conv2_issue<MT, WAVES, S>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + pslot * C::SLOT, hoff, woff, wv, s + AHEAD, ((s + AHEAD) * a.G + g0) * C::WGRP, H3D_DBG(a));
+            conv2_issue<MT, WAVES, S, NT>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + pslot * C::SLOT, hoff, woff, wv, s + AHEAD, ((s + AHEAD) * a.G + g0) * C::WGRP, H3D_DBG(a));
         const char *sl = smem + cslot * C::SLOT;
         cslot = cslot + 1 == SLOTS ? 0 : cslot + 1;
         pslot = pslot + 1 == SLOTS ? 0 : pslot + 1;
@@ -149,12 +151,16 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
-            const typename E::frag fb = E::lds_frag(sl + boff + dy * C::ROWB + dx * 48);
+            typename E::frag fb[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(sl + boff + (2 * n * S + dy) * C::ROWB + dx * 48);
             typename E::frag fa[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) fa[m] = E::lds_frag(sl + aoff + m * C::WGRP + tap * 32);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) E::mma(acc[m][0], fa[m], fb);
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
         }
     }
 
@@ -163,16 +169,16 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2) {
         __syncthreads();                          // nobody reads the ring any more
-        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
+        tile_epilogue_lds<MT, NT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT, NT>());
     } else {
-        tile_epilogue<bf16_t, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+        tile_epilogue<bf16_t, MT, NT, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }
 }
 
-template <int MT, int WAVES, int S = 1, int SLOTS = 2>
+template <int MT, int WAVES, int S = 1, int SLOTS = 2, int NT = 1>
 static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
 {
-    using C = Conv2Cfg<MT, WAVES, S, SLOTS>;
+    using C = Conv2Cfg<MT, WAVES, S, SLOTS, NT>;
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     Conv2Args a = a0;
     a.tiles_x = cdiv(a.Wo, 16);
@@ -180,13 +186,13 @@ static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4)) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d, %d>", MT, WAVES, epi, S, SLOTS)) return H3D_OK;
+    if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d, %d, %d>", MT, WAVES, epi, S, SLOTS, NT)) return H3D_OK;
     if (epi == 2)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S, SLOTS>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
     else if (epi == 1)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1, S, SLOTS>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0, S, SLOTS>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("conv2_kernel");
     return H3D_OK;
 }
@@ -229,6 +235,8 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
         case 0x204: return launch_conv2_cfg<2, 4>(a, st);
         case 0x108: return launch_conv2_cfg<1, 8>(a, st);
         case 0x104: return launch_conv2_cfg<1, 4>(a, st);
+        case 0x2408: return launch_conv2_cfg<4, 8, 1, 2, 2>(a, st);   // 0x2...: two N-tiles per wave (32 x 16 px tile, 8 waves)
+        case 0x2208: return launch_conv2_cfg<2, 8, 1, 2, 2>(a, st);
         case 0x3208: return launch_conv2_cfg<2, 8, 1, 3>(a, st);      // 0x3...: three ring slots
         case 0x3108: return launch_conv2_cfg<1, 8, 1, 3>(a, st);
         case 0x3404: return launch_conv2_cfg<4, 4, 1, 3>(a, st);
