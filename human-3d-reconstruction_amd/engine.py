@@ -232,16 +232,25 @@ class PackedWeights:
 class Plan:
     """Op array + the buffers it points into, for one (B,H,W)."""
 
-    def __init__(self, pw, B, H, W, fuse_heads=True, fuse_offsets=True, stream_convs=True, stream_dcn=True, stream_s2=True, wide_heads_m2=0, stream_dcn3=False, fuse_stem=True):
-        self.fuse_heads = fuse_heads
-        self.fuse_offsets = fuse_offsets
-        self.stream_convs = stream_convs
-        self.stream_dcn = stream_dcn
-        self.stream_s2 = stream_s2
+    # lowering switches (DLAEngine mirrors them as attributes; the defaults are the measured-best choices)
+    FLAGS = dict(
+        fuse_heads=True,       # False: one conv3x3 + conv1x1 launch pair per head (debug/ablation)
+        fuse_offsets=True,     # False: conv_offset_mask as its own launch + dcn2_kernel reading NHWC offsets
+        stream_convs=True,     # False: 3x3 convs through the register-staged kernel (csrc/conv.hip)
+        stream_dcn=True,       # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
+        stream_s2=True,        # False: stride-2 3x3 convs (Cin >= 64) through csrc/conv.hip
+        stream_dcn3=False,     # True: the remaining fused DeformConvs take their filters by LDS-DMA as well (measured: no gain)
+        fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
+        wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
+    )
+
+    def __init__(self, pw, B, H, W, **flags):
+        unknown = set(flags) - set(self.FLAGS)
+        if unknown:
+            raise TypeError("unknown lowering flags: %s" % sorted(unknown))
+        for k, v in self.FLAGS.items():
+            setattr(self, k, flags.get(k, v))
         self.stream_s2_min_cin = 64     # measured: the 32-channel stride-2 layer is faster on csrc/conv.hip (0.136 vs 0.165 ms)
-        self.wide_heads_m2 = wide_heads_m2
-        self.stream_dcn3 = stream_dcn3
-        self.fuse_stem = fuse_stem
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -532,22 +541,18 @@ class DLAEngine:
             raise RuntimeError("Not implemented on the CPU")
         self.pw = PackedWeights(state_dict, heads, use_dcn, dtype, self.device, head_conv)
         self.plans = {}
-        self.fuse_heads = True          # False: one conv3x3 + conv1x1 launch pair per head (debug/ablation)
-        self.fuse_offsets = True        # False: conv_offset_mask as its own launch + dcn2_kernel reading NHWC offsets
-        self.stream_convs = True        # False: 3x3 s1 convs through the register-staged kernel (csrc/conv.hip)
-        self.stream_dcn = True          # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
-        self.stream_s2 = True           # False: stride-2 3x3 convs (Cin >= 64) through csrc/conv.hip
-        self.stream_dcn3 = False        # True: the remaining fused DeformConvs take their filters by LDS-DMA as well (measured: no gain)
-        self.fuse_stem = True           # False: base_layer, level0 and level1 as three launches
-        self.wide_heads_m2 = 0          # 3: heads wider than 32 channels share one launch (3 output row tiles each)
+        for k, v in Plan.FLAGS.items():   # lowering switches, see Plan.FLAGS (changing one requires plans.clear())
+            setattr(self, k, v)
         self.streams = 1                # >1: run that many sub-batches concurrently on their own HIP streams
+
+    def _flags(self):
+        return {k: getattr(self, k) for k in Plan.FLAGS}
 
     def plan(self, B, H, W):
         key = (B, H, W)
         if key not in self.plans:
             with torch.cuda.device(self.device):
-                self.plans[key] = Plan(self.pw, B, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                                       stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2, stream_dcn3=self.stream_dcn3, fuse_stem=self.fuse_stem)
+                self.plans[key] = Plan(self.pw, B, H, W, **self._flags())
         return self.plans[key]
 
     def forward(self, images):
@@ -576,8 +581,7 @@ class DLAEngine:
         key = ("split", B, H, W)
         with torch.cuda.device(self.device):
             if key not in self.plans:
-                plans = [Plan(self.pw, sub, H, W, fuse_heads=self.fuse_heads, fuse_offsets=self.fuse_offsets,
-                              stream_convs=self.stream_convs, stream_dcn=self.stream_dcn, stream_s2=self.stream_s2, wide_heads_m2=self.wide_heads_m2, stream_dcn3=self.stream_dcn3, fuse_stem=self.fuse_stem)
+                plans = [Plan(self.pw, sub, H, W, **self._flags())
                          for _ in range(n)]
                 full = {h: torch.empty((B,) + tuple(o.shape[1:]), dtype=o.dtype, device=o.device)
                         for h, o in plans[0].outputs.items()}
