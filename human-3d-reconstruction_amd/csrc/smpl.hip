@@ -499,6 +499,32 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[c][t][i] = 0.f;
 
+    // the 3x4 transforms of a skinning round (8 persons per wave: [8][288] floats = 576 float4, 9 per lane) are fetched
+    // into registers one round ahead -- round 0 before the contraction -- so no round waits on global memory
+    constexpr int NA4 = S3_RP * SMPL_J * 3 / 64;          // 9
+    f32x4 apre[NA4];
+    auto load_A = [&](int rnd) {
+#pragma unroll
+        for (int k = 0; k < NA4; ++k) {
+            const int i = l + 64 * k;
+            const int q = i / (SMPL_J * 3), rr = i - q * (SMPL_J * 3);
+            const int p = p0 + wv * 32 + rnd * S3_RP + q;
+            apre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p < P) apre[k] = *reinterpret_cast<const f32x4 *>(A + (size_t)p * SMPL_J * 12 + 4 * rr);
+        }
+    };
+    load_A(0);
+    // this lane's vertex in the skinning phase: template position and (<= 4) joint indices / weights, also fetched early
+    const int v = v0 + l;
+    const int vc = v < V ? v : V - 1;
+    int jidx[4];
+    float jw[4];
+#pragma unroll
+    for (int sI = 0; sI < 4; ++sI) {
+        jidx[sI] = sI < nnz ? lbs_idx[(size_t)vc * nnz + sI] : 0;
+        jw[sI] = sI < nnz ? lbs_w[(size_t)vc * nnz + sI] : 0.f;
+    }
+    const float t0 = v_template[vc], t1 = v_template[Vpad + vc], t2 = v_template[2 * Vpad + vc];
     s3_issue((const char *)dirsK3, dbytes, (const char *)coefK3, cbytes, smem, aoff, boff, wv, 0);
     const int fa_off = r * S3_ROWB + h * 16;                                   // + (c * 64 + t * 32) rows, + part * 32
     const int fb_off = S3_APIECES * 1024 + (wv * 32 + r) * S3_ROWB + h * 16;
@@ -533,16 +559,6 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
 #endif
 
     // ---- skinning, lane = vertex (as gen 2): four rounds of 8 persons per wave -------------------------
-    const int v = v0 + l;
-    const int vc = v < V ? v : V - 1;
-    int jidx[4];
-    float jw[4];
-#pragma unroll
-    for (int sI = 0; sI < 4; ++sI) {
-        jidx[sI] = sI < nnz ? lbs_idx[(size_t)vc * nnz + sI] : 0;
-        jw[sI] = sI < nnz ? lbs_w[(size_t)vc * nnz + sI] : 0.f;
-    }
-    const float t0 = v_template[vc], t1 = v_template[Vpad + vc], t2 = v_template[2 * Vpad + vc];
     char *sT = smem + wv * (S3_RP * S3_TSTRIDE);                                // [8 persons][64 v][3] (+1)
     float *sA = reinterpret_cast<float *>(smem + 4 * S3_RP * S3_TSTRIDE) + wv * (S3_RP * SMPL_J * 12);
 #pragma unroll
@@ -561,15 +577,15 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
                         *reinterpret_cast<float *>(sT + pl * S3_TSTRIDE + (vl * 3 + c) * 4) = acc[c][t][i];
                     }
         }
-        // (b) the 3x4 transforms of those 8 persons: [8][288] floats = 576 float4, 9 per lane
-        for (int i = l; i < S3_RP * SMPL_J * 3; i += 64) {
+        // (b) the 3x4 transforms of those 8 persons (prefetched), then the next round's go in flight
+#pragma unroll
+        for (int k = 0; k < NA4; ++k) {
+            const int i = l + 64 * k;
             const int q = i / (SMPL_J * 3), rr = i - q * (SMPL_J * 3);
-            const int p = p0 + wv * 32 + rnd * S3_RP + q;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (p < P) val = *reinterpret_cast<const f32x4 *>(A + (size_t)p * SMPL_J * 12 + 4 * rr);
-            *reinterpret_cast<f32x4 *>(sA + q * SMPL_J * 12 + 4 * rr) = val;
+            *reinterpret_cast<f32x4 *>(sA + q * SMPL_J * 12 + 4 * rr) = apre[k];
         }
         __syncthreads();
+        if (rnd + 1 < 32 / S3_RP) load_A(rnd + 1);
         // (c) lane = vertex
 #pragma unroll 4
         for (int q = 0; q < S3_RP; ++q) {
