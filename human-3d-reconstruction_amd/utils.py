@@ -51,3 +51,32 @@ def _transpose_and_gather_feat(feat, ind):
     _lib.check(_lib.lib().h3d_gather_feat(_lib.ptr(feat), _lib.ptr(ind), B, C, H * W, K, 0, _lib.ptr(out),
                                           _lib.stream_ptr()), "_transpose_and_gather_feat")
     return out
+
+
+def flip_tensor(x):
+    """reference models/utils.py:29-30: mirror the width axis of an NCHW map."""
+    return torch.flip(x, [3])
+
+
+def _swap_index(n, flip_idx):
+    idx = list(range(n))
+    for a, b in flip_idx:                      # the reference swaps rows in sequence (utils.py:37-39)
+        idx[a], idx[b] = idx[b], idx[a]
+    return idx
+
+
+def flip_lr(x, flip_idx):
+    """reference models/utils.py:34-40 (flip test of the joint heat maps): mirror the width axis and swap the
+    left/right channel pairs of `flip_idx`; stays on the tensor's device (the reference round-trips through numpy)."""
+    y = torch.flip(x, [3])
+    return y[:, torch.as_tensor(_swap_index(x.shape[1], flip_idx), device=x.device)].contiguous()
+
+
+def flip_lr_off(x, flip_idx):
+    """reference models/utils.py:42-51 (flip test of the joint offsets `hps` [B,34,H,W]): mirror the width axis,
+    negate the x offsets, swap the left/right joint pairs."""
+    B, C, H, W = x.shape
+    y = torch.flip(x, [3]).reshape(B, 17, 2, H, W).clone()
+    y[:, :, 0] *= -1
+    y = y[:, torch.as_tensor(_swap_index(17, flip_idx), device=x.device)]
+    return y.reshape(B, C, H, W).contiguous()

@@ -174,3 +174,25 @@ def strict_prefix(scores, K):
     while p < n and uniq[p]:
         p += 1
     return p
+
+
+# ---- flip-test helpers (reference models/utils.py:29-51), numpy restatement ------------------------------
+def flip_tensor(x):
+    return x[..., ::-1].copy()
+
+
+def flip_lr(x, flip_idx):
+    tmp = x[..., ::-1].copy()
+    for e in flip_idx:
+        tmp[:, e[0], ...], tmp[:, e[1], ...] = tmp[:, e[1], ...].copy(), tmp[:, e[0], ...].copy()
+    return tmp
+
+
+def flip_lr_off(x, flip_idx):
+    tmp = x[..., ::-1].copy()
+    shape = tmp.shape
+    tmp = tmp.reshape(tmp.shape[0], 17, 2, tmp.shape[2], tmp.shape[3])
+    tmp[:, :, 0, :, :] *= -1
+    for e in flip_idx:
+        tmp[:, e[0], ...], tmp[:, e[1], ...] = tmp[:, e[1], ...].copy(), tmp[:, e[0], ...].copy()
+    return tmp.reshape(shape)

@@ -93,3 +93,21 @@ def test_gather_detections_world2_gloo():
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_OK" in r.stdout
+
+
+def test_flip_helpers_match_the_reference_semantics():
+    # models/utils.py:29-51 (flip test): host helpers (torch, device-resident) vs the numpy restatement
+    import numpy as np
+    import torch
+    from h3d_amd import utils
+    from oracle import decode as odec
+    flip_idx = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]      # COCO left/right joints
+    rng = np.random.default_rng(0)
+    hm = rng.standard_normal((2, 17, 6, 10)).astype(np.float32)
+    hps = rng.standard_normal((2, 34, 6, 10)).astype(np.float32)
+    assert np.array_equal(utils.flip_tensor(torch.from_numpy(hm)).numpy(), odec.flip_tensor(hm))
+    assert np.array_equal(utils.flip_lr(torch.from_numpy(hm), flip_idx).numpy(), odec.flip_lr(hm, flip_idx))
+    assert np.array_equal(utils.flip_lr_off(torch.from_numpy(hps), flip_idx).numpy(), odec.flip_lr_off(hps, flip_idx))
+    # overlapping pairs are applied in sequence, as the reference's loop does
+    odd = [[0, 1], [1, 2]]
+    assert np.array_equal(utils.flip_lr(torch.from_numpy(hm), odd).numpy(), odec.flip_lr(hm, odd))
