@@ -29,21 +29,29 @@ struct Dcn4Args {
     int B, H, W, in_cs;
     int Cout, out_cs, relu, out_mode, wrows;
     int G, tiles_x, tiles_y;
+    int dbg;            // profiling (ABLATE builds): leave after 1 the DMA prologue, 2 phase A, 3 geometry, 4 phase B
 };
 
-template <int MT>
+// DENSE = 0: MARGIN 2, apron rows of 4 KiB, three-slot main-filter ring, one 8-wave workgroup per CU (148 KiB).
+// DENSE = 1: MARGIN 1, apron rows of 3 KiB, ONE filter slot, 79 KiB -> two workgroups per CU (<= 128 VGPRs):
+//            the second workgroup computes while the first waits for its apron / filter stage / stores,
+//            which the phase timings showed to be 40 % of a tile (prologue DMA 18 %, stores 22 %).
+template <int MT, int DENSE>
 struct Dcn4Cfg {
-    static constexpr int MARGIN = 2;
-    static constexpr int HH = 16 + 2 + 2 * MARGIN;     // 22
-    static constexpr int PXB = 144, ROWB = 4096;
-    static constexpr int APRON = HH * ROWB;            // 90112
+    static constexpr int MARGIN = DENSE ? 1 : 2;
+    static constexpr int HH = 16 + 2 + 2 * MARGIN;     // 22 / 20
+    static constexpr int PXB = 144;
+    static constexpr int ROWB = (HH * PXB + 1023) / 1024 * 1024;   // 4096 / 3072: 0 mod 256 B
+    static constexpr int RPARTS = ROWB / 1024;
+    static constexpr int APIECES = HH * RPARTS;        // 88 / 60
+    static constexpr int APRON = HH * ROWB;            // 90112 / 61440
     static constexpr int WROW = 19 * 16, WGRP = 32 * WROW;
     static constexpr int WPIECES = (MT * WGRP + 1023) / 1024;
     static constexpr int WSLOT = WPIECES * 1024;
-    static constexpr int OPIECES = (WGRP + 1023) / 1024;    // offset-filter stage: 10 pieces
-    static constexpr int NSLOT = 3;                    // main-filter ring: stage s+2 is in flight while stage s is consumed
-    static constexpr int OALL = (4 * WGRP + 1023) / 1024;   // all four offset-filter stages at once: 38 pieces
-    static constexpr int RING = (NSLOT * WSLOT > OALL * 1024) ? NSLOT * WSLOT : OALL * 1024;
+    static constexpr int NSLOT = DENSE ? 1 : 3;        // main-filter ring: stage s+NSLOT-1 is in flight while stage s is consumed
+    static constexpr int OROUND = DENSE ? 2 : 4;       // offset-filter stages that land together
+    static constexpr int OPIECES = (OROUND * WGRP + 1023) / 1024;
+    static constexpr int RING = (NSLOT * WSLOT > OPIECES * 1024) ? NSLOT * WSLOT : OPIECES * 1024;
     static constexpr int LDS = APRON + RING;
     static constexpr int NSTAGE = 4;                   // 64 input channels / 16
 };
@@ -62,10 +70,10 @@ __device__ __forceinline__ void dcn4_issue_w(const char *base, int bytes, char *
     }
 }
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
+template <int MT, int EPI, int DENSE>
+__global__ __launch_bounds__(512, DENSE ? 4 : 2) void dcn4_kernel(Dcn4Args a)
 {
-    using C = Dcn4Cfg<MT>;
+    using C = Dcn4Cfg<MT, DENSE>;
     using X = SE<bf16_t>;
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
     char *s_ring = smem + C::APRON;
@@ -88,28 +96,28 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
     const int woffl = l * 16;
     const int off_bytes = C::NSTAGE * C::WGRP, main_bytes = C::NSTAGE * a.G * C::WGRP;
 
-    // ---- apron: 88 pieces (22 rows x 4), wave w takes pieces w, w+8, ...: piece & 3 == w & 3, so a
-    //      lane's pixel column and channel slot are fixed and only the row changes --------------------
+    // ---- apron: HH rows x RPARTS KiB pieces, wave w takes pieces w, w+8, ...; a lane's pixel column and channel
+    //      slot follow from the piece's KiB within the row ---------------------------------------------
     {
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, (int)img_bytes, 0x00020000);
-        const int slot = (wv & 3) * 64 + l;
-        const int ix = slot / 9, sub = slot - 9 * ix;
-        const int gx = hx0 + ix;
-        const bool okx = ix < C::HH && sub < 8 && gx >= 0 && gx < a.W;
-        const int xoff = (gx * a.in_cs + sub * 8) * 2;
 #pragma unroll
-        for (int j = 0; j < 11; ++j) {
-            const int q = wv + 8 * j;                 // < 88
-            const int row = q >> 2;
-            const int gy = hy0 + row;
-            const int voff = (okx && gy >= 0 && gy < a.H) ? gy * a.W * a.in_cs * 2 + xoff : 0x7ffffff0;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void4 *)(smem + q * 1024), 16, voff, 0, 0, 0);
+        for (int j = 0; j < (C::APIECES + 7) / 8; ++j) {
+            const int q = wv + 8 * j;
+            if (q < C::APIECES) {
+                const int row = q / C::RPARTS, part = q - row * C::RPARTS;
+                const int slot = part * 64 + l;
+                const int ix = slot / 9, sub = slot - 9 * ix;
+                const int gx = hx0 + ix, gy = hy0 + row;
+                const bool ok = ix < C::HH && sub < 8 && gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;
+                const int voff = ok ? ((gy * a.W + gx) * a.in_cs + sub * 8) * 2 : 0x7ffffff0;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void4 *)(smem + q * 1024), 16, voff, 0, 0, 0);
+            }
         }
     }
-    // all four offset-filter stages land in the (still idle) main-filter ring together with the apron: phase A
-    // then runs its 36 MFMAs per wave without a single wait (staged one by one, each 9-MFMA stage exposed a full
-    // DMA round trip: the SQ counters showed the waves parked 52 % of the time)
-    dcn4_issue_w<C::OALL>(a.woff, off_bytes, s_ring, 0, woffl, wv);
+    // the first OROUND offset-filter stages land in the (still idle) main-filter ring together with the apron; with
+    // all four (DENSE = 0) phase A runs its 36 MFMAs per wave without a single wait (staged one by one, each 9-MFMA
+    // stage exposed a full DMA round trip: the SQ counters showed the waves parked 52 % of the time)
+    dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring, 0, woffl, wv);
 
     // ================= phase A: offsets/mask = conv3x3(x; 27 filters) ==================================
     f32x16 aoffs;                                 // accumulators start at the (permuted) offset bias: its loads retire with the
@@ -122,9 +130,16 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
     const int aoff = r * C::WROW + h * 16;
     __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0)
     __syncthreads();
+    if (H3D_DBG(a) == 1) return;
 #pragma unroll
     for (int s = 0; s < C::NSTAGE; ++s) {
-        const char *sw = s_ring + s * C::WGRP;
+        if (s > 0 && s % C::OROUND == 0) {        // DENSE: stages 2,3 replace 0,1 (the CU's other workgroup covers the wait)
+            __syncthreads();
+            dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring, s * C::WGRP, woffl, wv);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+        }
+        const char *sw = s_ring + (s % C::OROUND) * C::WGRP;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
@@ -133,9 +148,10 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
             X::mma(aoffs, fa, fb);
         }
     }
-    __syncthreads();                              // the ring is free: main stages 0 and 1 fly while the geometry is computed
+    __syncthreads();                              // the ring is free: the first main stages fly while the geometry is computed
+    if (H3D_DBG(a) == 2) { if (aoffs[0] == 1234.5f) a.out[0] = 1; return; }
     dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring, g0 * C::WGRP, woffl, wv);
-    dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + C::WSLOT, (a.G + g0) * C::WGRP, woffl, wv);
+    if (C::NSLOT > 1) dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + C::WSLOT, (a.G + g0) * C::WGRP, woffl, wv);
 
     // ================= geometry (branch free): my taps (h=0: 0..4, h=1: 5..8), cross-half exchange ====
     int boff[9];
@@ -181,6 +197,7 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
         }
     }
 
+    if (H3D_DBG(a) == 3) { int q = 0; for (int u = 0; u < 9; ++u) q += boff[u] + geo[u].w01 + geo[u].w23; if (q == 12345) a.out[0] = 1; __builtin_amdgcn_s_waitcnt(0x0f70); return; }
     // ================= phase B: deformable contraction (branch-free, apron samples) ==================
     f32x16 acc[MT][1];
 #pragma unroll
@@ -189,39 +206,67 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
 #pragma unroll
     for (int s = 0; s < C::NSTAGE; ++s) {
-        // stage s has landed once at most the pieces of stage s+1 are outstanding: every wave issues at least
-        // PMIN pieces per stage and vmcnt retires in order, so vmcnt(PMIN) is safe for all waves
         constexpr int PMIN = C::WPIECES / 8;
         static_assert(PMIN >= 1 && PMIN <= 15, "vmcnt immediate");
-        if (s + 1 < C::NSTAGE) __builtin_amdgcn_s_waitcnt(0x0f70 | PMIN);
-        else __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        if (s + 2 < C::NSTAGE)
-            dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + ((s + 2) % C::NSLOT) * C::WSLOT, ((s + 2) * a.G + g0) * C::WGRP, woffl, wv);
+        if constexpr (C::NSLOT > 1) {
+            // stage s has landed once at most the pieces of stage s+1 are outstanding: every wave issues at least
+            // PMIN pieces per stage and vmcnt retires in order, so vmcnt(PMIN) is safe for all waves
+            if (s + 1 < C::NSTAGE) __builtin_amdgcn_s_waitcnt(0x0f70 | PMIN);
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            if (s + 2 < C::NSTAGE)
+                dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring + ((s + 2) % C::NSLOT) * C::WSLOT, ((s + 2) * a.G + g0) * C::WGRP, woffl, wv);
+        } else {
+            if (s > 0) {
+                __syncthreads();
+                dcn4_issue_w<C::WPIECES>(a.wimg, main_bytes, s_ring, (s * a.G + g0) * C::WGRP, woffl, wv);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+        }
         const char *sw = s_ring + (s % C::NSLOT) * C::WSLOT;
-        // software pipeline: tap t+1's four corner fragments and filter fragments are in flight while tap t is
-        // blended and multiplied (2 waves per SIMD cannot hide the LDS latency by themselves: the SQ counters
-        // showed the waves parked on s_waitcnt half of the time)
-        typename X::frag v[2][4], fa[2][MT];
-        auto gather = [&](int tap, int buf) {
-            const char *p00 = smem + boff[tap] + s * 32;
-            v[buf][0] = X::lds(p00);
-            v[buf][1] = X::lds(p00 + C::PXB);
-            v[buf][2] = X::lds(p00 + C::ROWB);
-            v[buf][3] = X::lds(p00 + C::ROWB + C::PXB);
+        if constexpr (!DENSE) {
+            // software pipeline: tap t+1's four corner fragments and filter fragments are in flight while tap t is
+            // blended and multiplied (2 waves per SIMD cannot hide the LDS latency by themselves: the SQ counters
+            // showed the waves parked on s_waitcnt half of the time)
+            typename X::frag v[2][4], fa[2][MT];
+            auto gather = [&](int tap, int buf) {
+                const char *p00 = smem + boff[tap] + s * 32;
+                v[buf][0] = X::lds(p00);
+                v[buf][1] = X::lds(p00 + C::PXB);
+                v[buf][2] = X::lds(p00 + C::ROWB);
+                v[buf][3] = X::lds(p00 + C::ROWB + C::PXB);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) fa[buf][m] = X::lds(sw + aoff + m * C::WGRP + tap * 32);
-        };
-        gather(0, 0);
+                for (int m = 0; m < MT; ++m) fa[buf][m] = X::lds(sw + aoff + m * C::WGRP + tap * 32);
+            };
+            gather(0, 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) gather(tap + 1, (tap + 1) & 1);
-            const typename X::frag fb = X::blend(v[tap & 1], geo[tap]);
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) gather(tap + 1, (tap + 1) & 1);
+                const typename X::frag fb = X::blend(v[tap & 1], geo[tap]);
 #pragma unroll
-            for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[tap & 1][m], fb);
+                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[tap & 1][m], fb);
+            }
+        } else {
+            // four waves per SIMD: the other waves cover the LDS latency, no register double buffer
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const char *p00 = smem + boff[tap] + s * 32;
+                typename X::frag v[4], fa[MT];
+                v[0] = X::lds(p00);
+                v[1] = X::lds(p00 + C::PXB);
+                v[2] = X::lds(p00 + C::ROWB);
+                v[3] = X::lds(p00 + C::ROWB + C::PXB);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds(sw + aoff + m * C::WGRP + tap * 32);
+                const typename X::frag fb = X::blend(v, geo[tap]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb);
+            }
         }
     }
 
+    if (H3D_DBG(a) == 4) { if (acc[0][0][0] + acc[MT - 1][0][5] == 1234.5f) a.out[0] = 1; return; }
     // ================= pass 2 (rare): samples whose corners left the apron ===========================
     if (__syncthreads_or(slow ? 1 : 0)) {
         for (int s = 0; s < C::NSTAGE; ++s) {
@@ -279,24 +324,25 @@ __global__ __launch_bounds__(512) void dcn4_kernel(Dcn4Args a)
     }
 }
 
-template <int MT>
+template <int MT, int DENSE>
 static int launch_dcn4_cfg(const Dcn4Args &a0, hipStream_t st)
 {
-    using C = Dcn4Cfg<MT>;
-    static_assert(C::LDS <= 160 * 1024, "LDS budget");
+    using C = Dcn4Cfg<MT, DENSE>;
+    static_assert(C::LDS <= (DENSE ? 80 : 160) * 1024, "LDS budget");
+    static_assert(8 * epi_lds_stride<MT>() <= C::LDS, "epilogue staging");
     Dcn4Args a = a0;
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("dcn4_kernel<%d, %d>", MT, epi)) return H3D_OK;
+    if (h3d_note_kernel("dcn4_kernel<%d, %d, %d>", MT, epi, DENSE)) return H3D_OK;
     if (epi == 2)
-        hipLaunchKernelGGL((dcn4_kernel<MT, 2>), grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((dcn4_kernel<MT, 2, DENSE>), grid, dim3(512), 0, st, a);
     else if (epi == 1)
-        hipLaunchKernelGGL((dcn4_kernel<MT, 1>), grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((dcn4_kernel<MT, 1, DENSE>), grid, dim3(512), 0, st, a);
     else
-        hipLaunchKernelGGL((dcn4_kernel<MT, 0>), grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((dcn4_kernel<MT, 0, DENSE>), grid, dim3(512), 0, st, a);
     H3D_CHECK_LAUNCH("dcn4_kernel");
     return H3D_OK;
 }
@@ -318,7 +364,8 @@ int h3d_launch_dcn4(const h3d_op &op, hipStream_t st)
     a.in = (const char *)op.in; a.wimg = (const char *)op.w; a.woff = (const char *)op.in2; a.bias = op.bias;
     a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.in_cs = op.in_cs;
     a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode; a.wrows = op.wrows;
-    a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0;
-    if (op.Cout <= 32) return launch_dcn4_cfg<1>(a, st);
-    return launch_dcn4_cfg<2>(a, st);
+    a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0; a.dbg = op.reserved & 0xff;
+    const bool dense = !(op.reserved & 0x100);    // tuning override (tools/ab_conv.py): 0x100 = one workgroup per CU
+    if (op.Cout <= 32) return dense ? launch_dcn4_cfg<1, 1>(a, st) : launch_dcn4_cfg<1, 0>(a, st);
+    return dense ? launch_dcn4_cfg<2, 1>(a, st) : launch_dcn4_cfg<2, 0>(a, st);
 }

@@ -253,6 +253,33 @@ def test_streamed_dcn_matches_dcn3(offset_scale, tol):
         assert e_ref <= max(BF16_TOL, 1.5 * e_off), (k, e_ref, e_off)
 
 
+@pytest.mark.parametrize("offset_scale", [0.5, 3.0, 12.0])
+def test_dcn4_two_workgroups_per_cu_matches_one(offset_scale):
+    # csrc/dcn4.hip DENSE = 1 (margin-1 apron, single filter slot, the default) vs DENSE = 0 (margin 2, 3-slot ring;
+    # h3d_op.reserved = 0x100): same arithmetic per sample, only the split between the apron pass and the
+    # global-gather pass 2 differs (offset_scale 3 puts samples between the two margins), i.e. fp32 summation order
+    from h3d_amd import _lib
+    sd = synth.synth_state_dict(arch.state_dict_shapes(HEADS, True), seed=0, offset_scale=offset_scale)
+    m = model.dla_net(HEADS, not_use_dcn=False, dtype="bf16")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=31)).to(DEV)
+    dense = {k: v.clone() for k, v in m(xs)[0].items()}
+    plan = m.engine(xs.device).plan(2, 96, 160)
+    idx = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_DCN_FUSED_F16]
+    assert idx
+    try:
+        for i in idx:
+            plan.op_array[i].reserved = 0x100
+        one = {k: v.clone() for k, v in m(xs)[0].items()}
+    finally:
+        for i in idx:
+            plan.op_array[i].reserved = 0
+    for k in HEADS:
+        e = float((dense[k] - one[k]).abs().max())
+        assert e <= 2e-2, (k, e)
+
+
 @pytest.mark.parametrize("offset_scale,tol", [(0.5, 6e-2), (12.0, 0.25)])
 def test_dma_filter_dcn3_matches_register_staged(offset_scale, tol):
     # csrc/dcn3.hip with the filters as stage-major images copied by LDS-DMA (H3D_OP_DCN_FUSED_STREAM) vs the
