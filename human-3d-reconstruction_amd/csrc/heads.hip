@@ -18,11 +18,16 @@
 // so the A-fragment ds_read_b128 stay conflict-free.  The 1x1 slice of a slab arrives the same way.
 // Outputs are written as contiguous NCHW fp32 rows (lane = pixel), the reference's head layout.
 #include "common.h"
+#include <type_traits>
+#include <utility>
 
 constexpr int HEADS_MAX = 16;
 constexpr int HC_IN = 64;     // channels of y (DLA-34 first_level = 2)
 constexpr int HC_SLAB = 64;   // intermediate channels per slab (two 32-row MFMA tiles)
 constexpr int HC_MT2 = 3;     // up to 96 output channels per head
+#ifndef HEADS_PF
+#define HEADS_PF 2      // measured 0: 1.363, 1: 1.348, 2: 1.335, 3: 1.343 ms (batch 64, the narrow-heads launch)
+#endif
 
 struct HeadsArgs {
     const char *in;      // NHWC T feature map
@@ -60,6 +65,18 @@ struct HeadsCfg {
     static constexpr int VPR = HC_IN * ES / 16;       // 16-byte vectors per halo pixel
 };
 
+// 16-byte LDS read the compiler's wait-count pass does not see (see heads_kernel's stage): the caller waits.
+template <int OFF>
+__device__ __forceinline__ void lds_read16_async(u32x4 &dst, uint32_t addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 __device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
@@ -84,36 +101,59 @@ __device__ __forceinline__ void heads_issue_bias(const float *b1, int hc, const 
 // The accumulator registers 8s..8s+7 of a 32x32 tile are K-step s of the B operand (lane = pixel);
 // the matching A fragment (K in accumulator-row order) sits at K offset m*32 + h*16 + s*8 of the
 // host-permuted W2 row (swizzled LDS image, see HeadsCfg).
-template <typename T, int TH, int NT, int M2>
+// BIASC: the accumulators were STARTED at b1 (C operand of the slab's first MFMA, see heads_kernel), so the slab leaves
+// them as conv + bias and nothing is added or zeroed here; on bf16 the ReLU runs on the packed pairs (v_pk_max_i16
+// against 0: a negative bf16 is a negative int16, and rounding never changes the sign).  That is 64 vector
+// instructions per slab and wave instead of 224 -- all eight waves do this at the same time, right after a barrier,
+// with the MFMA pipe idle.
+template <typename T, int TH, int NT, int M2, bool BIASC>
 __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][NT], const char *s_b1 /* LDS: this slab's 64 b1 */,
                                       const char *s_w2, int r, int h, int sw)
 {
     using C = HeadsCfg<T, TH>;
     using E = ET<T>;
     constexpr int ES = sizeof(T);
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb) {
             typename E::frag fb[NT];
             // accumulator registers 8sb..8sb+7 hold channels m*32 + 16sb + 4h + {0..3} and + 8 + {0..3}
-            const f32x4 b_lo = *reinterpret_cast<const f32x4 *>(s_b1 + (m * 32 + 16 * sb + 4 * h) * 4);
-            const f32x4 b_hi = *reinterpret_cast<const f32x4 *>(s_b1 + (m * 32 + 16 * sb + 4 * h + 8) * 4);
-            const float bias[8] = {b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+            float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if constexpr (!BIASC) {
+                const f32x4 b_lo = *reinterpret_cast<const f32x4 *>(s_b1 + (m * 32 + 16 * sb + 4 * h) * 4);
+                const f32x4 b_hi = *reinterpret_cast<const f32x4 *>(s_b1 + (m * 32 + 16 * sb + 4 * h + 8) * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bias[j] = b_lo[j]; bias[4 + j] = b_hi[j]; }
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 float x[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    x[j] = fmaxf(acc[m][n][8 * sb + j] + bias[j], 0.f);
-                    acc[m][n][8 * sb + j] = 0.f;
+                    if constexpr (BIASC) {
+                        x[j] = acc[m][n][8 * sb + j];
+                    } else {
+                        x[j] = fmaxf(acc[m][n][8 * sb + j] + bias[j], 0.f);
+                        acc[m][n][8 * sb + j] = 0.f;
+                    }
                 }
                 if constexpr (ES == 4) {
+                    if constexpr (BIASC) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
+                    }
                     fb[n].lo = f32x4{x[0], x[1], x[2], x[3]};
                     fb[n].hi = f32x4{x[4], x[5], x[6], x[7]};
                 } else {
-                    fb[n].v = u32x4{pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]),
-                                    pack_bf16x2(x[6], x[7])};
+                    uint32_t pk[4] = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
+                    if constexpr (BIASC) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[j]), s16x2{0, 0}));
+                    }
+                    fb[n].v = u32x4{pk[0], pk[1], pk[2], pk[3]};
                 }
             }
             const int c = (m * 32 + h * 16 + sb * 8) * ES / 16;        // first 16-byte chunk of this K run
@@ -128,7 +168,7 @@ __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][N
     }
 }
 
-template <typename T, int TH, int M2>
+template <typename T, int TH, int M2, bool BIASC>
 __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 {
     using C = HeadsCfg<T, TH>;
@@ -240,6 +280,94 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc2[m][n][i] = 0.f;
         for (int slab = 0; slab < slabs; ++slab) {
+            // one tap-row stage; FIRST: the slab's first MFMA of every accumulator tile takes its C operand from the
+            // bias tile (accumulator row = channel), so neither a zeroing pass nor a bias pass exists
+            auto stage = [&](auto first_tag, const char *slot, int tr) {
+                constexpr bool FIRST = decltype(first_tag)::value;
+                f32x16 bt[2];
+                if constexpr (FIRST) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 bv = *reinterpret_cast<const f32x4 *>(s_b + (slab * HC_SLAB + m * 32 + 8 * g + 4 * h) * 4);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) bt[m][4 * g + i] = bv[i];
+                        }
+                }
+                constexpr int NSTEP = C::TAPS * (HC_IN / 16);
+                if constexpr (ES == 2 && M2 == 1 && HEADS_PF > 0) {
+                    // bf16, narrow heads (registers to spare; a spilled fragment register would be saved before its data
+                    // arrived, so the wider variants -- which spill -- keep the compiler's schedule): explicit software pipeline.  The fragments of step i+1 (a step = one tap x 16 channels: 2 filter
+                    // + NT pixel fragments feeding 2*NT MFMAs) are requested BEFORE the MFMAs of step i and waited for with a
+                    // counted s_waitcnt.  Left to itself hipcc issues every ds_read right in front of its MFMA behind
+                    // lgkmcnt(0) -- and does so even when the loads are hoisted in the source -- so the reads are inline asm
+                    // (invisible to its wait-count pass) and the waits are ours: LDS returns in order, NT + 2 newer reads
+                    // may stay in flight.  sched_barrier pins the MFMAs behind their wait.
+                    const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)slot + r * C::RBW;
+                    uint32_t fa_base[HC_IN / 16];
+#pragma unroll
+                    for (int kk = 0; kk < HC_IN / 16; ++kk) fa_base[kk] = ring + (((2 * kk + h) ^ sw) << 4);
+                    const uint32_t fb_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)s_in + boff[0] + tr * C::RB;
+                    constexpr int PF = HEADS_PF, NBUF = PF + 1;          // steps in flight ahead of the MFMAs
+                    static_assert(PF * (NT + 2) <= 15, "lgkmcnt field");
+                    u32x4 fa[NBUF][2], fb[NBUF][NT];
+                    auto fetch = [&](auto step_tag) {
+                        constexpr int STEP = decltype(step_tag)::value, BUF = STEP % NBUF;
+                        constexpr int tp = STEP / (HC_IN / 16), kk = STEP - tp * (HC_IN / 16);
+                        lds_read16_async<(tp * HC_SLAB) * C::RBW>(fa[BUF][0], fa_base[kk]);
+                        lds_read16_async<(tp * HC_SLAB + 32) * C::RBW>(fa[BUF][1], fa_base[kk]);
+                        static_for<NT>([&](auto n_tag) {
+                            constexpr int n = decltype(n_tag)::value;
+                            lds_read16_async<n * C::RB + tp * C::SB + kk * 32>(fb[BUF][n], fb_base);
+                        });
+                    };
+                    static_for<PF>([&](auto step_tag) { fetch(step_tag); });
+                    static_for<NSTEP>([&](auto step_tag) {
+                        constexpr int STEP = decltype(step_tag)::value, BUF = STEP % NBUF;
+                        if constexpr (STEP + PF < NSTEP) fetch(std::integral_constant<int, STEP + PF>{});
+                        constexpr int NEWER = (STEP + PF < NSTEP ? PF : NSTEP - 1 - STEP) * (NT + 2);   // reads issued after step STEP's
+                        __builtin_amdgcn_s_waitcnt(0xc07f | (NEWER << 8));                              // lgkmcnt(NEWER)
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) {
+                                if (FIRST && STEP == 0) { acc[m][n] = bt[m]; }
+                                typename E::frag a_, b_;
+                                a_.v = fa[BUF][m]; b_.v = fb[BUF][n];
+                                E::mma(acc[m][n], a_, b_);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                } else {
+#pragma unroll
+                    for (int tp = 0; tp < C::TAPS; ++tp) {
+                        const int tap = tr * C::TAPS + tp;
+                        const int dy = tap / 3, dx = tap - dy * 3;
+                        const char *br = s_in + dy * C::RB + dx * C::SB;
+#pragma unroll
+                        for (int kk = 0; kk < HC_IN / 16; ++kk) {
+                            const int c = (kk * 16 + 8 * h) * ES / 16;
+                            typename E::frag fa[2], fb[NT];
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                const char *row = slot + (tp * HC_SLAB + m * 32 + r) * C::RBW;
+                                fa[m] = E::lds_frag2(row + ((c ^ sw) << 4), row + (((c + 1) ^ sw) << 4));
+                            }
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                                for (int n = 0; n < NT; ++n) {
+                                    if (FIRST && tp == 0 && kk == 0) { acc[m][n] = bt[m]; }
+                                    E::mma(acc[m][n], fa[m], fb[n]);
+                                }
+                        }
+                    }
+                }
+            };
 #pragma unroll 1
             for (int tr = 0; tr < C::TRS; ++tr, ++s) {
                 if (s + 1 < nstages) issue_w1(s + 1);          // slot (s+1)&1 was last read in stage s-1
@@ -248,32 +376,12 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                     heads_issue_bias(a.b1 + (head + 1) * a.head_conv, a.head_conv, a.b2[head + 1],   // previous head's epilogue, at least one barrier ago
                                      s_bias + ((head + 1) & 1) * C::LDS_BIAS, __builtin_amdgcn_readfirstlane(wv), l);
                 const char *slot = s_ring + (s & 1) * C::SLOT;
-#pragma unroll
-                for (int tp = 0; tp < C::TAPS; ++tp) {
-                    const int tap = tr * C::TAPS + tp;
-                    const int dy = tap / 3, dx = tap - dy * 3;
-                    const char *br = s_in + dy * C::RB + dx * C::SB;
-#pragma unroll
-                    for (int kk = 0; kk < HC_IN / 16; ++kk) {
-                        const int c = (kk * 16 + 8 * h) * ES / 16;
-                        typename E::frag fa[2], fb[NT];
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) {
-                            const char *row = slot + (tp * HC_SLAB + m * 32 + r) * C::RBW;
-                            fa[m] = E::lds_frag2(row + ((c ^ sw) << 4), row + (((c + 1) ^ sw) << 4));
-                        }
-#pragma unroll
-                        for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
-#pragma unroll
-                        for (int m = 0; m < 2; ++m)
-#pragma unroll
-                            for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
-                    }
-                }
+                if (BIASC && tr == 0) stage(std::true_type{}, slot, tr);
+                else stage(std::false_type{}, slot, tr);
                 __syncthreads();   // vmcnt(0) + barrier: next stage's weights (and the 1x1 slice) have landed
             }
-            // ---- slab done: X = ReLU(acc + b1) -> B operand; acc2 += W2[:, slab] . X; acc = 0 ------------
-            gemm2<T, TH, NT, M2>(acc, acc2, s_b + slab * HC_SLAB * 4, s_w2, r, h, sw);
+            // ---- slab done: X = ReLU(acc [+ b1]) -> B operand; acc2 += W2[:, slab] . X ----------------------
+            gemm2<T, TH, NT, M2, BIASC>(acc, acc2, s_b + slab * HC_SLAB * 4, s_w2, r, h, sw);
             if (C::TRS == 1) __syncthreads();   // (f32 path) s_w2 is rewritten in the very next stage
         }
         // ---- head done: z = acc2 + b2 -> NCHW fp32 (lane = pixel: coalesced rows) ------------------------
@@ -317,7 +425,7 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
     if (d->nheads <= 0 || d->nheads > HEADS_MAX) H3D_FAIL(H3D_ERR_SHAPE, "heads: %d heads (max %d)", d->nheads, HEADS_MAX);
     HeadsArgs a;
     a.in = (const char *)op.in; a.w1 = (const char *)op.w; a.b1 = op.bias;
-    a.dbg = op.reserved;
+    a.dbg = op.reserved & 0xff;
     a.nheads = d->nheads; a.head_conv = op.Cout; a.B = op.B; a.H = op.H; a.W = op.W; a.in_cs = op.in_cs;
     for (int i = 0; i < d->nheads; ++i) {
         if (!d->head[i].w2 || !d->head[i].b2 || !d->head[i].out) H3D_FAIL(H3D_ERR_ARG, "heads: head %d null pointer", i);
@@ -331,16 +439,24 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
     a.tiles_x = cdiv(op.W, 32); a.tiles_y = cdiv(op.H, th);
     const dim3 grid(op.B * a.tiles_x * a.tiles_y), blk(512);
     if (op.dtype != H3D_BF16 && op.dtype != H3D_F32) H3D_FAIL(H3D_ERR_DTYPE, "heads: dtype %d", op.dtype);
-    if (h3d_note_kernel("heads_kernel<%s, %d, %d>", op.dtype == H3D_BF16 ? "unsigned short" : "float", th, m2)) return H3D_OK;
+    const bool biasc = !(op.reserved & 0x200);    // tuning override (tools/ab_heads.py): 0x200 = separate bias / zeroing pass
+    if (h3d_note_kernel("heads_kernel<%s, %d, %d, %s>", op.dtype == H3D_BF16 ? "unsigned short" : "float", th, m2, biasc ? "true" : "false"))
+        return H3D_OK;
+#define H3D_HEADS_LAUNCH(T, TH, M2)                                                                 \
+    do {                                                                                             \
+        if (biasc) hipLaunchKernelGGL((heads_kernel<T, TH, M2, true>), grid, blk, 0, st, a);         \
+        else hipLaunchKernelGGL((heads_kernel<T, TH, M2, false>), grid, blk, 0, st, a);              \
+    } while (0)
     if (op.dtype == H3D_BF16) {
-        if (m2 == 1) hipLaunchKernelGGL((heads_kernel<bf16_t, 16, 1>), grid, blk, 0, st, a);
-        else if (m2 == 2) hipLaunchKernelGGL((heads_kernel<bf16_t, 16, 2>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((heads_kernel<bf16_t, 16, 3>), grid, blk, 0, st, a);
+        if (m2 == 1) H3D_HEADS_LAUNCH(bf16_t, 16, 1);
+        else if (m2 == 2) H3D_HEADS_LAUNCH(bf16_t, 16, 2);
+        else H3D_HEADS_LAUNCH(bf16_t, 16, 3);
     } else {
-        if (m2 == 1) hipLaunchKernelGGL((heads_kernel<float, 8, 1>), grid, blk, 0, st, a);
-        else if (m2 == 2) hipLaunchKernelGGL((heads_kernel<float, 8, 2>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((heads_kernel<float, 8, 3>), grid, blk, 0, st, a);
+        if (m2 == 1) H3D_HEADS_LAUNCH(float, 8, 1);
+        else if (m2 == 2) H3D_HEADS_LAUNCH(float, 8, 2);
+        else H3D_HEADS_LAUNCH(float, 8, 3);
     }
+#undef H3D_HEADS_LAUNCH
     H3D_CHECK_LAUNCH("heads_kernel");
     return H3D_OK;
 }

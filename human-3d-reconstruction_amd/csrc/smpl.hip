@@ -473,6 +473,10 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
     const int tid = threadIdx.x, l = tid & 63, r = l & 31, h = l >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v0 = blockIdx.x * S3_VT, p0 = blockIdx.y * S3_PB;
+#ifdef H3D_ABLATE
+    const bool contraction_only = nnz & 0x100;         // profiling flag rides on nnz
+    nnz &= 0xff;
+#endif
 
     // per-lane DMA source offsets (stage 0) of my pieces: slot q -> row q / 7, 16-byte column q % 7 (6 = pad)
     int aoff[(S3_APIECES + 3) / 4], boff[(S3_BPIECES + 3) / 4];
@@ -551,11 +555,10 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
     }
     __syncthreads();                                   // the ring is free: it becomes the transpose + transform staging area
 #ifdef H3D_ABLATE
-    if (nnz & 0x100) {      // ablation: contraction only
+    if (contraction_only) {
         if (acc[0][0][0] == 12345.678f) verts[0] = acc[1][1][3] + acc[2][0][5] + acc[0][1][7] + acc[1][0][2] + acc[2][1][9];
         return;
     }
-    nnz &= 0xff;
 #endif
 
     // ---- skinning, lane = vertex (as gen 2): four rounds of 8 persons per wave -------------------------
