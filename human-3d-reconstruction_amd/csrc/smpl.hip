@@ -10,6 +10,7 @@
 //                      Model tensors are stored K-major ([k][V*3]) so lanes (= vertices) read
 //                      consecutive addresses for every k.
 #include "common.h"
+#include <type_traits>
 
 constexpr int SMPL_J = 24;
 constexpr int SMPL_NB = 10;
@@ -423,46 +424,59 @@ extern "C" int h3d_smpl_verts(const float *betas, const float *pose_feat, const 
 //              ([16 h][16 m][16 l] = 96 B): dirsK3 [3][Vpad][14][3][16] (host pack), coefK3 [Ppad][14][3][16]
 //              (h3d_smpl_coef_pack).  One step per stage streams through a 2-slot LDS ring by LDS-DMA; row stride
 //              112 B (96 + 16 pad: odd multiple of 16 B, conflict-free ds_read_b128); one barrier per 36 MFMAs.
-//   workgroup  64 vertices x 128 persons, wave w = persons [32w, 32w+32) x 64 vertices x 3 coordinates
-//              (6 accumulator tiles).
+//   workgroup  64 vertices x 256 persons, 8 waves; wave w = persons [32w, 32w+32) x 64 vertices x 3 coordinates
+//              (6 accumulator tiles, the two tiles of a coordinate alternating in the MFMA stream).  170 B of LDS-DMA
+//              per MFMA instead of the 249 B of the first version (128 persons, 4 waves): 0.39 -> 0.30 ms for the
+//              contraction, which is bound by its data movement, not by the matrix pipe (0.155 ms at full rate):
+//              `make ABLATE=1` + H3D_SMPL_ABLATE: without the MFMAs it still takes 0.18 ms, without the direction
+//              reads 0.20, without the DMA 0.24.  Tried and measured neutral: an XCD-aware tile order (directions
+//              resident in one L2), a third ring slot (two stages in flight), DMA pieces issued between the MFMA groups.
 //   skinning   gen 2's 4-sparse LBS with lane = vertex: the accumulators (lane = person in the MFMA C layout)
 //              are transposed through LDS 8 persons at a time (person stride 193 dwords), so the transforms are
 //              broadcast-friendly reads and every person's 64 vertices leave as one contiguous 768-byte run.
-//              70 KB of LDS: two workgroups per CU, one's skinning overlaps the other's MFMAs.
-constexpr int S3_KP = 224, S3_NST = S3_KP / 16, S3_VT = 64, S3_PB = 128;
+//              The staging areas are private to a wave: wave-level ordering only, no workgroup barrier.
+constexpr int S3_KP = 224, S3_NST = S3_KP / 16, S3_VT = 64, S3_NW = 8, S3_PB = 32 * S3_NW;   // 8 waves x 32 persons
+constexpr int S3_PPAD = 128;                                  // the hosts pad the person count to this
 constexpr int S3_SPR = 7;                                     // 16-byte slots per row and stage: 6 data + 1 pad
 constexpr int S3_ROWB = S3_SPR * 16;                          // 112
 constexpr int S3_GROW = S3_NST * 96;                          // bytes of a row in global memory: 1344
 constexpr int S3_APIECES = 3 * S3_VT * S3_SPR / 64;           // 21 KiB pieces of direction rows
-constexpr int S3_BPIECES = S3_PB * S3_SPR / 64;               // 14 of coefficient rows
-constexpr int S3_SLOT = (S3_APIECES + S3_BPIECES) * 1024;     // 35840
+constexpr int S3_BPIECES = S3_PB * S3_SPR / 64;               // 28 of coefficient rows
+constexpr int S3_SLOT = (S3_APIECES + S3_BPIECES) * 1024;     // 50176
 constexpr int S3_RP = 8;                                      // persons per skinning round and wave
 constexpr int S3_TSTRIDE = 193 * 4;                           // transposed tile: bytes per person (64 v x 3 floats + 1)
-constexpr int S3_LBS = 4 * S3_RP * S3_TSTRIDE + 4 * S3_RP * SMPL_J * 12 * 4;   // 24704 + 36864
+constexpr int S3_LBS = S3_NW * S3_RP * S3_TSTRIDE + S3_NW * S3_RP * SMPL_J * 12 * 4;   // 49408 + 73728
 constexpr int S3_LDS = 2 * S3_SLOT > S3_LBS ? 2 * S3_SLOT : S3_LBS;
+
+constexpr int S3_AJ = (S3_APIECES + S3_NW - 1) / S3_NW, S3_BJ = (S3_BPIECES + S3_NW - 1) / S3_NW;   // pieces per wave: 3 + 4
+
+// piece j of this wave (0 .. S3_AJ-1 direction rows, then coefficient rows) of stage st -> slot
+__device__ __forceinline__ void s3_issue_piece(const char *dirsK, int dbytes, const char *coefK, int cbytes, char *slot,
+                                               const int *aoff, const int *boff, int wv, int st, int j)
+{
+    if (j < S3_AJ) {
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc((void *)dirsK, 0, dbytes, 0x00020000);
+        const int p = wv + S3_NW * j;
+        if (p < S3_APIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void *)(slot + p * 1024), 16, aoff[j], st * 96,
+                                                     0, 0);
+    } else {
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc((void *)coefK, 0, cbytes, 0x00020000);
+        const int p = wv + S3_NW * (j - S3_AJ);
+        if (p < S3_BPIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(slot + (S3_APIECES + p) * 1024), 16,
+                                                     boff[j - S3_AJ], st * 96, 0, 0);
+    }
+}
 
 __device__ __forceinline__ void s3_issue(const char *dirsK, int dbytes, const char *coefK, int cbytes, char *slot,
                                          const int *aoff, const int *boff, int wv, int st)
 {
-    const auto ra = __builtin_amdgcn_make_buffer_rsrc((void *)dirsK, 0, dbytes, 0x00020000);
-    const auto rb = __builtin_amdgcn_make_buffer_rsrc((void *)coefK, 0, cbytes, 0x00020000);
 #pragma unroll
-    for (int j = 0; j < (S3_APIECES + 3) / 4; ++j) {
-        const int p = wv + 4 * j;
-        if (p < S3_APIECES)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void *)(slot + p * 1024), 16, aoff[j], st * 96,
-                                                     0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < (S3_BPIECES + 3) / 4; ++j) {
-        const int p = wv + 4 * j;
-        if (p < S3_BPIECES)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void *)(slot + (S3_APIECES + p) * 1024), 16,
-                                                     boff[j], st * 96, 0, 0);
-    }
+    for (int j = 0; j < S3_AJ + S3_BJ; ++j) s3_issue_piece(dirsK, dbytes, coefK, cbytes, slot, aoff, boff, wv, st, j);
 }
 
-__global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restrict__ coefK3, const float *__restrict__ A,
+__global__ __launch_bounds__(64 * S3_NW) void smpl_verts3_kernel(const bf16_t *__restrict__ coefK3, const float *__restrict__ A,
                                                           const float *__restrict__ v_template,
                                                           const bf16_t *__restrict__ dirsK3, const int32_t *__restrict__ lbs_idx,
                                                           const float *__restrict__ lbs_w, int nnz, int P, int Ppad, int V,
@@ -474,22 +488,24 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int v0 = blockIdx.x * S3_VT, p0 = blockIdx.y * S3_PB;
 #ifdef H3D_ABLATE
-    const bool contraction_only = nnz & 0x100;         // profiling flag rides on nnz
+    const bool contraction_only = nnz & 0x100;         // profiling flags ride on nnz
+    const int ablate_mode = (nnz >> 9) & 3;
     nnz &= 0xff;
 #endif
 
     // per-lane DMA source offsets (stage 0) of my pieces: slot q -> row q / 7, 16-byte column q % 7 (6 = pad)
-    int aoff[(S3_APIECES + 3) / 4], boff[(S3_BPIECES + 3) / 4];
+    static_assert(S3_APIECES % S3_NW != 0 && S3_BPIECES % S3_NW != 0 && S3_AJ + S3_BJ == 7, "piece counts behind the vmcnt immediates");
+    int aoff[S3_AJ], boff[S3_BJ];
 #pragma unroll
-    for (int j = 0; j < (S3_APIECES + 3) / 4; ++j) {
-        const int q = (wv + 4 * j) * 64 + l;
+    for (int j = 0; j < (S3_APIECES + S3_NW - 1) / S3_NW; ++j) {
+        const int q = (wv + S3_NW * j) * 64 + l;
         const int row = q / S3_SPR, sub = q - S3_SPR * row;           // row = c * 64 + v
         const int c = row >> 6, v = row & 63;
         aoff[j] = (sub < S3_SPR - 1 && row < 3 * S3_VT) ? (c * Vpad + v0 + v) * S3_GROW + sub * 16 : 0x7ffffff0;
     }
 #pragma unroll
-    for (int j = 0; j < (S3_BPIECES + 3) / 4; ++j) {
-        const int q = (wv + 4 * j) * 64 + l;
+    for (int j = 0; j < (S3_BPIECES + S3_NW - 1) / S3_NW; ++j) {
+        const int q = (wv + S3_NW * j) * 64 + l;
         const int row = q / S3_SPR, sub = q - S3_SPR * row;           // row = person inside the workgroup
         boff[j] = (sub < S3_SPR - 1 && row < S3_PB) ? (p0 + row) * S3_GROW + sub * 16 : 0x7ffffff0;
     }
@@ -532,27 +548,52 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
     s3_issue((const char *)dirsK3, dbytes, (const char *)coefK3, cbytes, smem, aoff, boff, wv, 0);
     const int fa_off = r * S3_ROWB + h * 16;                                   // + (c * 64 + t * 32) rows, + part * 32
     const int fb_off = S3_APIECES * 1024 + (wv * 32 + r) * S3_ROWB + h * 16;
-    for (int st = 0; st < S3_NST; ++st) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        if (st + 1 < S3_NST)
-            s3_issue((const char *)dirsK3, dbytes, (const char *)coefK3, cbytes, smem + ((st + 1) & 1) * S3_SLOT, aoff, boff, wv, st + 1);
-        const char *sl = smem + (st & 1) * S3_SLOT;
-        const E::frag bh = E::lds_frag(sl + fb_off), bm = E::lds_frag(sl + fb_off + 32), bl = E::lds_frag(sl + fb_off + 64);
+    // MODE (profiling, ABLATE builds): 0 the contraction, 1 without the MFMAs, 2 without the direction-fragment reads,
+    // 3 without the DMA after stage 0
+    auto contract = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        for (int st = 0; st < S3_NST; ++st) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            if (st + 1 < S3_NST && MODE != 3)
+                s3_issue((const char *)dirsK3, dbytes, (const char *)coefK3, cbytes, smem + ((st + 1) & 1) * S3_SLOT, aoff, boff, wv, st + 1);
+            const char *sl = smem + (st & 1) * S3_SLOT;
+            const E::frag bh = E::lds_frag(sl + fb_off), bm = E::lds_frag(sl + fb_off + 32), bl = E::lds_frag(sl + fb_off + 64);
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const char *ap = sl + fa_off + (c * 64 + t * 32) * S3_ROWB;
-                const E::frag ah = E::lds_frag(ap), am = E::lds_frag(ap + 32), al = E::lds_frag(ap + 64);
-                E::mma(acc[c][t], al, bh);          // smallest terms first
-                E::mma(acc[c][t], ah, bl);
-                E::mma(acc[c][t], am, bm);
-                E::mma(acc[c][t], am, bh);
-                E::mma(acc[c][t], ah, bm);
-                E::mma(acc[c][t], ah, bh);
+            for (int c = 0; c < 3; ++c) {
+                // the two vertex tiles of a coordinate alternate, so consecutive MFMAs do not share an accumulator
+                const char *ap0 = sl + fa_off + (c * 64) * S3_ROWB, *ap1 = ap0 + 32 * S3_ROWB;
+                E::frag ah0 = bh, am0 = bm, al0 = bl, ah1 = bh, am1 = bm, al1 = bl;
+                if constexpr (MODE != 2) {
+                    ah0 = E::lds_frag(ap0); am0 = E::lds_frag(ap0 + 32); al0 = E::lds_frag(ap0 + 64);
+                    ah1 = E::lds_frag(ap1); am1 = E::lds_frag(ap1 + 32); al1 = E::lds_frag(ap1 + 64);
+                }
+                if constexpr (MODE == 1) {
+                    asm volatile("" ::"v"(ah0.v), "v"(am0.v), "v"(al0.v), "v"(ah1.v), "v"(am1.v), "v"(al1.v), "v"(bh.v), "v"(bm.v), "v"(bl.v));
+                } else {
+                    E::mma(acc[c][0], al0, bh);          // smallest terms first
+                    E::mma(acc[c][1], al1, bh);
+                    E::mma(acc[c][0], ah0, bl);
+                    E::mma(acc[c][1], ah1, bl);
+                    E::mma(acc[c][0], am0, bm);
+                    E::mma(acc[c][1], am1, bm);
+                    E::mma(acc[c][0], am0, bh);
+                    E::mma(acc[c][1], am1, bh);
+                    E::mma(acc[c][0], ah0, bm);
+                    E::mma(acc[c][1], ah1, bm);
+                    E::mma(acc[c][0], ah0, bh);
+                    E::mma(acc[c][1], ah1, bh);
+                }
             }
-    }
+        }
+    };
+#ifdef H3D_ABLATE
+    if (ablate_mode == 1) contract(std::integral_constant<int, 1>{});
+    else if (ablate_mode == 2) contract(std::integral_constant<int, 2>{});
+    else if (ablate_mode == 3) contract(std::integral_constant<int, 3>{});
+    else
+#endif
+        contract(std::integral_constant<int, 0>{});
     __syncthreads();                                   // the ring is free: it becomes the transpose + transform staging area
 #ifdef H3D_ABLATE
     if (contraction_only) {
@@ -563,10 +604,13 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
 
     // ---- skinning, lane = vertex (as gen 2): four rounds of 8 persons per wave -------------------------
     char *sT = smem + wv * (S3_RP * S3_TSTRIDE);                                // [8 persons][64 v][3] (+1)
-    float *sA = reinterpret_cast<float *>(smem + 4 * S3_RP * S3_TSTRIDE) + wv * (S3_RP * SMPL_J * 12);
+    float *sA = reinterpret_cast<float *>(smem + S3_NW * S3_RP * S3_TSTRIDE) + wv * (S3_RP * SMPL_J * 12);
 #pragma unroll
     for (int rnd = 0; rnd < 32 / S3_RP; ++rnd) {
-        if (rnd) __syncthreads();
+        // sT and sA are private to the wave and LDS executes a wave's instructions in order: wave-level ordering is all
+        // the rounds need, and without workgroup barriers the eight waves drift apart, one's transposition (LDS)
+        // under another's blend (vector ALU)
+        __builtin_amdgcn_wave_barrier();
         // (a) my accumulators of persons [8 rnd, 8 rnd + 8): C layout row = vertex, column = person
         if ((r / S3_RP) == rnd) {
             const int pl = r % S3_RP;
@@ -587,7 +631,7 @@ __global__ __launch_bounds__(256) void smpl_verts3_kernel(const bf16_t *__restri
             const int q = i / (SMPL_J * 3), rr = i - q * (SMPL_J * 3);
             *reinterpret_cast<f32x4 *>(sA + q * SMPL_J * 12 + 4 * rr) = apre[k];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         if (rnd + 1 < 32 / S3_RP) load_A(rnd + 1);
         // (c) lane = vertex
 #pragma unroll 4
@@ -649,7 +693,7 @@ __global__ void smpl_coef_pack_kernel(const float *__restrict__ betas, const flo
 extern "C" int h3d_smpl_coef_pack(const float *betas, const float *pose_feat, int P, int Ppad, void *coefK3, void *stream)
 {
     if (!betas || !pose_feat || !coefK3) H3D_FAIL(H3D_ERR_ARG, "smpl_coef_pack: null pointer");
-    if (P <= 0 || Ppad < P || Ppad % S3_PB) H3D_FAIL(H3D_ERR_SHAPE, "smpl_coef_pack: P=%d Ppad=%d (multiple of %d)", P, Ppad, S3_PB);
+    if (P <= 0 || Ppad < P || Ppad % S3_PPAD) H3D_FAIL(H3D_ERR_SHAPE, "smpl_coef_pack: P=%d Ppad=%d (multiple of %d)", P, Ppad, S3_PPAD);
     const size_t n = (size_t)Ppad * S3_KP;
     hipLaunchKernelGGL(smpl_coef_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, betas, pose_feat, P,
                        Ppad, (bf16_t *)coefK3);
@@ -663,17 +707,18 @@ extern "C" int h3d_smpl_verts3(const void *coefK3, const float *A, const float *
 {
     if (!coefK3 || !A || !v_template || !dirsK3 || !lbs_idx || !lbs_w || !verts) H3D_FAIL(H3D_ERR_ARG, "smpl_verts3: null pointer");
 #ifdef H3D_ABLATE
-    const int nnz_flags = getenv("H3D_SMPL_ABLATE") ? 0x100 : 0;
+    const char *abl = getenv("H3D_SMPL_ABLATE");      // bit 0: stop after the contraction; bits 1-2: contraction mode
+    const int nnz_flags = abl ? ((atoi(abl) & 1) << 8) | (((atoi(abl) >> 1) & 3) << 9) : 0;
 #else
     const int nnz_flags = 0;
 #endif
-    if (P <= 0 || V <= 0 || nnz <= 0 || nnz > 4 || Ppad % S3_PB || Ppad < P || Vpad % S3_VT || Vpad < V)
+    if (P <= 0 || V <= 0 || nnz <= 0 || nnz > 4 || Ppad % S3_PPAD || Ppad < P || Vpad % S3_VT || Vpad < V)
         H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts3: P=%d (pad %d, multiple of %d) V=%d (pad %d, multiple of %d) nnz=%d (<= 4)", P, Ppad,
-                 S3_PB, V, Vpad, S3_VT, nnz);
+                 S3_PPAD, V, Vpad, S3_VT, nnz);
     if ((size_t)3 * Vpad * S3_GROW >= 0x7ffffff0ull || (size_t)Ppad * S3_GROW >= 0x7ffffff0ull)
         H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts3: operand of 2 GiB or more");
-    dim3 grid(Vpad / S3_VT, Ppad / S3_PB);
-    hipLaunchKernelGGL(smpl_verts3_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)coefK3, A, v_template,
+    dim3 grid(Vpad / S3_VT, cdiv(Ppad, S3_PB));      // (coefficient rows past Ppad are outside the buffer: zeros)
+    hipLaunchKernelGGL(smpl_verts3_kernel, grid, dim3(64 * S3_NW), 0, (hipStream_t)stream, (const bf16_t *)coefK3, A, v_template,
                        (const bf16_t *)dirsK3, lbs_idx, lbs_w, nnz | nnz_flags, P, Ppad, V, Vpad, verts);
     H3D_CHECK_LAUNCH("smpl_verts3_kernel");
     return H3D_OK;

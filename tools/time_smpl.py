@@ -1,5 +1,6 @@
 """Profiling aid: time the SMPL kernels at the bench size (6400 persons).  With a `make ABLATE=1` build,
-H3D_SMPL_ABLATE=1 stops smpl_verts3 after the contraction."""
+H3D_SMPL_ABLATE=<bits> changes smpl_verts3: bit 0 stops after the contraction; bits 1-2 select the contraction mode
+(1 no MFMAs, 2 no direction-fragment reads, 3 no DMA after stage 0), e.g. 3 = contraction only, without MFMAs."""
 import sys, torch
 sys.path.insert(0, ".")
 import h3d_amd
