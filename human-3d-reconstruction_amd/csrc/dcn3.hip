@@ -70,7 +70,7 @@ __device__ __forceinline__ void dcn3_issue_w(const char *base, int bytes, char *
 }
 
 template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
-__global__ __launch_bounds__(512) void dcn3_kernel(Dcn3Args a)
+__global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kernel(Dcn3Args a)
 {
     using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA>;
     using X = SE<T>;
@@ -385,9 +385,8 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     return H3D_OK;
 }
 
-// channels per filter stage the fused kernel uses for a layer: hosts pack the stage-major images of
-// H3D_OP_DCN_FUSED_STREAM with this CK (32 for <= 64 output channels and Cin % 32 == 0, else 16)
-extern "C" int h3d_dcn_fused_ck(int Cin, int Cout) { return (Cin % 32 == 0 && Cout <= 64) ? 32 : 16; }
+// channels per filter stage of H3D_OP_DCN_FUSED_STREAM: hosts pack the stage-major filter images with this CK
+extern "C" int h3d_dcn_fused_ck(int Cin, int Cout) { (void)Cin; (void)Cout; return 16; }
 
 int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
 {
@@ -412,12 +411,10 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.dbg = op.reserved;
     a.G = op.wrows / 32;
     if (wdma) {
-        if (op.Cin % 32 == 0 && op.Cout <= 64) {
-            if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 32, 2, true>(a, st);
-            return launch_dcn3_cfg<bf16_t, 2, 32, 2, true>(a, st);
-        }
-        if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 2, true>(a, st);
-        if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 2, true>(a, st);
+        // <= 64 output channels: margin-1 apron, 16-channel stages, <= 128 VGPRs and 58 KB of LDS -> two workgroups
+        // (16 waves) per CU, one computing while the other waits at its stage barriers (as csrc/dcn4.hip DENSE)
+        if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 1, true>(a, st);
+        if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 1, true>(a, st);
         return launch_dcn3_cfg<bf16_t, 4, 16, 2, true>(a, st);
     }
     if (op.dtype == H3D_BF16) {

@@ -239,7 +239,9 @@ class Plan:
         stream_convs=True,     # False: 3x3 convs through the register-staged kernel (csrc/conv.hip)
         stream_dcn=True,       # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
         stream_s2=True,        # False: stride-2 3x3 convs (Cin >= 64) through csrc/conv.hip
-        stream_dcn3=False,     # True: the remaining fused DeformConvs take their filters by LDS-DMA as well (measured: no gain)
+        stream_dcn3=False,     # True: ALL remaining fused DeformConvs take their filters by LDS-DMA (no gain above 64 output channels)
+        dense_dcn3=True,       # those with <= 64 output channels do: margin-1 apron, two workgroups per CU (csrc/dcn3.hip)
+        dense_dcn3_min_tiles=512,   # ... when the layer has at least this many 16x16 tiles (two per CU)
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
     )
@@ -397,8 +399,12 @@ class Plan:
                      out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
                      stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
             return out
-        if self.pw.use_dcn and self.fuse_offsets and self.stream_dcn3 and self.pw.dtype == "bf16":
-            w = self.pw.sd[p + ".conv.weight"]
+        w = self.pw.sd[p + ".conv.weight"]
+        if (self.pw.use_dcn and self.fuse_offsets and self.pw.dtype == "bf16"
+                and (self.stream_dcn3 or (self.dense_dcn3 and w.shape[0] <= 64
+                                          # two workgroups per CU only pay with >= 2 x 256 tiles (measured: the 32x32 layer
+                                          # of a batch-64 plan, 256 tiles, 0.062 -> 0.076 ms)
+                                          and self.B * ((x.H + 15) // 16) * ((x.W + 15) // 16) >= self.dense_dcn3_min_tiles))):
             ck = int(_lib.lib().h3d_dcn_fused_ck(int(w.shape[1]), int(w.shape[0])))
             wimg, woimg, bias, cout, cin, rows = self.pw.dcn_stream(p, ck)
             if out is None:

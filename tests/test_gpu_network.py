@@ -290,7 +290,8 @@ def test_dma_filter_dcn3_matches_register_staged(offset_scale, tol):
     m = m.to(DEV).eval()
     xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=31)).to(DEV)
     eng = m.engine(xs.device)
-    eng.stream_dcn3 = True            # off by default (no speed-up measured); _ab leaves it on
+    eng.stream_dcn3 = True            # off by default (no speed-up measured above 64 output channels); _ab leaves it on
+    eng.dense_dcn3 = False            # so that "off" is the register-staged kernel on every layer
     eng.plans.clear()
     on, off = _ab(m, xs, "stream_dcn3")
     from h3d_amd import _lib
@@ -298,6 +299,31 @@ def test_dma_filter_dcn3_matches_register_staged(offset_scale, tol):
     for k in HEADS:
         e = float((on[k] - off[k]).abs().max())
         assert e <= tol, (k, e)
+
+
+@pytest.mark.parametrize("offset_scale,tol", [(0.5, 6e-2), (3.0, 0.1), (12.0, 0.25)])
+def test_dense_dcn3_matches_register_staged(offset_scale, tol):
+    # the default for DeformConvs with <= 64 output channels: csrc/dcn3.hip with DMA'd filters, a margin-1 apron and
+    # two workgroups per CU, vs the register-staged margin-2 kernel; offset_scale 3 puts samples between the two
+    # margins (apron pass on one side, global-gather pass 2 on the other), 12 drives most of them into pass 2
+    from h3d_amd import _lib
+    sd = synth.synth_state_dict(arch.state_dict_shapes(HEADS, True), seed=0, offset_scale=offset_scale)
+    m = model.dla_net(HEADS, not_use_dcn=False, dtype="bf16")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=41)).to(DEV)
+    m.engine(xs.device).dense_dcn3_min_tiles = 0      # (the default engages it from 512 tiles per layer)
+    on, off = _ab(m, xs, "dense_dcn3")
+    kinds = [op.kind for op in m.engine(xs.device).plan(2, 96, 160).ops]
+    assert _lib.OP_DCN_FUSED_STREAM in kinds and _lib.OP_DCN_FUSED in kinds
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(xs.cpu())[0]
+    for k in HEADS:
+        e = float((on[k] - off[k]).abs().max())
+        assert e <= tol, (k, e)
+        e_ref = float((on[k].cpu() - ref[k]).abs().max())
+        e_off = float((off[k].cpu() - ref[k]).abs().max())
+        assert e_ref <= max(BF16_TOL, 1.5 * e_off), (k, e_ref, e_off)
 
 
 def test_fused_stem_levels_match_three_launches():
