@@ -42,6 +42,8 @@ def op_flops(op):
         return 2.0 * px * op.Cout * op.Cin * op.ksize * op.ksize
     if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_F16, _lib.OP_DCN_FUSED_STREAM):
         return 2.0 * px * (op.Cout + 27) * op.Cin * 9
+    if op.kind == _lib.OP_UPDCN_F16:    # DeformConv (+ offset conv) at the output resolution, plus the 2x2-tap up-sampling
+        return 2.0 * px * ((op.Cout + 27) * op.Cin * 9 + op.Cin * 4)
     if op.kind == _lib.OP_STEM3:        # 7x7 3->16 and 3x3 16->16 at full resolution, 3x3 16->32 at half
         return 2.0 * op.B * (op.H * op.W * 16 * (3 * 49 + 16 * 9) + op.Ho * op.Wo * 32 * 16 * 9)
     if op.kind == _lib.OP_UPADD:

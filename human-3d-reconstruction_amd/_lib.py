@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libh3d_hip.so")
 
 H3D_F32, H3D_BF16 = 0, 1
 OP_STEM, OP_CONV, OP_DCN, OP_MAXPOOL, OP_UPADD, OP_COPY, OP_HEADS, OP_DCN_V1, OP_DCN_FUSED = 1, 2, 3, 4, 5, 6, 7, 8, 9
-OP_CONV_STREAM, OP_DCN_FUSED_F16, OP_DCN_FUSED_STREAM, OP_STEM3 = 10, 11, 12, 13
+OP_CONV_STREAM, OP_DCN_FUSED_F16, OP_DCN_FUSED_STREAM, OP_STEM3, OP_UPDCN_F16 = 10, 11, 12, 13, 14
 HEADS_MAX = 16
 OUT_NHWC, OUT_NCHW_F32, OUT_NHWC_F32, OUT_NHWC_F16 = 0, 1, 2, 3
 ABI_VERSION = 1
@@ -41,6 +41,11 @@ class _HeadEntry(ctypes.Structure):
 class H3dHeadsDesc(ctypes.Structure):
     """Mirror of `struct h3d_heads_desc` (host-side descriptor behind H3D_OP_HEADS)."""
     _fields_ = [("nheads", ctypes.c_int32), ("reserved", ctypes.c_int32), ("head", _HeadEntry * HEADS_MAX)]
+
+
+class H3dUpdcnDesc(ctypes.Structure):
+    """Mirror of `struct h3d_updcn_desc` (host-side descriptor behind H3D_OP_UPDCN_F16)."""
+    _fields_ = [("skip", c_vp), ("w_up", c_vp), ("w_off", c_vp), ("skip_cs", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 # name -> argtypes (restype is int unless noted); also the export list the CPU test checks

@@ -436,46 +436,6 @@ int h3d_launch_stem(const h3d_op &op, hipStream_t st)
 // Elementwise NHWC kernels (HBM-bound; 16 B per lane)
 template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
 
-template <typename T>
-__device__ __forceinline__ void unpack16(const u32x4 &v, float *o)
-{
-    if constexpr (sizeof(T) == 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(v[i]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[2 * i] = __uint_as_float(v[i] << 16);
-            o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
-        }
-    }
-}
-template <typename T>
-__device__ __forceinline__ u32x4 pack16(const float *o)
-{
-    u32x4 v;
-    if constexpr (sizeof(T) == 4) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(o[i]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
-    }
-    return v;
-}
-
-// 8 floats -> 8 fp16 (clamped to the fp16 range): the input format of csrc/dcn4.hip
-__device__ __forceinline__ u32x4 pack16_f16(const float *o)
-{
-    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-    u32x4 v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        v[i] = __builtin_bit_cast(uint32_t, h2{(_Float16)__builtin_amdgcn_fmed3f(o[2 * i], -65504.f, 65504.f),
-                                               (_Float16)__builtin_amdgcn_fmed3f(o[2 * i + 1], -65504.f, 65504.f)});
-    return v;
-}
-
 // 2x2/2 max pool (floor semantics of nn.MaxPool2d(2, stride=2), model.py:201)
 template <typename T>
 __global__ void maxpool_kernel(const T *__restrict__ in, T *__restrict__ out, int B, int H, int W, int C,

@@ -30,6 +30,11 @@ struct Dcn4Args {
     int Cout, out_cs, relu, out_mode, wrows;
     int G, tiles_x, tiles_y;
     int dbg;            // profiling (ABLATE builds): leave after 1 the DMA prologue, 2 phase A, 3 geometry, 4 phase B
+    // UP = 1 (H3D_OP_UPDCN_F16): the input is  skip + ConvTranspose2d_depthwise(xlo)  computed into the apron
+    const char *xlo;    // bf16 NHWC [B][Hl][Wl][xlo_cs], Hl = H / f
+    const char *skip;   // bf16 NHWC [B][H][W][skip_cs]
+    const float *wup;   // fp32 [k*k][64] tap-major (k = 2f), as H3D_OP_UPADD
+    int f, Hl, Wl, xlo_cs, skip_cs;
 };
 
 // DENSE = 0: MARGIN 2, apron rows of 4 KiB, three-slot main-filter ring, one 8-wave workgroup per CU (148 KiB).
@@ -70,7 +75,33 @@ __device__ __forceinline__ void dcn4_issue_w(const char *base, int bytes, char *
     }
 }
 
-template <int MT, int EPI, int DENSE>
+// UP, pass 2 only: 8 channels (c0 .. c0+7) of  skip + up(xlo)  at pixel (gy, gx) inside the image, straight from global
+// memory (tap table included): the same arithmetic as the apron prologue
+__device__ __forceinline__ u32x4 dcn4_up8(const Dcn4Args &a, const char *xb, const char *sb, int gy, int gx, int c0)
+{
+    const int fs = a.f >> 1, k = 2 * a.f, pd = a.f >> 1;
+    float acc[8], x[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] = 0.f;
+    const int ry = (gy + pd) & (a.f - 1), rx = (gx + pd) & (a.f - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ky = ry + (q >> 1) * a.f, kx = rx + (q & 1) * a.f;
+        const int ny = gy + pd - ky, nx = gx + pd - kx;
+        const int iy = ny >> fs, ix = nx >> fs;
+        if (!(ny >= 0 && iy < a.Hl && nx >= 0 && ix < a.Wl)) continue;
+        unpack16<bf16_t>(*reinterpret_cast<const u32x4 *>(xb + ((size_t)(iy * a.Wl + ix) * a.xlo_cs + c0) * 2), x);
+        const float *wp = a.wup + (ky * k + kx) * 64 + c0;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[n] = fmaf(wp[n], x[n], acc[n]);
+    }
+    unpack16<bf16_t>(*reinterpret_cast<const u32x4 *>(sb + ((size_t)(gy * a.W + gx) * a.skip_cs + c0) * 2), x);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[n] += x[n];
+    return pack16_f16(acc);
+}
+
+template <int MT, int EPI, int DENSE, int UP = 0>
 __global__ __launch_bounds__(512, DENSE ? 4 : 2) void dcn4_kernel(Dcn4Args a)
 {
     using C = Dcn4Cfg<MT, DENSE>;
@@ -96,6 +127,7 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void dcn4_kernel(Dcn4Args a)
     const int woffl = l * 16;
     const int off_bytes = C::NSTAGE * C::WGRP, main_bytes = C::NSTAGE * a.G * C::WGRP;
 
+    if constexpr (!UP) {
     // ---- apron: HH rows x RPARTS KiB pieces, wave w takes pieces w, w+8, ...; a lane's pixel column and channel
     //      slot follow from the piece's KiB within the row ---------------------------------------------
     {
@@ -118,6 +150,97 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void dcn4_kernel(Dcn4Args a)
     // all four (DENSE = 0) phase A runs its 36 MFMAs per wave without a single wait (staged one by one, each 9-MFMA
     // stage exposed a full DMA round trip: the SQ counters showed the waves parked 52 % of the time)
     dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring, 0, woffl, wv);
+    } else {
+    // ---- UP: the apron is computed, not copied: apron[y][x][c] = skip[y][x][c] + sum of the 2x2 taps of the depthwise
+    //      transposed convolution of xlo that reach (y, x) -- the arithmetic of upadd_kernel (csrc/conv.hip), same
+    //      order, same single rounding to fp16 -- so the up-sampled sum (134 MB at batch 64) never exists in HBM.
+    //      Thread = (channel vector tid & 7, apron pixel (tid >> 3) + 64 j); the k*k x 64 tap table sits in the idle ring.
+        const int fs = a.f >> 1;                                // f = 2 or 4: log2
+        const int k = 2 * a.f, pd = a.f >> 1;
+        const int vec = tid & 7, pp = tid >> 3;
+        const char *xb = a.xlo + (size_t)b * a.Hl * a.Wl * a.xlo_cs * 2;
+        const char *sb = a.skip + (size_t)b * a.H * a.W * a.skip_cs * 2;
+        constexpr int NIT = (C::HH * C::HH + 63) / 64;          // 7
+        u32x4 xv[2][4], sv[2];
+        auto geom = [&](int j, int &gy, int &gx, int &ldso) -> bool {
+            const int pidx = pp + 64 * j;
+            const int row = pidx / C::HH, col = pidx - row * C::HH;
+            gy = hy0 + row; gx = hx0 + col;
+            ldso = row * C::ROWB + col * C::PXB + vec * 16;
+            return pidx < C::HH * C::HH;
+        };
+        auto taps = [&](int g, int lim, int (&ii)[2], int (&kk)[2], bool (&ok)[2]) {   // one axis: input index, kernel index, valid
+            const int rr = (g + pd) & (a.f - 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                kk[t] = rr + t * a.f;
+                const int num = g + pd - kk[t];
+                ii[t] = num >> fs;                               // exact when num >= 0 (multiple of f)
+                ok[t] = num >= 0 && ii[t] < lim;
+            }
+        };
+        auto fetch = [&](int j, int buf) {
+            int gy, gx, ldso;
+            const bool live = geom(j, gy, gx, ldso) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            int iy[2], ky[2], ix[2], kx[2];
+            bool oky[2], okx[2];
+            taps(gy, a.Hl, iy, ky, oky);
+            taps(gx, a.Wl, ix, kx, okx);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xv[buf][q] = u32x4{0u, 0u, 0u, 0u};
+                if (live && oky[q >> 1] && okx[q & 1])
+                    xv[buf][q] = *reinterpret_cast<const u32x4 *>(xb + ((size_t)(iy[q >> 1] * a.Wl + ix[q & 1]) * a.xlo_cs + vec * 8) * 2);
+            }
+            sv[buf] = u32x4{0u, 0u, 0u, 0u};
+            if (live) sv[buf] = *reinterpret_cast<const u32x4 *>(sb + ((size_t)(gy * a.W + gx) * a.skip_cs + vec * 8) * 2);
+        };
+        const float *s_w = reinterpret_cast<const float *>(s_ring);
+        auto blend = [&](int j, int buf) {
+            int gy, gx, ldso;
+            if (!geom(j, gy, gx, ldso)) return;
+            const bool live = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            int iy[2], ky[2], ix[2], kx[2];
+            bool oky[2], okx[2];
+            taps(gy, a.Hl, iy, ky, oky);
+            taps(gx, a.Wl, ix, kx, okx);
+            float acc[8], x[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) acc[n] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!(live && oky[q >> 1] && okx[q & 1])) continue;     // taps (a, c2) ascending, as upadd_kernel
+                unpack16<bf16_t>(xv[buf][q], x);
+                const float *wp = s_w + (ky[q >> 1] * k + kx[q & 1]) * 64 + vec * 8;
+                const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) { acc[n] = fmaf(w0[n], x[n], acc[n]); acc[4 + n] = fmaf(w1[n], x[4 + n], acc[4 + n]); }
+            }
+            unpack16<bf16_t>(sv[buf], x);
+#pragma unroll
+            for (int n = 0; n < 8; ++n) acc[n] += x[n];
+            u32x4 o = pack16_f16(acc);
+            if (!live) o = u32x4{0u, 0u, 0u, 0u};                       // outside the image: the zero padding
+            *reinterpret_cast<u32x4 *>(smem + ldso) = o;
+        };
+        fetch(0, 0);
+        fetch(1, 1);
+        {   // tap table -> ring (KiB pieces), behind the first two fetches in the same vmcnt queue
+            const int tbytes = k * k * 64 * 4;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.wup, 0, tbytes, 0x00020000);
+            for (int p = wv; p * 1024 < tbytes; p += 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void4 *)(s_ring + p * 1024), 16, woffl, p * 1024, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) {
+            blend(j, j & 1);
+            if (j + 2 < NIT) fetch(j + 2, j & 1);
+        }
+        __syncthreads();                                        // apron complete, tap table no longer read
+        dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring, 0, woffl, wv);
+    }
 
     // ================= phase A: offsets/mask = conv3x3(x; 27 filters) ==================================
     f32x16 aoffs;                                 // accumulators start at the (permuted) offset bias: its loads retire with the
@@ -299,7 +422,18 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void dcn4_kernel(Dcn4Args a)
                         typename X::frag v[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            v[k] = ok[k] ? X::lds(img + ((size_t)pix[k] * a.in_cs + s * 16 + 8 * h) * 2) : X::zero();   // fp16 input: plain 16-byte load
+                        {
+                            if constexpr (UP) {
+                                v[k] = X::zero();
+                                if (ok[k]) {
+                                    const int yy = hl + (k >> 1), xx = wl + (k & 1);
+                                    v[k].v = __builtin_bit_cast(decltype(v[k].v), dcn4_up8(a, a.xlo + (size_t)b * a.Hl * a.Wl * a.xlo_cs * 2,
+                                                                                            a.skip + (size_t)b * a.H * a.W * a.skip_cs * 2, yy, xx, s * 16 + 8 * h));
+                                }
+                            } else {
+                                v[k] = ok[k] ? X::lds(img + ((size_t)pix[k] * a.in_cs + s * 16 + 8 * h) * 2) : X::zero();   // fp16 input: plain 16-byte load
+                            }
+                        }
                         fb = X::blend(v, g);
                     }
                 }
@@ -324,25 +458,26 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void dcn4_kernel(Dcn4Args a)
     }
 }
 
-template <int MT, int DENSE>
+template <int MT, int DENSE, int UP = 0>
 static int launch_dcn4_cfg(const Dcn4Args &a0, hipStream_t st)
 {
     using C = Dcn4Cfg<MT, DENSE>;
     static_assert(C::LDS <= (DENSE ? 80 : 160) * 1024, "LDS budget");
     static_assert(8 * epi_lds_stride<MT>() <= C::LDS, "epilogue staging");
+    static_assert(!UP || C::RING >= 8 * 8 * 64 * 4, "tap table of the 4x up-sampling in the ring");
     Dcn4Args a = a0;
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("dcn4_kernel<%d, %d, %d>", MT, epi, DENSE)) return H3D_OK;
+    if (h3d_note_kernel("dcn4_kernel<%d, %d, %d, %d>", MT, epi, DENSE, UP)) return H3D_OK;
     if (epi == 2)
-        hipLaunchKernelGGL((dcn4_kernel<MT, 2, DENSE>), grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((dcn4_kernel<MT, 2, DENSE, UP>), grid, dim3(512), 0, st, a);
     else if (epi == 1)
-        hipLaunchKernelGGL((dcn4_kernel<MT, 1, DENSE>), grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((dcn4_kernel<MT, 1, DENSE, UP>), grid, dim3(512), 0, st, a);
     else
-        hipLaunchKernelGGL((dcn4_kernel<MT, 0, DENSE>), grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((dcn4_kernel<MT, 0, DENSE, UP>), grid, dim3(512), 0, st, a);
     H3D_CHECK_LAUNCH("dcn4_kernel");
     return H3D_OK;
 }
@@ -365,7 +500,38 @@ int h3d_launch_dcn4(const h3d_op &op, hipStream_t st)
     a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.in_cs = op.in_cs;
     a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode; a.wrows = op.wrows;
     a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0; a.dbg = op.reserved & 0xff;
+    a.xlo = a.skip = nullptr; a.wup = nullptr; a.f = a.Hl = a.Wl = a.xlo_cs = a.skip_cs = 0;
     const bool dense = !(op.reserved & 0x100);    // tuning override (tools/ab_conv.py): 0x100 = one workgroup per CU
     if (op.Cout <= 32) return dense ? launch_dcn4_cfg<1, 1>(a, st) : launch_dcn4_cfg<1, 0>(a, st);
     return dense ? launch_dcn4_cfg<2, 1>(a, st) : launch_dcn4_cfg<2, 0>(a, st);
+}
+
+// H3D_OP_UPDCN_F16: IDAUp's  node(up(x) + skip)  in one launch (model.py:384-390): the depthwise transposed convolution and
+// the skip add are evaluated while the apron is filled (dcn4_kernel UP = 1).  op.in = x (bf16, H x W = the LOW resolution),
+// op.Ho x op.Wo = f * (H x W), op.stride = f, op.in2 = HOST pointer to h3d_updcn_desc, op.w / op.bias as DCN_FUSED_F16.
+int h3d_launch_updcn(const h3d_op &op, hipStream_t st)
+{
+    if (!op.in || !op.w || !op.bias || !op.out || !op.in2) H3D_FAIL(H3D_ERR_ARG, "updcn: null pointer");
+    const h3d_updcn_desc *d = (const h3d_updcn_desc *)op.in2;
+    if (!d->skip || !d->w_up || !d->w_off) H3D_FAIL(H3D_ERR_ARG, "updcn: null pointer in the descriptor");
+    if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "updcn: bf16 plans only (dtype %d)", op.dtype);
+    const int f = op.stride;
+    if ((f != 2 && f != 4) || op.Ho != op.H * f || op.Wo != op.W * f)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "updcn: up-sampling factor %d (2 or 4), %dx%d -> %dx%d", f, op.H, op.W, op.Ho, op.Wo);
+    if (op.Cin != 64 || op.in_cs % 8 || op.Cin > op.in_cs || d->skip_cs % 8 || d->skip_cs < 64)
+        H3D_FAIL(H3D_ERR_SHAPE, "updcn: Cin=%d (strides %d, %d), 64 expected", op.Cin, op.in_cs, d->skip_cs);
+    if (op.Cout > 64) H3D_FAIL(H3D_ERR_SHAPE, "updcn: Cout=%d > 64", op.Cout);
+    if (op.Ho > 32767 || op.Wo > 32767) H3D_FAIL(H3D_ERR_SHAPE, "updcn: image too large");
+    if (op.wrows % 128 || op.wrows < op.Cout) H3D_FAIL(H3D_ERR_SHAPE, "updcn: packed weight rows %d for Cout %d", op.wrows, op.Cout);
+    if (op.out_mode != H3D_OUT_NCHW_F32 && (op.out_cs % 4 || op.Cout > op.out_cs))
+        H3D_FAIL(H3D_ERR_SHAPE, "updcn: out channel stride %d", op.out_cs);
+    Dcn4Args a;
+    a.in = nullptr; a.wimg = (const char *)op.w; a.woff = (const char *)d->w_off; a.bias = op.bias;
+    a.out = (char *)op.out; a.B = op.B; a.H = op.Ho; a.W = op.Wo; a.in_cs = 64;
+    a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode; a.wrows = op.wrows;
+    a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0; a.dbg = op.reserved & 0xff;
+    a.xlo = (const char *)op.in; a.skip = (const char *)d->skip; a.wup = d->w_up;
+    a.f = f; a.Hl = op.H; a.Wl = op.W; a.xlo_cs = op.in_cs; a.skip_cs = d->skip_cs;
+    if (op.Cout <= 32) return launch_dcn4_cfg<1, 1, 1>(a, st);
+    return launch_dcn4_cfg<2, 1, 1>(a, st);
 }

@@ -36,6 +36,7 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st);
 int h3d_launch_dcn3(const h3d_op &op, hipStream_t st);
 int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st);
 int h3d_launch_dcn4(const h3d_op &op, hipStream_t st);
+int h3d_launch_updcn(const h3d_op &op, hipStream_t st);
 int h3d_launch_stem3(const h3d_op &op, hipStream_t st);
 
 static int run_one(const h3d_op &op, int i, hipStream_t st);
@@ -101,6 +102,7 @@ static int run_one(const h3d_op &op, int i, hipStream_t st)
     case H3D_OP_DCN_FUSED:
     case H3D_OP_DCN_FUSED_STREAM: rc = h3d_launch_dcn3(op, st); break;
     case H3D_OP_DCN_FUSED_F16: rc = h3d_launch_dcn4(op, st); break;
+    case H3D_OP_UPDCN_F16: rc = h3d_launch_updcn(op, st); break;
     case H3D_OP_HEADS: rc = h3d_launch_heads(op, st); break;
     case H3D_OP_MAXPOOL:
     case H3D_OP_UPADD:

@@ -242,6 +242,10 @@ class Plan:
         stream_dcn3=False,     # True: ALL remaining fused DeformConvs take their filters by LDS-DMA (no gain above 64 output channels)
         dense_dcn3=True,       # those with <= 64 output channels do: margin-1 apron, two workgroups per CU (csrc/dcn3.hip)
         dense_dcn3_min_tiles=512,   # ... when the layer has at least this many 16x16 tiles (two per CU)
+        fuse_upnode=True,      # False: up-sample + add always as its own launch in front of the 64-channel node DeformConvs
+        fuse_upnode_min_f=4,   # fold it into the DeformConv from this up-sampling factor (measured at batch 64: the 4x layer
+                               # 0.101 + 0.167 -> 0.242 ms, the 2x layers 0.068 + 0.167 -> 0.241: the blend moves into a kernel that
+                               # is itself vector/LDS bound, while the stand-alone up-sampling kernel is HBM bound)
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
     )
@@ -438,8 +442,26 @@ class Plan:
             k = i - startp
             y = self._deform(layers[i], "%s.proj_%d" % (p, k))
             f16 = self._dcn_f16_ok("%s.node_%d" % (p, k))
+            if f16 and self.fuse_upnode and self.pw.up("%s.up_%d.weight" % (p, k))[1] // 2 >= self.fuse_upnode_min_f:
+                layers[i] = self._updcn(y, layers[i - 1], "%s.up_%d.weight" % (p, k), "%s.node_%d" % (p, k))
+                continue
             y = self.upadd(y, layers[i - 1], "%s.up_%d.weight" % (p, k), f16=f16)
             layers[i] = self._deform(y, "%s.node_%d" % (p, k), x_is_f16=f16)
+
+    def _updcn(self, x, skip, wkey, p):
+        """node(up(x) + skip) in one launch (csrc/dcn4.hip UP = 1): the up-sampled sum never reaches HBM."""
+        wup, k = self.pw.up(wkey)
+        f = k // 2
+        wimg, woimg, bias, cout, cin, rows = self.pw.dcn_stream(p)
+        assert (skip.H, skip.W, skip.C) == (x.H * f, x.W * f, x.C) and cin == x.C == 64, wkey
+        out = self._alloc(skip.H, skip.W, cout)
+        desc = _lib.H3dUpdcnDesc()
+        desc.skip, desc.w_up, desc.w_off, desc.skip_cs = skip.ptr, wup.data_ptr(), woimg.data_ptr(), skip.cs
+        self.keep.append(desc)
+        self._op(_lib.OP_UPDCN_F16, in_=x.ptr, in2=ctypes.addressof(desc), w=wimg.data_ptr(), bias=bias.data_ptr(), out=out.ptr,
+                 H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=out.H, Wo=out.W, Cout=cout, out_cs=out.cs, ksize=3, stride=f, relu=1,
+                 out_mode=_lib.OUT_NHWC, wrows=rows)
+        return out
 
     def _lower(self):
         B, H, W = self.B, self.H, self.W

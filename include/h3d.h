@@ -88,6 +88,10 @@ enum {
                            [B,Ho,Wo,32]; w = bf16 [16][7][32] stem (k = dx*4+c) | [5][16][32] level0 (k = (tap&1)*16+c of tap pair)
                            | [32][9][16] level1; bias = fp32 [16 | 16 | 32]; Cin = 3, Cout = 32                          */
     H3D_OP_DCN_V1 = 8,  /* first-generation DCN kernel (global gather, bf16 weights): kept as an A/B reference */
+    H3D_OP_UPDCN_F16 = 14, /* IDAUp's node(up(x) + skip) in one launch (model.py:384-390): depthwise ConvTranspose2d (k = 2f,
+                           stride f in {2, 4}) + skip add evaluated while the DeformConv's input tile is staged, then
+                           DCN_FUSED_F16's kernel.  in = x at the LOW resolution H x W, Ho x Wo = f * (H x W), stride = f,
+                           in2 = HOST pointer to h3d_updcn_desc; bf16 plans, 64 channels                               */
     H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
                            (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */
 };
@@ -108,6 +112,14 @@ typedef struct h3d_heads_desc {
         int32_t pad;
     } head[H3D_HEADS_MAX];
 } h3d_heads_desc;
+/* H3D_OP_UPDCN_F16: the operands that do not fit h3d_op */
+typedef struct h3d_updcn_desc {
+    const void *skip;    /* bf16 NHWC [B][Ho][Wo][skip_cs]: layers[i-1]                         */
+    const float *w_up;   /* fp32 [k*k][64] tap-major transposed-convolution weights (as UPADD)  */
+    const void *w_off;   /* offset/mask filter image (as DCN_FUSED_F16's in2)                   */
+    int32_t skip_cs;
+    int32_t reserved;
+} h3d_updcn_desc;
 enum { H3D_OUT_NHWC = 0, H3D_OUT_NCHW_F32 = 1, H3D_OUT_NHWC_F32 = 2,
        H3D_OUT_NHWC_F16 = 3 /* H3D_OP_UPADD in a bf16 plan only: fp16 output, the input of H3D_OP_DCN_FUSED_F16 */ };
 
@@ -134,7 +146,7 @@ typedef struct h3d_op {
                            ablation switches in the high bits (tools/ab_*.py)                              */
 } h3d_op;
 
-/* channels per filter stage H3D_OP_DCN_FUSED_STREAM expects for a layer (32 or 16) */
+/* channels per filter stage H3D_OP_DCN_FUSED_STREAM expects for a layer (16) */
 int h3d_dcn_fused_ck(int Cin, int Cout);
 
 /* Launch ops[0..n) in order on `stream`.  Returns H3D_OK or the first error (index in the

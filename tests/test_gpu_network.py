@@ -241,7 +241,7 @@ def test_streamed_dcn_matches_dcn3(offset_scale, tol):
     on, off = _ab(m, xs, "stream_dcn")
     from h3d_amd import _lib
     kinds = [op.kind for op in m.engine(xs.device).plan(2, 96, 160).ops]
-    assert _lib.OP_DCN_FUSED_F16 in kinds
+    assert _lib.OP_DCN_FUSED_F16 in kinds and _lib.OP_UPDCN_F16 in kinds    # (the 4x layer has its up-sampling folded in)
     with torch.no_grad():
         ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(xs.cpu())[0]
     for k in HEADS:
@@ -264,6 +264,7 @@ def test_dcn4_two_workgroups_per_cu_matches_one(offset_scale):
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to(DEV).eval()
     xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=31)).to(DEV)
+    m.engine(xs.device).fuse_upnode = False     # the one-workgroup variant exists for the fp16-input op only
     dense = {k: v.clone() for k, v in m(xs)[0].items()}
     plan = m.engine(xs.device).plan(2, 96, 160)
     idx = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_DCN_FUSED_F16]
@@ -278,6 +279,26 @@ def test_dcn4_two_workgroups_per_cu_matches_one(offset_scale):
     for k in HEADS:
         e = float((dense[k] - one[k]).abs().max())
         assert e <= 2e-2, (k, e)
+
+
+@pytest.mark.parametrize("offset_scale", [0.5, 12.0])
+def test_fused_upsample_node_is_bit_identical(offset_scale):
+    # H3D_OP_UPDCN_F16 (csrc/dcn4.hip UP = 1: skip + depthwise ConvTranspose2d evaluated while the apron is filled, and
+    # again from global memory for pass-2 samples) vs H3D_OP_UPADD writing fp16 + H3D_OP_DCN_FUSED_F16: the same
+    # arithmetic in the same order with the same single rounding to fp16, so every head must match bit for bit
+    # (2x up-sampling on four levels, 4x on the last; ragged tiles; offset_scale 12 exercises pass 2)
+    from h3d_amd import _lib
+    sd = synth.synth_state_dict(arch.state_dict_shapes(HEADS, True), seed=0, offset_scale=offset_scale)
+    m = model.dla_net(HEADS, not_use_dcn=False, dtype="bf16")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    xs = torch.from_numpy(synth.synth_images(3, 96, 160, seed=43)).to(DEV)
+    m.engine(xs.device).fuse_upnode_min_f = 2         # every 64-channel node (the default folds the 4x layer only)
+    on, off = _ab(m, xs, "fuse_upnode")
+    kinds = [op.kind for op in m.engine(xs.device).plan(3, 96, 160).ops]
+    assert _lib.OP_UPDCN_F16 in kinds and _lib.OP_DCN_FUSED_F16 not in kinds
+    for k in HEADS:
+        assert torch.equal(on[k], off[k]), (k, float((on[k] - off[k]).abs().max()))
 
 
 @pytest.mark.parametrize("offset_scale,tol", [(0.5, 6e-2), (12.0, 0.25)])
