@@ -223,20 +223,99 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void dcn4_kernel(Dcn4Args a)
             if (!live) o = u32x4{0u, 0u, 0u, 0u};                       // outside the image: the zero padding
             *reinterpret_cast<u32x4 *>(smem + ldso) = o;
         };
-        fetch(0, 0);
-        fetch(1, 1);
-        {   // tap table -> ring (KiB pieces), behind the first two fetches in the same vmcnt queue
+        auto issue_table = [&]() {   // tap table -> ring (KiB pieces), behind the first fetches in the same vmcnt queue
             const int tbytes = k * k * 64 * 4;
             const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.wup, 0, tbytes, 0x00020000);
             for (int p = wv; p * 1024 < tbytes; p += 8)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void4 *)(s_ring + p * 1024), 16, woffl, p * 1024, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
+        };
+        if (a.f == 2) {
+            // 2x: the output pixels (2m+1 .. 2m+2) x (2n+1 .. 2n+2) share their four inputs (m .. m+1) x (n .. n+1), so a
+            // thread takes such a QUAD: 8 loads and 4 input conversions for 4 apron pixels instead of 20 and 16.  The apron
+            // (rows -2 .. 17 of the tile) is covered by 11 x 11 quads; quad rows / columns -1 and 20 are outside it.
+            constexpr int QN = C::HH / 2 + 1, QIT = (QN * QN + 63) / 64;      // 11, 2
+            u32x4 qv[QIT][4], qs[QIT][4];
+            auto qgeom = [&](int j, int &m, int &n) -> bool {
+                const int item = pp + 64 * j;
+                const int qy = item / QN, qx = item - qy * QN;
+                m = (hy0 >> 1) - 1 + qy; n = (hx0 >> 1) - 1 + qx;             // hy0, hx0 are even
+                return item < QN * QN;
+            };
+            auto qfetch = [&](int j) {
+                int m, n;
+                const bool act = qgeom(j, m, n);
 #pragma unroll
-        for (int j = 0; j < NIT; ++j) {
-            blend(j, j & 1);
-            if (j + 2 < NIT) fetch(j + 2, j & 1);
+                for (int q = 0; q < 4; ++q) {
+                    const int iy = m + 1 - (q >> 1), ix = n + 1 - (q & 1);     // tap order of upadd_kernel
+                    qv[j][q] = u32x4{0u, 0u, 0u, 0u};
+                    if (act && iy >= 0 && iy < a.Hl && ix >= 0 && ix < a.Wl)
+                        qv[j][q] = *reinterpret_cast<const u32x4 *>(xb + ((size_t)(iy * a.Wl + ix) * a.xlo_cs + vec * 8) * 2);
+                    const int gy = 2 * m + 1 + (q >> 1), gx = 2 * n + 1 + (q & 1);
+                    qs[j][q] = u32x4{0u, 0u, 0u, 0u};
+                    if (act && (unsigned)(gy - hy0) < (unsigned)C::HH && (unsigned)(gx - hx0) < (unsigned)C::HH && gy >= 0 && gy < a.H &&
+                        gx >= 0 && gx < a.W)
+                        qs[j][q] = *reinterpret_cast<const u32x4 *>(sb + ((size_t)(gy * a.W + gx) * a.skip_cs + vec * 8) * 2);
+                }
+            };
+            auto qblend = [&](int j) {
+                int m, n;
+                if (!qgeom(j, m, n)) return;
+                float xf[4][8];
+                bool okin[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int iy = m + 1 - (q >> 1), ix = n + 1 - (q & 1);
+                    okin[q] = iy >= 0 && iy < a.Hl && ix >= 0 && ix < a.Wl;
+                    unpack16<bf16_t>(qv[j][q], xf[q]);
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int gy = 2 * m + 1 + (o >> 1), gx = 2 * n + 1 + (o & 1);
+                    const int row = gy - hy0, col = gx - hx0;
+                    if (!((unsigned)row < (unsigned)C::HH && (unsigned)col < (unsigned)C::HH)) continue;
+                    const bool live = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    float acc[8], x[8];
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) acc[c8] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (!okin[q]) continue;
+                        const int ky = (o >> 1) + 2 * (q >> 1), kx = (o & 1) + 2 * (q & 1);   // (gy + 1) & 1 == o >> 1
+                        const float *wp = s_w + (ky * 4 + kx) * 64 + vec * 8;
+                        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 4);
+#pragma unroll
+                        for (int c8 = 0; c8 < 4; ++c8) {
+                            acc[c8] = fmaf(w0[c8], xf[q][c8], acc[c8]);
+                            acc[4 + c8] = fmaf(w1[c8], xf[q][4 + c8], acc[4 + c8]);
+                        }
+                    }
+                    unpack16<bf16_t>(qs[j][o], x);
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) acc[c8] += x[c8];
+                    u32x4 ov = pack16_f16(acc);
+                    if (!live) ov = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4 *>(smem + row * C::ROWB + col * C::PXB + vec * 16) = ov;
+                }
+            };
+            static_assert(QIT == 2, "quad schedule");
+            qfetch(0);
+            issue_table();
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            qblend(0);                                          // (fetching quad 1 up front as well costs 32 more live registers
+            qfetch(1);                                          //  under the 128-VGPR cap: spills in the main loop)
+            qblend(1);
+        } else {
+            fetch(0, 0);
+            fetch(1, 1);
+            issue_table();
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NIT; ++j) {
+                blend(j, j & 1);
+                if (j + 2 < NIT) fetch(j + 2, j & 1);
+            }
         }
         __syncthreads();                                        // apron complete, tap table no longer read
         dcn4_issue_w<C::OPIECES>(a.woff, off_bytes, s_ring, 0, woffl, wv);

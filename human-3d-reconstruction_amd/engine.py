@@ -243,9 +243,8 @@ class Plan:
         dense_dcn3=True,       # those with <= 64 output channels do: margin-1 apron, two workgroups per CU (csrc/dcn3.hip)
         dense_dcn3_min_tiles=512,   # ... when the layer has at least this many 16x16 tiles (two per CU)
         fuse_upnode=True,      # False: up-sample + add always as its own launch in front of the 64-channel node DeformConvs
-        fuse_upnode_min_f=4,   # fold it into the DeformConv from this up-sampling factor (measured at batch 64: the 4x layer
-                               # 0.101 + 0.167 -> 0.242 ms, the 2x layers 0.068 + 0.167 -> 0.241: the blend moves into a kernel that
-                               # is itself vector/LDS bound, while the stand-alone up-sampling kernel is HBM bound)
+        fuse_upnode_min_f=2,   # ... from this up-sampling factor.  Same box, batch 64, up-sampling + node over the five layers:
+                               # 1.234 ms as two launches each, 1.194 with the 4x layer folded, 1.156 with all five
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
     )

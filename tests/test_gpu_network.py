@@ -241,7 +241,7 @@ def test_streamed_dcn_matches_dcn3(offset_scale, tol):
     on, off = _ab(m, xs, "stream_dcn")
     from h3d_amd import _lib
     kinds = [op.kind for op in m.engine(xs.device).plan(2, 96, 160).ops]
-    assert _lib.OP_DCN_FUSED_F16 in kinds and _lib.OP_UPDCN_F16 in kinds    # (the 4x layer has its up-sampling folded in)
+    assert _lib.OP_UPDCN_F16 in kinds           # (dcn4 with the up-sample + add folded in: the default)
     with torch.no_grad():
         ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(xs.cpu())[0]
     for k in HEADS:
@@ -293,7 +293,6 @@ def test_fused_upsample_node_is_bit_identical(offset_scale):
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to(DEV).eval()
     xs = torch.from_numpy(synth.synth_images(3, 96, 160, seed=43)).to(DEV)
-    m.engine(xs.device).fuse_upnode_min_f = 2         # every 64-channel node (the default folds the 4x layer only)
     on, off = _ab(m, xs, "fuse_upnode")
     kinds = [op.kind for op in m.engine(xs.device).plan(3, 96, 160).ops]
     assert _lib.OP_UPDCN_F16 in kinds and _lib.OP_DCN_FUSED_F16 not in kinds
