@@ -245,6 +245,7 @@ class Plan:
         fuse_upnode=True,      # False: up-sample + add always as its own launch in front of the 64-channel node DeformConvs
         fuse_upnode_min_f=2,   # ... from this up-sampling factor.  Same box, batch 64, up-sampling + node over the five layers:
                                # 1.234 ms as two launches each, 1.194 with the 4x layer folded, 1.156 with all five
+        share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
     )
@@ -358,14 +359,18 @@ class Plan:
         t = self.conv(x, p + ".conv1.weight", bn=p + ".bn1", stride=stride)
         return self.conv(t, p + ".conv2.weight", bn=p + ".bn2", res=residual, out=out)
 
-    def _tree1(self, x, p, cin, cout, stride, level_root, out, cat=None):
+    def _tree1(self, x, p, cin, cout, stride, level_root, out, cat=None, bottom=None):
         """One-level Tree (model.py:209-218).  `cat` = pre-allocated Root input whose trailing
-        slices (children) the caller has filled; layout [x2 | x1 | children...]."""
+        slices (children) the caller has filled; layout [x2 | x1 | children...].  `bottom`: the
+        max-pooled x when the caller already has it (the reference pools the same tensor in the outer
+        and in the inner tree, model.py:213)."""
         Ho, Wo = x.H // stride, x.W // stride
         if cat is None:
             cat = self._alloc(Ho, Wo, 2 * cout + (cin if level_root else 0))
         s_x2, s_x1 = cat.slice(0, cout), cat.slice(cout, cout)
-        if stride > 1:
+        if bottom is not None:
+            assert stride > 1 and not level_root and (bottom.H, bottom.W, bottom.C) == (Ho, Wo, cin)
+        elif stride > 1:
             bottom = self.pool(x, cat.slice(2 * cout, cin) if level_root else None)
         else:
             bottom = x
@@ -382,8 +387,9 @@ class Plan:
         tree2 = [x2 | x1 | bottom | tree1 output]."""
         Ho, Wo = x.H // 2, x.W // 2
         cat = self._alloc(Ho, Wo, 2 * cout + cin + cout)
-        self.pool(x, cat.slice(2 * cout, cin))
-        x1 = self._tree1(x, p + ".tree1", cin, cout, 2, False, cat.slice(2 * cout + cin, cout))
+        pooled = self.pool(x, cat.slice(2 * cout, cin))
+        x1 = self._tree1(x, p + ".tree1", cin, cout, 2, False, cat.slice(2 * cout + cin, cout),
+                         bottom=pooled if self.share_pool else None)
         return self._tree1(x1, p + ".tree2", cout, cout, 1, False, out, cat=cat)
 
     def _dcn_f16_ok(self, p):
