@@ -61,6 +61,7 @@ SIGNATURES = {
     "h3d_nchw_f32_to_nhwc": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "h3d_nhwc_to_nchw_f32": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "h3d_nms_topk": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "h3d_nms_topk2": [c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "h3d_nms": [c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "h3d_topk_merge": [c_vp] * 4 + [c_i] * 3 + [c_vp] * 5 + [c_vp],
     "h3d_gather_feat": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],

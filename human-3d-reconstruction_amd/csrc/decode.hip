@@ -80,11 +80,25 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *s_wave
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__restrict__ heat, int C, int H, int W, int K,
-                                                               int ncand, int flags, float *__restrict__ o_score,
-                                                               int64_t *__restrict__ o_ind, float *__restrict__ o_y,
-                                                               float *__restrict__ o_x)
+// One launch can serve two heat-map tensors of the same H x W and K (the detector's `hm` and `hm_hp`: 1 and 17 maps per
+// image; on its own the 64-workgroup `hm` launch occupies a quarter of the CUs for a full map latency).
+struct NmsJob {
+    const float *heat;
+    float *o_score;
+    int64_t *o_ind;
+    float *o_y, *o_x;
+    int nblk;       // B * C maps
+};
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob j1, int H, int W, int K, int ncand, int flags)
 {
+    int blk = blockIdx.x;
+    NmsJob jb = j0;
+    if (blk >= j0.nblk) { blk -= j0.nblk; jb = j1; }     // (workgroup-uniform)
+    const float *__restrict__ heat = jb.heat;
+    float *__restrict__ o_score = jb.o_score;
+    int64_t *__restrict__ o_ind = jb.o_ind;
+    float *__restrict__ o_y = jb.o_y, *__restrict__ o_x = jb.o_x;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_key[];  // [HW] keys, then candidates, then keep bits
     __shared__ uint32_t s_hist[256];
     __shared__ uint32_t s_wave[NMS_WAVES];
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__re
     __shared__ uint32_t s_cnt;
     const int tid = threadIdx.x;
     const int HW = H * W;
-    const float *map = heat + (size_t)blockIdx.x * HW;
+    const float *map = heat + (size_t)blk * HW;
     u64 *s_cand = reinterpret_cast<u64 *>(s_key + ((HW + 1) & ~1));
     u64 *s_mask = s_cand + ncand;             // keep bits, one word per 64 pixels
 
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__re
     for (int j = tid; j < K; j += NMS_THREADS) {
         const u64 c = s_cand[j];
         const uint32_t idx = 0xffffffffu - (uint32_t)(c & 0xffffffffull);
-        const size_t o = (size_t)blockIdx.x * K + j;
+        const size_t o = (size_t)blk * K + j;
         o_score[o] = fkey_inv((uint32_t)(c >> 32));
         o_ind[o] = (int64_t)idx;
         o_y[o] = (float)(int)(idx / (uint32_t)W);
@@ -235,11 +249,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(const float *__re
     }
 }
 
-extern "C" int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K, int flags, float *scores,
-                            int64_t *inds, float *ys, float *xs, void *stream)
+static int nms_topk_launch(const NmsJob &j0, const NmsJob &j1, int H, int W, int K, int flags, void *stream)
 {
-    if (!heat || !scores || !inds || !ys || !xs) H3D_FAIL(H3D_ERR_ARG, "nms_topk: null pointer");
-    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) H3D_FAIL(H3D_ERR_SHAPE, "nms_topk: bad shape");
     const long HW = (long)H * W;
     if (K <= 0 || K > HW) H3D_FAIL(H3D_ERR_SHAPE, "nms_topk: selected index k out of range (K=%d, H*W=%ld)", K, HW);
     if (K > NMS_MAXK || HW > 36864)
@@ -253,10 +264,30 @@ extern "C" int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K
             H3D_FAIL(H3D_ERR_LAUNCH, "nms_topk: cannot reserve %zu bytes of LDS", lds);
         max_set = lds;
     }
-    hipLaunchKernelGGL(nms_topk_kernel, dim3(B * C), dim3(NMS_THREADS), lds, (hipStream_t)stream, heat, C, H, W, K,
-                       N, flags, scores, inds, ys, xs);
+    hipLaunchKernelGGL(nms_topk_kernel, dim3(j0.nblk + j1.nblk), dim3(NMS_THREADS), lds, (hipStream_t)stream, j0, j1, H, W, K, N, flags);
     H3D_CHECK_LAUNCH("nms_topk_kernel");
     return H3D_OK;
+}
+
+extern "C" int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K, int flags, float *scores,
+                            int64_t *inds, float *ys, float *xs, void *stream)
+{
+    if (!heat || !scores || !inds || !ys || !xs) H3D_FAIL(H3D_ERR_ARG, "nms_topk: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) H3D_FAIL(H3D_ERR_SHAPE, "nms_topk: bad shape");
+    const NmsJob j0 = {heat, scores, inds, ys, xs, B * C}, j1 = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    return nms_topk_launch(j0, j1, H, W, K, flags, stream);
+}
+
+extern "C" int h3d_nms_topk2(const float *heat_a, int Ca, float *scores_a, int64_t *inds_a, float *ys_a, float *xs_a,
+                             const float *heat_b, int Cb, float *scores_b, int64_t *inds_b, float *ys_b, float *xs_b,
+                             int B, int H, int W, int K, int flags, void *stream)
+{
+    if (!heat_a || !scores_a || !inds_a || !ys_a || !xs_a || !heat_b || !scores_b || !inds_b || !ys_b || !xs_b)
+        H3D_FAIL(H3D_ERR_ARG, "nms_topk2: null pointer");
+    if (B <= 0 || Ca <= 0 || Cb <= 0 || H <= 0 || W <= 0) H3D_FAIL(H3D_ERR_SHAPE, "nms_topk2: bad shape");
+    // the many-map tensor first: its workgroups fill the CUs while the few maps of the other ride along
+    const NmsJob ja = {heat_a, scores_a, inds_a, ys_a, xs_a, B * Ca}, jb = {heat_b, scores_b, inds_b, ys_b, xs_b, B * Cb};
+    return Ca >= Cb ? nms_topk_launch(ja, jb, H, W, K, flags, stream) : nms_topk_launch(jb, ja, H, W, K, flags, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

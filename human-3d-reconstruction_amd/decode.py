@@ -35,6 +35,21 @@ def _map_topk(scores, K, flags):
     return s, i, y, x
 
 
+def _map_topk2(a, b, K, flags):
+    """_map_topk of two tensors with the same B, H, W in ONE launch (h3d_nms_topk2)."""
+    a, b = _f32c(a), _f32c(b)
+    B, Ca, H, W = a.shape
+    Cb = b.shape[1]
+    dev = a.device
+    outs = []
+    for C in (Ca, Cb):
+        outs.append((torch.empty(B, C, K, dtype=torch.float32, device=dev), torch.empty(B, C, K, dtype=torch.int64, device=dev),
+                     torch.empty(B, C, K, dtype=torch.float32, device=dev), torch.empty(B, C, K, dtype=torch.float32, device=dev)))
+    _lib.check(_lib.lib().h3d_nms_topk2(_lib.ptr(a), Ca, *[_lib.ptr(t) for t in outs[0]], _lib.ptr(b), Cb,
+                                        *[_lib.ptr(t) for t in outs[1]], B, H, W, K, flags, _lib.stream_ptr()), "topk2")
+    return outs
+
+
 def _merge(s, i, y, x, K):
     B, C, _ = s.shape
     dev = s.device
@@ -82,12 +97,16 @@ def _multi_pose(heat, wh, kps, reg, hm_hp, hp_offset, K, logits, return_aux=Fals
     B, C, H, W = heat.shape
     J = kps.shape[1] // 2
     flags = NMS_SIGMOID if logits else 0
-    s, i, c, y, x = _merge(*_map_topk(heat, K, flags), K)
-    if hm_hp is not None:
-        hs, hi, hy, hx = _map_topk(hm_hp, K, flags)
+    if hm_hp is not None and hm_hp.shape[0] == B and hm_hp.shape[2:] == heat.shape[2:]:
+        (s1, i1, y1, x1), (hs, hi, hy, hx) = _map_topk2(heat, hm_hp, K, flags)      # one launch for both tensors
+        s, i, c, y, x = _merge(s1, i1, y1, x1, K)
     else:
-        hs = hi = hy = hx = None
-        hp_offset = None
+        s, i, c, y, x = _merge(*_map_topk(heat, K, flags), K)
+        if hm_hp is not None:
+            hs, hi, hy, hx = _map_topk(hm_hp, K, flags)
+        else:
+            hs = hi = hy = hx = None
+            hp_offset = None
     dets = torch.empty(B, K, 5 + 2 * J + 1, dtype=torch.float32, device=heat.device)
     _lib.check(_lib.lib().h3d_multi_pose_assemble(
         _lib.ptr(s), _lib.ptr(i), _lib.ptr(c), _lib.ptr(y), _lib.ptr(x),

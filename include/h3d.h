@@ -181,6 +181,11 @@ int h3d_nhwc_to_nchw_f32(const void *src, int dtype, float *dst, int B, int C, i
 #define H3D_NMS_SKIP 2    /* heat is already NMS-ed (plain _topk/_topk_channel) */
 int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K, int flags,
                  float *scores, int64_t *inds, float *ys, float *xs, void *stream);
+/* The same for TWO heat-map tensors [B,Ca,H,W] and [B,Cb,H,W] in one launch (the detector's `hm` and `hm_hp`,
+ * decode.py:85 and :118: the 1-class map alone occupies B workgroups).  Outputs as h3d_nms_topk, per tensor. */
+int h3d_nms_topk2(const float *heat_a, int Ca, float *scores_a, int64_t *inds_a, float *ys_a, float *xs_a,
+                  const float *heat_b, int Cb, float *scores_b, int64_t *inds_b, float *ys_b, float *xs_b,
+                  int B, int H, int W, int K, int flags, void *stream);
 
 /* stand-alone _nms (decode.py:6-13): out = heat * (maxpool3x3(heat) == heat), [B,C,H,W] */
 int h3d_nms(const float *heat, int B, int C, int H, int W, float *out, void *stream);

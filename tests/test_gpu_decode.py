@@ -93,6 +93,19 @@ def test_all_equal_map_ties_lowest_index_first():
     assert s.cpu().tolist() == [[0.5] * 10]
 
 
+def test_paired_topk_launch_matches_two_launches():
+    # h3d_nms_topk2 (hm + hm_hp in one launch: decode._map_topk2) vs h3d_nms_topk per tensor: the same workgroup
+    # program on the same maps -> identical scores, indices and coordinates (ragged map size, both flag settings)
+    g = torch.Generator().manual_seed(5)
+    a = (torch.randn(3, 1, 24, 40, generator=g) * 2 - 1).to(DEV)
+    b = (torch.randn(3, 17, 24, 40, generator=g) * 2 - 1).to(DEV)
+    for flags in (0, decode.NMS_SIGMOID):
+        pa, pb = decode._map_topk2(a, b, 20, flags)
+        for got, ref in ((pa, decode._map_topk(a, 20, flags)), (pb, decode._map_topk(b, 20, flags))):
+            for x, y in zip(got, ref):
+                assert torch.equal(x, y)
+
+
 def test_topk_k_out_of_range_raises():
     hm = torch.zeros(1, 1, 4, 4, device=DEV)
     with pytest.raises(RuntimeError, match="out of range"):
