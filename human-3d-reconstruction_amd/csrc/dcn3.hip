@@ -424,6 +424,13 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
         }
         if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 2>(a, st);
         if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 2>(a, st);
+        // a layer whose 128-channel workgroups would leave CUs idle (16x16 maps at batch 64: 128 workgroups) runs
+        // 64-channel workgroups instead: twice the gather / blend work, but on CUs that had nothing to do
+        const long wgs4 = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
+        if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) {
+            if (op.Cin % 32 == 0) return launch_dcn3_cfg<bf16_t, 2, 32, 2>(a, st);
+            return launch_dcn3_cfg<bf16_t, 2, 16, 2>(a, st);
+        }
         return launch_dcn3_cfg<bf16_t, 4, 16, 2>(a, st);
     }
     if (op.dtype == H3D_F32) {
