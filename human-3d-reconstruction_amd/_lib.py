@@ -86,6 +86,10 @@ def lib():
                 "h3d_amd: HIP library not built (%s). Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C human-3d-reconstruction_amd/csrc`. There is no CPU fallback."
                 % LIB_PATH)
+        # PyTorch first: its wheel bundles its own HIP / HSA runtime, and libh3d_hip.so must bind to THAT copy (same
+        # SONAME once it is loaded).  Loaded the other way round, the process ends up with two runtimes and the first
+        # launch fails with "no ROCm-capable device is detected" (seen with build() followed by smoke() in one process).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.h3d_last_error.restype = ctypes.c_char_p
         L.h3d_last_error.argtypes = []
