@@ -237,11 +237,18 @@ template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipSt
     }
     if (op.ksize == 1 && op.stride == 1) {
         if (cin % 64 == 0) {
+            if (co > 32 && (op.reserved & 0x1000)) {           // tuning override (tools/ab_conv1x1.py): 0x1000 | MT << 4 | TH >> 3
+                const int mt = (op.reserved >> 4) & 15, th = (op.reserved & 15) * 8;
+                if (mt == 4 && th == 16) return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 16>(a, st);
+                if (mt == 4 && th == 8) return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 8>(a, st);
+                if (mt == 2 && th == 16) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 16>(a, st);
+                if (mt == 2 && th == 8) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 8>(a, st);
+            }
             if (co <= 32) return launch_conv_cfg<bf16_t, 1, 1, 1, 64, 16>(a, st);
-            if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 16>(a, st);
-            if (nblk(16, 128) >= WANT) return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 16>(a, st);
-            if (nblk(8, 128) >= WANT) return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 8>(a, st);
-            return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 8>(a, st);
+            // 8-row tiles throughout: these layers are HBM / latency bound and twice the workgroups hide more of it
+            // (tools/ab_conv1x1.py, batch 64: 448->128 @64x64 0.085 -> 0.073 ms, 1280->512 @16x16 0.042 -> 0.036, ...)
+            if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 8>(a, st);
+            return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 8>(a, st);
         }
         if (co <= 32) return launch_conv_cfg<bf16_t, 1, 1, 1, 16, 16>(a, st);
         if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 16, 16>(a, st);
