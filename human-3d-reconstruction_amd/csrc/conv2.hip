@@ -138,6 +138,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
             conv2_issue<MT, WAVES, S, NT>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + j * C::SLOT, hoff, woff, wv, j, (j * a.G + g0) * C::WGRP, H3D_DBG(a));
     int cslot = 0, pslot = AHEAD % SLOTS;          // slot consumed by stage s / filled with stage s + AHEAD
     for (int s = 0; s < nst; ++s) {
+        if constexpr (SLOTS == 1) {
+            // one slot, several stages: the stage is fetched once nobody reads its predecessor any more; the wait is
+            // covered by the CU's other workgroups (the slot is small enough for two or three of them)
+            if (s > 0) {
+                __syncthreads();
+                conv2_issue<MT, WAVES, S, NT>(in_b, (int)img_bytes, a.wimg, w_bytes, smem, hoff, woff, wv, s, (s * a.G + g0) * C::WGRP, H3D_DBG(a));
+            }
+        }
         // my pieces of stage s have landed once only stage s+1's may be outstanding (vmcnt retires in order)
         if (AHEAD == 2 && s + 1 < nst) __builtin_amdgcn_s_waitcnt(WAIT_PMIN);
         else __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -222,7 +230,15 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
     const int gq = cdiv(op.Cout, 32);
     auto nblk = [&](int th, int mt) { return (long)op.B * cdiv(op.Wo, 16) * cdiv(op.Ho, th) * cdiv(gq, mt); };
     if (op.stride == 2) {          // the stride-2 halo is (2 TH + 1) x 33 pixels: 4-wave tiles are what fits twice in the LDS
-        if (gq >= 4) return launch_conv2_cfg<4, 4, 2>(a, st);
+        switch (op.reserved & 0xffff) {           // tuning override (tools/ab_conv.py)
+        case 0x4404: return launch_conv2_cfg<4, 4, 2, 1>(a, st);    // 0x4...: ONE ring slot (more workgroups per CU)
+        case 0x4408: return launch_conv2_cfg<4, 8, 2, 1>(a, st);
+        case 0x4204: return launch_conv2_cfg<2, 4, 2, 1>(a, st);
+        default: break;
+        }
+        // one ring slot (73 KB): two workgroups per CU instead of one 4-wave workgroup with a two-slot ring
+        // (tools/ab_conv_s2.py, batch 64: 64->128 0.093 -> 0.073 ms, 128->256 0.081 -> 0.082, 256->512 0.064 -> 0.051)
+        if (gq >= 4) return (op.reserved & 0xffff) == 0x2404 ? launch_conv2_cfg<4, 4, 2>(a, st) : launch_conv2_cfg<4, 4, 2, 1>(a, st);
         if (gq >= 2) return launch_conv2_cfg<2, 4, 2>(a, st);
         return launch_conv2_cfg<1, 4, 2>(a, st);
     }
