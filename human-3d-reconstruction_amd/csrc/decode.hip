@@ -114,6 +114,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob
     // pass 1: (optional) sigmoid of every pixel ONCE, straight into LDS; 8 independent loads per
     //         thread in flight per batch (8192 per workgroup)
     float *s_val = reinterpret_cast<float *>(s_key);
+    const int wshift = (W & (W - 1)) == 0 ? __builtin_ctz(W) : -1;             // heat maps are 128 wide in the detector
     for (int base = 0; base < HW; base += 8 * NMS_THREADS) {
         float v[8];
 #pragma unroll
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob
         const int i = base + tid;
         bool keep = false;
         if (i < HW) {
-            const int y = i / W, x = i - y * W;
+            const int y = wshift >= 0 ? (i >> wshift) : i / W, x = i - y * W;     // (a division costs ~25 instructions per pixel)
             const float v = s_val[i];
             float m = v;
             if (!(flags & 2)) {
