@@ -8,17 +8,26 @@ DLA-34+DCNv2 (+pose/shape heads) -> sigmoid+NMS+top-k decode -> per-detection SM
 and for N>1 the single all-gather of the decoded detections (RCCL).  One process per GPU
 (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE); per-GPU batch is fixed (weak scaling).
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF (a child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, spawned before anything touches the GPU) and relays
+rank 0's JSON line; under torchrun it is a rank.
+
 Rank 0 prints ONE JSON line with the driver's contract fields plus
   "roofline"     -- dominant kernel family (by device time) timed live with HIP events on the
                     launch stream: algorithmic FLOP per launch / mean launch duration vs the dense
                     bf16 MFMA peak of MI355X;
+                    plus network_frac / step_frac = the whole network's / whole step's FLOP rate vs that peak;
   "cpu_baseline" -- the oracle's torch-CPU restatement of the same graph timed on this box's host
-                    cores on a bounded sample (a reported baseline, not the target).
+                    cores on a bounded sample (a reported baseline, not the target);
+  "index_match"  -- top-k peak indices of the GPU (bf16) path vs the fp32 oracle on the same 2 images
+                    (oracle/index_match.py; the oracle is the checker here, never the thing measured).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -79,8 +88,9 @@ def per_kernel_profile(plan, iters):
     return groups
 
 
-def cpu_baseline(opt, sd, seconds_budget=20.0):
-    """Oracle (torch-CPU restatement, kind 'port') on a bounded sample of the same workload."""
+def cpu_baseline(opt, sd, seconds_budget=20.0, keep=None):
+    """Oracle (torch-CPU restatement, kind 'port') on a bounded sample of the same workload.
+    keep: dict that receives the sample's input images and the oracle's head maps (for index_match)."""
     from oracle import decode as odec, dla as odla, smpl as osmpl
     from h3d_amd import smpl as psmpl
     try:
@@ -97,6 +107,8 @@ def cpu_baseline(opt, sd, seconds_budget=20.0):
     def step():
         with torch.no_grad():
             o = {k: v.numpy() for k, v in net(x)[0].items()}
+        if keep is not None and "heads" not in keep:
+            keep["images"], keep["heads"] = x, o
         dets, aux = odec.multi_pose_decode(odec.sigmoid_clamp(o["hm"]), o["wh"], o["hps"], o["reg"],
                                            odec.sigmoid_clamp(o["hm_hp"]), o["hp_offset"], K=opt.K, return_aux=True)
         n = 4                                             # meshes per image in the CPU sample (fp64 numpy)
@@ -120,6 +132,114 @@ def cpu_baseline(opt, sd, seconds_budget=20.0):
                       "4 fp64 SMPL meshes/image)" % (iters, B, cores)}
 
 
+def dcn_pass2_fraction(det, images2, dev):
+    """Share of DeformConv samples (pixel x tap) whose bilinear corners leave the LDS apron of their 16x16 tile and go
+    through the kernels' global-gather pass 2, for the weights this run uses (synthetic offsets are small; trained
+    networks have larger ones -- `--offset-scale`).  The fused kernels never write their offsets, so an UNFUSED twin of
+    the plan (conv_offset_mask as its own launch) is run on 2 images and the test of csrc/dcn3.hip / dcn4.hip
+    (`ry >= 0 && ry + 1 < HH && ...`) is evaluated on its offset maps with each layer's own apron margin."""
+    import re
+    from h3d_amd.engine import Plan
+    eng = det.model.engine(dev)
+    B, _, H, W = images2.shape
+    fused = Plan(eng.pw, B, H, W, **eng._flags())
+    margins = []
+    for op in fused.ops:
+        if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_STREAM):
+            margins.append(int(re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+),", kernel_name(op)).group(1)))
+        elif op.kind in (_lib.OP_DCN_FUSED_F16, _lib.OP_UPDCN_F16):
+            margins.append(1 if re.match(r"dcn4_kernel<\d+, \d+, 1,", kernel_name(op)) else 2)
+    twin = Plan(eng.pw, B, H, W, **dict(eng._flags(), fuse_offsets=False))
+    twin.op_array[0].in_ = images2.data_ptr()
+    twin.run()
+    torch.cuda.synchronize()
+    dcn_ops = [op for op in twin.ops if op.kind == _lib.OP_DCN]
+    assert len(dcn_ops) == len(margins), (len(dcn_ops), len(margins))
+    slow_all = tot_all = 0.0
+    worst, mean_abs = 0.0, []
+    for op, M in zip(dcn_ops, margins):
+        om = [t for t in twin.keep if torch.is_tensor(t) and t.data_ptr() == op.in2][0]      # [B,h,w,32] fp32
+        h, w = om.shape[1], om.shape[2]
+        ys = torch.arange(h, device=dev, dtype=torch.float32).view(1, h, 1)
+        xs = torch.arange(w, device=dev, dtype=torch.float32).view(1, 1, w)
+        y0, x0 = ys - ys % 16 - 1 - M, xs - xs % 16 - 1 - M              # apron origin of the pixel's tile
+        HH = 18 + 2 * M
+        slow = tot = 0.0
+        for t in range(9):
+            ti, tj = divmod(t, 3)
+            h_im, w_im = ys - 1 + ti + om[..., 2 * t], xs - 1 + tj + om[..., 2 * t + 1]
+            inside = (h_im > -1) & (w_im > -1) & (h_im < h) & (w_im < w)
+            ry, rx = torch.floor(h_im) - y0, torch.floor(w_im) - x0
+            ok = (ry >= 0) & (ry + 1 < HH) & (rx >= 0) & (rx + 1 < HH)
+            slow += float((inside & ~ok).sum())
+            tot += float(inside.numel())
+        mean_abs.append(float(om[..., :18].abs().mean()))
+        slow_all, tot_all = slow_all + slow, tot_all + tot
+        worst = max(worst, slow / tot)
+    return {"layers": len(margins), "samples_pass2_frac": round(slow_all / tot_all, 5), "worst_layer_frac": round(worst, 5),
+            "mean_abs_offset_px": round(float(np.mean(mean_abs)), 3)}
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD job (one process per GPU,
+    rendezvous on 127.0.0.1) and relay its output; this process never touches the GPU, and nothing is exec'ed over a
+    process that has.  Returns the child's exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """--dry-run: the launcher / rendezvous / barrier / max-over-ranks / JSON plumbing of the N-rank bench over gloo on
+    CPU tensors -- no HIP call, no network step (tests/test_cpu_host.py).  The line is marked "dry_run": true."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    dets = torch.full((args.batch, 100, 40), float(rank))
+
+    def step():
+        return gather_detections(dets, n_images=world * args.batch) if world > 1 else dets
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.shape == (world * args.batch, 100, 40)
+    assert all(float(out[r * args.batch, 0, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": round(world * args.batch * args.steps / dt, 2), "unit": "images/s",
+                          "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "DRY RUN: all-gather of dets only (gloo, CPU)", "batch_per_gpu": args.batch,
+                                     "global_batch": world * args.batch}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+METRIC = "images/sec whole-node, DLA-34+SMPL batch-64 512x512; top-k index bit-match"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,15 +249,27 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--people", type=int, default=100, help="SMPL meshes per image (<= K)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batches run concurrently on their own HIP streams")
+    ap.add_argument("--offset-scale", type=float, default=0.5,
+                    help="scale of the synthetic conv_offset_mask filters (h3d_amd.synth): DCN offsets are ~N(0, (0.6 S)^2) px; "
+                         "trained networks have larger offsets than the default, which moves samples into the DeformConv's "
+                         "global-gather pass 2")
+    ap.add_argument("--weight-gain", type=float, default=1.25,
+                    help="gain of the synthetic conv weights (h3d_amd.synth): 1.25 keeps the signal alive through DLA-34, so "
+                         "the heat map has separated peaks and index_match means something; 1.0 = round 1's weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + collective plumbing only, gloo on CPU (tests)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
     torch.cuda.set_device(local)
@@ -148,7 +280,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
 
     opt = Opt(input_h=512, input_w=512, smpl=True, smpl_people=args.people, dtype=args.dtype, K=100)
-    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, offset_scale=args.offset_scale, gain=args.weight_gain)
     det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
     det.model.engine(dev).streams = args.streams
     images = torch.from_numpy(synth.synth_images(1, 512, 512, seed=317 + rank)).to(dev)
@@ -157,7 +289,7 @@ def main():
 
     def step():
         res = det.run(images)
-        return gather_detections(res["dets"]) if world > 1 else res["dets"]
+        return gather_detections(res["dets"], n_images=world * args.batch) if world > 1 else res["dets"]
 
     # one-time setup outside both warm-up and the timed region: weight packing + plan lowering (host work and uploads,
     # no network launches) and the SMPL model upload.  The first launch of every kernel still pays its code-object
@@ -200,10 +332,12 @@ def main():
 
     if rank == 0:
         gflop_img = arch.conv_flops(opt.heads, True) / 1e9
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else 157.3
         line = {
-            "metric": "images/sec whole-node, DLA-34+SMPL batch-64 512x512; top-k index bit-match",
+            "metric": METRIC,
             "value": round(world * args.batch * args.steps / dt, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "DLA-34+DCNv2 multi_pose + pose/shape heads -> sigmoid/NMS/top-100 decode -> "
@@ -211,37 +345,52 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "K": 100,
                        "smpl_people_per_image": args.people, "conv_gflop_per_image": round(gflop_img, 2),
                        "parallelism": "dp%d (image shards, one all-gather of dets)" % world,
-                       "weights": "synthetic (h3d_amd.synth, seed 0)"},
+                       "weights": "synthetic (h3d_amd.synth, seed 0, gain %g, offset_scale %g)" % (args.weight_gain, args.offset_scale)},
         }
-        line["model_tflops"] = round(gflop_img * line["value"] / 1e3, 1)
+        line["model_tflops"] = round(gflop_img * line["value"] / 1e3 / world, 1)      # per GPU
         if not args.no_roofline:
             plan = det.model.engine(dev).plan(args.batch, 512, 512)
             groups = per_kernel_profile(plan, iters=3)
             total_ms = sum(g["ms"] for g in groups.values())
             name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes of this build
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
-            except (OSError, ValueError, KeyError):
-                pass
+            traffic, traffic_src = None, None   # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", f)))["kernels"]
+                    traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
+                except (OSError, ValueError, KeyError):
+                    traffic = None
+                if traffic:
+                    traffic_src = "profiles/%s (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 unit corrections)" % f
+                    break
+            net_tflops = args.batch * gflop_img / total_ms                         # GFLOP / ms = TFLOP/s
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1),
-                                "peak": PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                                "frac": round(ach / (PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, "
-                                "separate --pmc passes)" if traffic else None, "launches_per_step": g["launches"],
+                                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                                "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": g["launches"],
                                 "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                                 "share_of_network_time": round(g["ms"] / total_ms, 3),
-                                "network_ms_per_step": round(total_ms, 3)}
+                                "network_ms_per_step": round(total_ms, 3),
+                                # the north_star's target is quoted on the whole DLA-34+DCNv2 forward: all conv FLOP of
+                                # the network / its device time, and the same FLOP / the whole step (decode, SMPL, gather)
+                                "network_tflops": round(net_tflops, 1), "network_frac": round(net_tflops / peak, 4),
+                                "step_frac": round(line["model_tflops"] / peak, 4)}
             print("[bench] roofline %s" % json.dumps(line["roofline"]), file=sys.stderr, flush=True)
             line["kernels"] = {k: {"ms": round(v["ms"], 3), "n": v["launches"],
                                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             print("[bench] kernels %s" % json.dumps(line["kernels"]), file=sys.stderr, flush=True)
+            line["dcn_pass2"] = dcn_pass2_fraction(det, images[:2].contiguous(), dev)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(opt, sd)
-        print(json.dumps(line))
+            keep = {}
+            line["cpu_baseline"] = cpu_baseline(opt, sd, keep=keep)
+            # the checker's second use: the same 2 images through the GPU path, indices compared with the oracle's
+            from oracle import index_match as oim
+            res = det.run(keep["images"].to(dev))
+            line["index_match"] = oim.index_match({k: v.cpu().numpy() for k, v in res["heads"].items()},
+                                                  res["inds"].cpu().numpy(), keep["heads"], K=opt.K)
+            print("[bench] index_match %s" % json.dumps(line["index_match"]), file=sys.stderr, flush=True)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

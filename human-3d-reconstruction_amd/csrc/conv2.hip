@@ -258,6 +258,7 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
         case 0x3404: return launch_conv2_cfg<4, 4, 1, 3>(a, st);
         case 0x5408: return launch_conv2_cfg<4, 8, 1, 1>(a, st);      // 0x5...: ONE ring slot
         case 0x5208: return launch_conv2_cfg<2, 8, 1, 1>(a, st);
+        case 0x5108: return launch_conv2_cfg<1, 8, 1, 1>(a, st);
         case 0x1: break;           // 1 = auto configuration (used with the ablation bits)
         default: H3D_FAIL(H3D_ERR_ARG, "conv_stream: unknown tuning override %#x", op.reserved);
         }

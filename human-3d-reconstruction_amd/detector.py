@@ -118,17 +118,39 @@ def multi_pose_post_process(dets, c, s, h, w):
     return out
 
 
-def gather_detections(dets, group=None):
-    """All ranks' [B_local,K,40] -> [world*B_local,K,40] with ONE all-gather (RCCL over xGMI when
-    the backend is nccl; gloo in the CPU tests).  Nothing else crosses ranks: images are
-    independent, weights are replicated (the reference's DataParallel scatter, trainer.py:176)."""
+def gather_detections(dets, group=None, n_images=None):
+    """All ranks' [B_rank,K,40] -> [sum B_rank,K,40] with ONE all-gather (RCCL over xGMI when the backend is
+    nccl; gloo in the CPU tests).  Nothing else crosses ranks: images are independent, weights are replicated
+    (the reference's DataParallel scatter of dim 0, trainer.py:176).
+
+    n_images: the global batch that `shard_batch` split.  None = every rank holds the same number of images.
+    When the split is uneven (n_images % world != 0: the lowest ranks hold one image more) every rank pads its
+    shard to ceil(n_images / world) rows, so the collective stays ONE fixed-size all_gather_into_tensor, and the
+    pad rows are dropped afterwards."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return dets
     world = dist.get_world_size(group)
-    out = torch.empty((world * dets.shape[0],) + tuple(dets.shape[1:]), dtype=dets.dtype, device=dets.device)
-    dist.all_gather_into_tensor(out, dets.contiguous(), group=group)
-    return out
+    dets = dets.contiguous()
+    if n_images is None or n_images % world == 0:
+        if n_images is not None and dets.shape[0] != n_images // world:
+            raise RuntimeError("gather_detections: this rank holds %d images, shard_batch(%d, ., %d) gives %d"
+                               % (dets.shape[0], n_images, world, n_images // world))
+        out = torch.empty((world * dets.shape[0],) + tuple(dets.shape[1:]), dtype=dets.dtype, device=dets.device)
+        dist.all_gather_into_tensor(out, dets, group=group)
+        return out
+    rows = -(-n_images // world)
+    lo, hi = shard_batch(n_images, dist.get_rank(group), world)
+    if dets.shape[0] != hi - lo:
+        raise RuntimeError("gather_detections: this rank holds %d images, shard_batch(%d, %d, %d) gives %d"
+                           % (dets.shape[0], n_images, dist.get_rank(group), world, hi - lo))
+    mine = dets.new_zeros((rows,) + tuple(dets.shape[1:]))
+    mine[:hi - lo] = dets
+    out = torch.empty((world * rows,) + tuple(dets.shape[1:]), dtype=dets.dtype, device=dets.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    out = out.view((world, rows) + tuple(dets.shape[1:]))
+    sizes = [shard_batch(n_images, r, world) for r in range(world)]
+    return torch.cat([out[r, :b - a] for r, (a, b) in enumerate(sizes)], 0)
 
 
 def shard_batch(n_images, rank, world):

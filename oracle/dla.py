@@ -21,9 +21,17 @@ BN_EPS = 1e-5
 
 
 class DLAOracle:
-    def __init__(self, state_dict, heads, use_dcn, down_ratio=4, last_level=5, acc_dtype=None):
+    def __init__(self, state_dict, heads, use_dcn, down_ratio=4, last_level=5, acc_dtype=None, emulate_bf16=False):
+        """emulate_bf16: round every conv / DeformConv input and every conv weight to bf16 (fp32 accumulation, as
+        the MFMA does).  NOT a model of the GPU kernels' exact rounding points (they fold BatchNorm into the weights
+        before rounding and keep DeformConv filters in fp16): an independent bf16 evaluation of the same graph whose
+        distance from the fp32 result says how much of the GPU's bf16 error is the arithmetic's, not a bug's
+        (tests/test_gpu_fullsize.py)."""
         self.sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.asarray(v)))
                    for k, v in state_dict.items()}
+        self.q = (lambda t: t.to(torch.bfloat16).float()) if emulate_bf16 else (lambda t: t)
+        if emulate_bf16:
+            self.sd = {k: (self.q(v) if v.dim() == 4 else v) for k, v in self.sd.items()}
         self.heads = heads
         self.use_dcn = use_dcn
         self.first_level = int(np.log2(down_ratio))
@@ -32,7 +40,7 @@ class DLAOracle:
 
     # -- primitives ---------------------------------------------------------------------------
     def _conv(self, x, key, stride=1, padding=0):
-        return F.conv2d(x, self.sd[key + ".weight"], self.sd.get(key + ".bias"), stride, padding)
+        return F.conv2d(self.q(x), self.sd[key + ".weight"], self.sd.get(key + ".bias"), stride, padding)
 
     def _bn(self, x, key):
         sd = self.sd
@@ -87,6 +95,7 @@ class DLAOracle:
     def _deform_conv(self, x, p):
         if self.use_dcn:
             sd = self.sd
+            x = self.q(x)
             y = _dcn.dcn_module_forward(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"],
                                         sd[p + ".conv.conv_offset_mask.weight"],
                                         sd[p + ".conv.conv_offset_mask.bias"],
@@ -101,7 +110,7 @@ class DLAOracle:
             w = self.sd["%s.up_%d.weight" % (p, k)]
             f = w.shape[2] // 2
             y = self._deform_conv(layers[i], "%s.proj_%d" % (p, k))
-            y = F.conv_transpose2d(y, w, None, stride=f, padding=f // 2, groups=w.shape[0])
+            y = F.conv_transpose2d(self.q(y), w, None, stride=f, padding=f // 2, groups=w.shape[0])
             layers[i] = self._deform_conv(y + layers[i - 1], "%s.node_%d" % (p, k))
 
     def forward(self, x):

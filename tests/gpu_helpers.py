@@ -55,7 +55,7 @@ def mk(kind, dtype, **kw):
 
 
 def conv(x, w, b, dtype, stride=1, relu=False, res=None, out_mode=_lib.OUT_NHWC, in_pad=0, out_pad=0,
-         pad_cout_to=None):
+         pad_cout_to=None, name_only=False):
     """x NCHW fp32 cpu; returns NCHW fp32 cpu result of the HIP conv (input/output living inside wider
     channel-strided buffers when in_pad/out_pad > 0)."""
     B, Ci, H, W = x.shape
@@ -84,6 +84,8 @@ def conv(x, w, b, dtype, stride=1, relu=False, res=None, out_mode=_lib.OUT_NHWC,
     op = mk(_lib.OP_CONV, dtype, in_=xptr, in2=rptr, w=wp.data_ptr(), bias=bp.data_ptr(), out=optr, B=B, H=H, W=W,
             Cin=Ci, in_cs=Ci + in_pad, in2_cs=rcs, Ho=Ho, Wo=Wo, Cout=cout, out_cs=ocs, ksize=k, stride=stride,
             relu=int(relu), out_mode=out_mode, wrows=rows)
+    if name_only:
+        return kernel_name(op)
     run(op)
     if out_mode == _lib.OUT_NCHW_F32:
         return out.cpu(), None
@@ -103,3 +105,134 @@ def bf16_round(t):
 def rnd(key, shape, lo=-1.0, hi=1.0, seed=0):
     from h3d_amd import synth
     return torch.from_numpy(synth.uniform(key, shape, lo, hi, seed))
+
+
+# ------------------------------------------------------------------------------------------------
+# Per-op drivers for the LDS-DMA kernels (csrc/conv2.hip, dcn3.hip, dcn4.hip).  Weights go through the
+# PRODUCT's packer (engine.PackedWeights), so the stage-major filter images are tested with it.
+def kernel_name(op):
+    """Kernel instantiation `op` dispatches to (dry run, nothing is launched)."""
+    buf = ctypes.create_string_buffer(200)
+    _lib.check(_lib.lib().h3d_op_kernel_name(ctypes.byref(op), buf, 200), "op_kernel_name")
+    return buf.value.decode()
+
+
+def fake_pw(sd, dtype):
+    """engine.PackedWeights over an ad-hoc {key: tensor} table (no architecture check)."""
+    from h3d_amd import engine
+    pw = object.__new__(engine.PackedWeights)
+    pw.sd = {k: v.float() for k, v in sd.items()}
+    pw.dtype, pw.device, pw.t = dtype, torch.device(DEV), {}
+    return pw
+
+
+class Built:
+    """An op + the tensors it points into + how to read its output back as NCHW fp32 (cpu)."""
+
+    def __init__(self, op, keep, read):
+        self.op, self.keep, self.read = op, keep, read
+
+    @property
+    def name(self):
+        return kernel_name(self.op)
+
+    def run(self):
+        run(self.op)
+        return self.read()
+
+
+def conv_stream_op(x, w, b, stride=1, relu=True, res=None, reserved=0, in_pad=0, out_pad=0):
+    """H3D_OP_CONV_STREAM (bf16) for NCHW fp32 cpu tensors; in_pad/out_pad: live inside wider buffers."""
+    B, Ci, H, W = x.shape
+    pw = fake_pw({"w": w, "b": b}, "bf16")
+    wimg, bp, cout, cin, rows = pw.conv_stream("w", "b")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    xin, xptr = nhwc(x, "bf16", Ci + in_pad, in_pad // 2 // 8 * 8)
+    keep = [wimg, bp, xin]
+    rptr, rcs = None, 0
+    if res is not None:
+        rbuf, rptr = nhwc(res, "bf16")
+        rcs = res.shape[1]
+        keep.append(rbuf)
+    ocs, coff = cout + out_pad, out_pad // 2 // 8 * 8
+    out = torch.full((B, Ho, Wo, ocs), 7.0, dtype=torch.bfloat16, device=DEV)
+    op = mk(_lib.OP_CONV_STREAM, "bf16", in_=xptr, in2=rptr, w=wimg.data_ptr(), bias=bp.data_ptr(),
+            out=out.data_ptr() + coff * 2, B=B, H=H, W=W, Cin=Ci, in_cs=Ci + in_pad, in2_cs=rcs, Ho=Ho, Wo=Wo, Cout=cout,
+            out_cs=ocs, ksize=3, stride=stride, relu=int(relu), out_mode=_lib.OUT_NHWC, wrows=rows, reserved=reserved)
+
+    def read():
+        if out_pad:
+            m = torch.ones(ocs, dtype=torch.bool)
+            m[coff:coff + cout] = False
+            assert bool((out[..., m.to(DEV)].float() == 7.0).all().item()), "neighbouring channels overwritten"
+        return from_nhwc(out, cout, coff)
+    return Built(op, keep, read)
+
+
+def _dcn_sd(w, b, wo, bo):
+    co = w.shape[0]
+    return {"p.conv.weight": w, "p.conv.bias": b, "p.conv.conv_offset_mask.weight": wo, "p.conv.conv_offset_mask.bias": bo,
+            "p.actf.0.weight": torch.ones(co), "p.actf.0.bias": torch.zeros(co), "p.actf.0.running_mean": torch.zeros(co),
+            "p.actf.0.running_var": torch.full((co,), 1.0 - 1e-5)}   # + BN_EPS = 1: identity
+
+
+def dcn_fused_op(kind, x, w, b, wo, bo, dtype="bf16", reserved=0, skip=None, w_up=None):
+    """DeformConv with conv_offset_mask fused in, through one of
+         'fused'   H3D_OP_DCN_FUSED        (csrc/dcn3.hip, register-staged filters; f32 or bf16)
+         'stream'  H3D_OP_DCN_FUSED_STREAM (csrc/dcn3.hip WDMA; bf16)
+         'f16'     H3D_OP_DCN_FUSED_F16    (csrc/dcn4.hip; x is stored as fp16)
+         'updcn'   H3D_OP_UPDCN_F16        (csrc/dcn4.hip UP = 1; x is the LOW-resolution bf16 map, skip/w_up given)
+    x/skip NCHW fp32 cpu, w [Co,Ci,3,3], wo [27,Ci,3,3], w_up [C,1,2f,2f].  BatchNorm = identity, ReLU on."""
+    B, Ci, H, W = x.shape
+    pw = fake_pw(_dcn_sd(w, b, wo, bo), dtype)
+    keep = []
+    Ho, Wo, stride = H, W, 1
+    in2 = None
+    if kind == "fused":
+        wp, bp, cout, cin, k, rows = pw.conv("p.conv.weight", "p.conv.bias", "p.actf.0", as_half=True)
+        wop, bop = pw.offset_conv("p.conv.conv_offset_mask.weight", "p.conv.conv_offset_mask.bias", rows)
+        bias = torch.cat([bp.cpu(), bop]).contiguous().to(DEV)
+        xin, xptr = nhwc(x, dtype)
+        opk, wptr, in2 = _lib.OP_DCN_FUSED, wp.data_ptr(), wop.data_ptr()
+        keep += [wp, wop, bias, xin]
+    else:
+        assert dtype == "bf16"
+        ck = int(_lib.lib().h3d_dcn_fused_ck(Ci, w.shape[0])) if kind == "stream" else 16
+        wimg, woimg, bias, cout, cin, rows = pw.dcn_stream("p", ck)
+        wptr = wimg.data_ptr()
+        keep += [wimg, woimg, bias]
+        if kind == "stream":
+            xin, xptr = nhwc(x, "bf16")
+            opk, in2 = _lib.OP_DCN_FUSED_STREAM, woimg.data_ptr()
+        elif kind == "f16":
+            xin = x.permute(0, 2, 3, 1).contiguous().to(torch.float16).to(DEV)
+            xptr = xin.data_ptr()
+            opk, in2 = _lib.OP_DCN_FUSED_F16, woimg.data_ptr()
+        else:
+            k2 = w_up.shape[2]
+            f = k2 // 2
+            Ho, Wo, stride = H * f, W * f, f
+            xin, xptr = nhwc(x, "bf16")
+            sbuf, sptr = nhwc(skip, "bf16")
+            wup = w_up.reshape(Ci, k2 * k2).t().contiguous().float().to(DEV)
+            desc = _lib.H3dUpdcnDesc()
+            desc.skip, desc.w_up, desc.w_off, desc.skip_cs = sptr, wup.data_ptr(), woimg.data_ptr(), Ci
+            keep += [sbuf, wup, desc]
+            opk, in2 = _lib.OP_UPDCN_F16, ctypes.addressof(desc)
+        keep.append(xin)
+    out = torch.zeros(B, Ho, Wo, cout, dtype=TD[dtype], device=DEV)
+    op = mk(opk, dtype, in_=xptr, in2=in2, w=wptr, bias=bias.data_ptr(), out=out.data_ptr(), B=B, H=H, W=W, Cin=Ci, in_cs=Ci,
+            Ho=Ho, Wo=Wo, Cout=cout, out_cs=cout, ksize=3, stride=stride, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows,
+            reserved=reserved)
+    return Built(op, keep, lambda: from_nhwc(out, cout))
+
+
+def dcn_fused_reference(x, w, b, wo, bo):
+    """fp64-accumulated oracle of DCN.forward + ReLU (dcn_v2.py:118-128; oracle/dcn.py), x NCHW."""
+    from oracle import dcn as odcn
+    om = torch.nn.functional.conv2d(x.double(), wo.double(), bo.double(), 1, 1).float()
+    o1, o2, mask = torch.chunk(om, 3, dim=1)
+    offset = torch.cat((o1, o2), dim=1).contiguous()
+    y = odcn.dcn_v2_forward(x, w, b, offset, torch.sigmoid(mask).contiguous(), 3, 3, 1, 1, 1, 1, 1, 1, 1,
+                            acc_dtype=torch.float64)
+    return torch.relu(y), om

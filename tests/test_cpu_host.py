@@ -85,14 +85,32 @@ def test_shard_batch_partitions():
         assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
 
 
-def test_gather_detections_world2_gloo():
+@pytest.mark.parametrize("world,port", [(2, 29531), (4, 29537)])
+def test_gather_detections_gloo(world, port):
+    # even and uneven shards (n = 8, 9, 10, ...), see tests/dist_worker.py
     script = os.path.join(ROOT, "tests", "dist_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29531", script],
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), script],
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_OK" in r.stdout
+
+
+def test_bench_launches_its_own_ranks_gloo_dry_run():
+    # `python bench.py --gpus 2` without torchrun must start 2 ranks itself and relay rank 0's JSON line; --dry-run
+    # replaces the GPU step by the collective on CPU tensors over gloo (no HIP call anywhere), everything else --
+    # launcher, rendezvous on 127.0.0.1, barriers, max-over-ranks timing, the line's contract fields -- is the real code
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run", "--batch", "5"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["config"]["global_batch"] == 10 and line["dry_run"] is True and line["scaling"] == "weak"
 
 
 def test_flip_helpers_match_the_reference_semantics():

@@ -33,18 +33,37 @@ CONV_CASES = [
     (2, 32, 64, 16, 16, 1, 1, False, False),    # project 1x1 (CK=16 path)
     (1, 448, 128, 16, 16, 1, 1, True, False),   # root 1x1 over a concat
     (1, 1280, 512, 4, 4, 1, 1, True, False),    # level5 root
+    (2, 128, 64, 24, 24, 1, 1, True, False),    # level2 root (Cin % 64 == 0, <= 64 channels: 8-row tiles)
+    (1, 32, 64, 40, 24, 3, 2, True, False),     # level2 tree1.conv1 (stride 2 below 64 input channels stays on conv.hip)
+    (1, 128, 256, 24, 24, 3, 2, True, False),   # stride 2, 128-channel workgroups
 ]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_matches_torch(case, dtype):
+def _case_tensors(case, dtype):
     B, Ci, Co, H, W, k, s, relu, use_res = case
     x = rnd("x", (B, Ci, H, W))
     w = rnd("w", (Co, Ci, k, k), -1.0, 1.0) * (1.5 / np.sqrt(Ci * k * k))
     b = rnd("b", (Co,))
     if dtype == "bf16":
         x, w = bf16_round(x), bf16_round(w)
+    return x, w, b
+
+
+def conv_case_kernel_names(dtype):
+    """Kernel instantiations CONV_CASES dispatch to (dry run; tests/test_gpu_variants.py's coverage check)."""
+    names = set()
+    for case in CONV_CASES:
+        x, w, b = _case_tensors(case, dtype)
+        res = rnd("r", (case[0], case[2], (case[3] - 1) // case[6] + 1, (case[4] - 1) // case[6] + 1)) if case[8] else None
+        names.add(conv(x, w, b, dtype, stride=case[6], relu=case[7], res=res, name_only=True))
+    return names
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_torch(case, dtype):
+    B, Ci, Co, H, W, k, s, relu, use_res = case
+    x, w, b = _case_tensors(case, dtype)
     ref = F.conv2d(x.double(), w.double(), b.double(), s, k // 2)
     res = None
     if use_res:

@@ -1,0 +1,96 @@
+"""BASELINE configs[1] (batch 32) and configs[2] (batch 64) at their real size: 512x512 bf16, the plan bench.py times.
+
+Two distinct synthetic images repeated B/2 times go through the default bf16 plan (the same kernels, tile
+configurations and grid sizes as the benchmark); then
+  * the heads of the two images are compared with the fp32 oracle network (oracle/dla.py, pinned to the reference's
+    own model output by tests/test_oracle_golden.py).  The tolerance is not a constant: the synthetic weights with
+    gain 1.25 keep the signal alive through DLA-34 (head maps with std 1-2.5), which also amplifies rounding noise,
+    so the yardstick is an INDEPENDENT bf16 evaluation of the same graph on the CPU (DLAOracle(emulate_bf16=True)):
+    the GPU's distance from the fp32 result may be at most 1.5x that evaluation's, in max-norm and in rms, per head
+    (measured: GPU 0.41-0.73 max / emulation 0.39-0.70 max on heads of std 0.8-2.5);
+  * every repeat must be BIT-identical to the first occurrence, and a second forward to the first forward -- a race in
+    a DMA ring / counted wait of the 8- and 16-wave variants shows up here;
+  * the decoded top-k peak indices are compared with the oracle's (oracle/index_match.py): bit-identical on the
+    ranks whose order the bf16 error cannot change, statistics asserted for the rest.
+"""
+import numpy as np
+import pytest
+import torch
+
+import h3d_amd  # noqa: F401
+from h3d_amd import arch, synth
+from h3d_amd.detector import MultiPoseDetector, Opt
+from oracle import dla as odla
+from oracle import index_match as oim
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF16_RATIO = 1.5  # GPU bf16 error / CPU bf16-emulation error (both vs the fp32 oracle), max-norm and rms
+GAIN = 1.25       # signal-preserving synthetic weights (h3d_amd.synth): head maps with O(1) variation and separated peaks
+
+
+@pytest.fixture(scope="module")
+def setup():
+    opt = Opt(input_h=512, input_w=512, smpl=True, dtype="bf16", K=100)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=GAIN)
+    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    two = synth.synth_images(2, 512, 512, seed=317)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    with torch.no_grad():
+        ref = {k: v.numpy() for k, v in odla.DLAOracle(sd, opt.heads, use_dcn=True)(torch.from_numpy(two))[0].items()}
+        emu = {k: v.numpy() for k, v in odla.DLAOracle(sd, opt.heads, use_dcn=True, emulate_bf16=True)(torch.from_numpy(two))[0].items()}
+    tol = {k: (float(np.abs(emu[k] - ref[k]).max()), float(np.sqrt(np.mean((emu[k] - ref[k]) ** 2)))) for k in ref}
+    return opt, det, two, ref, tol, sd
+
+
+@pytest.mark.parametrize("batch", [32, 64])
+def test_full_size_bf16_plan_vs_oracle(setup, batch):
+    opt, det, two, ref, tol, _ = setup
+    xs = torch.from_numpy(two).to(DEV).repeat(batch // 2, 1, 1, 1).contiguous()
+    res = det.run(xs)
+    heads = {k: v.clone() for k, v in res["heads"].items()}
+    inds = res["inds"].clone()
+    dets = res["dets"].clone()
+    # (1) parity of the first two images
+    got = {k: v[:2].cpu().numpy() for k, v in heads.items()}
+    worst = {k: (float(np.abs(got[k] - ref[k]).max()), float(np.sqrt(np.mean((got[k] - ref[k]) ** 2)))) for k in opt.heads}
+    print("batch %d: head error vs fp32 oracle (max, rms): %s" % (batch, {k: (round(a, 4), round(b, 4)) for k, (a, b) in worst.items()}))
+    print("          CPU bf16 emulation         (max, rms): %s" % {k: (round(a, 4), round(b, 4)) for k, (a, b) in tol.items()})
+    for k, (emax, erms) in worst.items():
+        assert emax <= BF16_RATIO * tol[k][0] + 1e-3 and erms <= BF16_RATIO * tol[k][1] + 1e-4, (k, emax, erms, tol[k])
+    # (2) every repeat bit-identical, run-to-run bit-identical
+    for k, v in heads.items():
+        r = v.view(batch // 2, 2, *v.shape[1:])
+        assert torch.equal(r, r[:1].expand_as(r)), "head %s differs between repeats of the same image" % k
+    assert torch.equal(inds.view(batch // 2, 2, -1), inds[:2].unsqueeze(0).expand(batch // 2, 2, -1))
+    again = det.run(xs)
+    for k in heads:
+        assert torch.equal(heads[k], again["heads"][k]), k
+    assert torch.equal(dets, again["dets"])
+    # (3) top-k peak indices vs the oracle
+    m = oim.index_match(got, inds[:2].cpu().numpy(), ref, K=opt.K)
+    print("batch %d: index_match %s" % (batch, m))
+    assert m["robust_prefix_equal"], m
+    # random-weight heat maps are noise-like: the median score gap between consecutive peaks (6e-4) is far below the
+    # bf16 score error (0.07), so ranks shuffle; the peaks themselves mostly survive (measured overlap 0.70)
+    assert m["set_overlap"] >= 0.5, m
+    assert res["verts"].shape == (batch, opt.K, 6890, 3)
+    del res, again, heads
+    torch.cuda.empty_cache()
+
+
+def test_full_size_f32_mode_indices_match_oracle(setup):
+    """Parity mode (fp32 activations, exact fmaf chains on v_mfma_f32_32x32x2_f32) at 512x512: here the metric's
+    "top-k index bit-match" is attainable end to end -- heads within 2e-3 of the oracle (max |head| ~ 10) and the decoded
+    peak indices identical to the oracle's wherever the score gap exceeds that error."""
+    opt, _, two, ref, _, sd = setup
+    o32 = Opt(input_h=512, input_w=512, smpl=True, dtype="f32", K=100)
+    det = MultiPoseDetector(o32, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    res = det.run(torch.from_numpy(two).to(DEV))
+    got = {k: v.cpu().numpy() for k, v in res["heads"].items()}
+    for k in o32.heads:
+        e = float(np.abs(got[k] - ref[k]).max())
+        assert e <= 2e-3, (k, e)
+    m = oim.index_match(got, res["inds"].cpu().numpy(), ref, K=100)
+    print("f32 mode: index_match %s" % m)
+    assert m["robust_prefix_equal"] and m["agreement"] >= 0.95 and m["set_overlap"] >= 0.98, m

@@ -20,7 +20,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
 F32_TOL = 2e-4      # abs, heads are O(1): f32 MFMA = exact fmaf chain, BN folding + summation order only
-BF16_TOL = 0.12     # abs: ~50 layers of bf16 activations/weights (2^-9 relative per rounding)
+BF16_TOL = 0.06     # abs, 2x the measured worst (0.03): ~50 layers of bf16 activations/weights (2^-9 relative per rounding);
+                    # tests/test_gpu_fullsize.py has the 512x512 check against a bf16-emulating oracle and the index statistics
 
 
 def _net(use_dcn, dtype, heads=HEADS):

@@ -1,0 +1,195 @@
+"""GPU parity of EVERY tile configuration the LDS-DMA kernels can dispatch to, per op, through the C ABI
+(h3d_run_ops): csrc/conv2.hip (`H3D_OP_CONV_STREAM`) against F.conv2d in fp64, csrc/dcn3.hip / dcn4.hip
+(`H3D_OP_DCN_FUSED`, `_STREAM`, `_F16`, `H3D_OP_UPDCN_F16`) against the oracle (oracle/dcn.py, the restatement
+of dcn_v2_im2col_cuda.cu:125-195 + dcn_v2.py:118-128).
+
+Why this file exists: the launchers choose <MT, WAVES, S, SLOTS> from the workgroup count, so the small
+network tests only ever reach the 4-wave variants while a batch-64 512x512 plan runs the 8/16-wave ones.
+Here every variant is forced on small tensors with `h3d_op.reserved` and, separately, selected the natural
+way by a tensor large enough; `test_bench_plan_kernels_are_all_covered` asserts that the set of kernel
+instantiations tested here and in test_gpu_conv.py contains every instantiation of the batch-64 bench plan
+and of the batch-32 plan (BASELINE configs 1 and 2).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_helpers import DEV, Built, bf16_round, conv_stream_op, dcn_fused_op, dcn_fused_reference, kernel_name, rnd
+from h3d_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+# ---- csrc/conv2.hip ------------------------------------------------------------------------------------
+# (override, B, Cin, Cout, H, W, stride, relu, residual, in_pad, out_pad)
+CONV2_CASES = [
+    # forced variants on small, ragged tensors (H not a multiple of the tile height, W not of 16)
+    (0x410, 2, 64, 128, 40, 24, 1, True, True, 0, 0),      # <4,16>: 32 x 16 px tiles, 16 waves
+    (0x410, 1, 128, 256, 64, 32, 1, True, False, 0, 0),    #         two 128-channel groups, aligned
+    (0x408, 2, 128, 128, 24, 40, 1, True, True, 0, 0),     # <4,8>
+    (0x404, 1, 256, 256, 12, 20, 1, False, False, 0, 0),   # <4,4>
+    (0x208, 2, 64, 64, 24, 40, 1, True, True, 64, 64),     # <2,8> inside concat buffers
+    (0x204, 1, 32, 64, 20, 36, 1, True, False, 0, 0),      # <2,4>
+    (0x108, 2, 32, 32, 24, 24, 1, True, False, 0, 0),      # <1,8>
+    (0x104, 1, 48, 32, 10, 18, 1, False, False, 0, 0),     # <1,4>
+    (0x5108, 2, 16, 16, 40, 40, 1, True, False, 0, 0),     # <1,8,1,1>: one stage, no ring
+    (0x5208, 1, 64, 64, 24, 24, 1, True, True, 0, 0),      # <2,8,1,1>: one ring slot
+    (0x5408, 1, 64, 128, 24, 24, 1, True, False, 0, 0),    # <4,8,1,1>
+    (0x3208, 1, 96, 64, 24, 24, 1, True, False, 0, 0),     # three ring slots (counted vmcnt wait)
+    (0x3108, 1, 96, 32, 24, 24, 1, True, False, 0, 0),
+    (0x3404, 1, 96, 128, 12, 24, 1, True, False, 0, 0),
+    (0x2408, 1, 64, 128, 40, 24, 1, True, True, 0, 0),     # two N-tiles per wave
+    (0x2208, 1, 64, 64, 40, 24, 1, True, False, 0, 0),
+    # stride 2 (33-pixel halo rows = two DMA pieces)
+    (0, 2, 64, 128, 36, 40, 2, True, False, 0, 0),         # auto: <4,4,2,1>
+    (0x2404, 1, 128, 256, 24, 24, 2, True, False, 0, 0),   # <4,4,2> two-slot ring
+    (0x4408, 1, 64, 128, 40, 24, 2, True, False, 0, 0),    # <4,8,2,1>
+    (0x4204, 1, 64, 64, 24, 40, 2, True, False, 0, 0),     # <2,4,2,1>
+    (0, 1, 64, 64, 22, 34, 2, True, False, 0, 0),          # auto, odd sizes: <2,4,2>
+    (0, 1, 64, 32, 24, 24, 2, False, False, 0, 0),         # auto: <1,4,2>
+    # selected the natural way (>= 256 workgroups), the shapes of the batch-64 / batch-32 plans in miniature
+    (0, 32, 32, 128, 64, 64, 1, True, True, 0, 0),         # level3/4 class: 256 tiles of 32 x 16 px -> <4,16>
+    (0, 24, 32, 128, 48, 64, 1, True, True, 0, 0),         # level5 class: H not a multiple of 32 -> <4,8>
+    (0, 4, 64, 64, 128, 128, 1, True, True, 0, 0),         # level2 class -> <2,8>
+]
+
+
+def _conv2_built(case):
+    ov, B, Ci, Co, H, W, s, relu, use_res, ipad, opad = case
+    x = bf16_round(rnd("x", (B, Ci, H, W)))
+    w = bf16_round(rnd("w", (Co, Ci, 3, 3)) * (1.5 / np.sqrt(Ci * 9)))
+    b = rnd("b", (Co,))
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = bf16_round(rnd("r", (B, Co, Ho, Wo))) if use_res else None
+    return x, w, b, res, conv_stream_op(x, w, b, s, relu, res, ov, ipad, opad)
+
+
+@pytest.mark.parametrize("case", CONV2_CASES, ids=lambda c: "%#x-%dx%d-%dx%d-s%d-b%d" % (c[0], c[2], c[3], c[4], c[5], c[6], c[1]))
+def test_conv_stream_variant_matches_torch(case):
+    x, w, b, res, built = _conv2_built(case)
+    s, relu = case[6], case[7]
+    ref = F.conv2d(x.double(), w.double(), b.double(), s, 1)
+    if res is not None:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    got = built.run()
+    # bf16 operands are exact in the reference, accumulation is fp32: what is left is the final rounding to bf16
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref.float()).abs().max())
+    assert err <= 2.0 ** -8 * scale, "%s: max err %.3g (scale %.2f)" % (built.name, err, scale)
+    # the 16 x 32 px x 128 ch workgroups must be deterministic (DMA ring / counted waits)
+    again = built.run()
+    assert torch.equal(got, again), built.name
+
+
+def test_conv_stream_auto_selection_reaches_the_wide_variants():
+    names = {_conv2_built(c)[4].name for c in CONV2_CASES if c[0] == 0 and c[6] == 1}
+    assert {"conv2_kernel<4, 16, 2, 1, 2, 1>", "conv2_kernel<4, 8, 2, 1, 2, 1>", "conv2_kernel<2, 8, 2, 1, 2, 1>"} <= names, names
+
+
+# ---- csrc/dcn3.hip, csrc/dcn4.hip ------------------------------------------------------------------------
+# (kind, dtype, override, B, Cin, Cout, H, W, offset_scale)
+DCN_CASES = [
+    ("fused", "bf16", 0x400, 1, 128, 128, 24, 40, 0.5),    # dcn3<bf16,4,16,2>: every >= 128-channel layer of the batch-64 plan
+    ("fused", "bf16", 0x400, 1, 256, 256, 16, 16, 3.0),
+    ("fused", "bf16", 0x400, 1, 512, 256, 16, 16, 12.0),   #   ... with most samples through pass 2 (global gather)
+    ("fused", "bf16", 0x200, 1, 256, 128, 24, 24, 0.5),    # dcn3<bf16,2,32,2> on a >64-channel layer (two channel groups)
+    ("fused", "bf16", 0x200, 1, 144, 128, 16, 16, 3.0),    # dcn3<bf16,2,16,2> (Cin not a multiple of 32)
+    ("fused", "bf16", 0, 2, 128, 64, 24, 40, 0.5),         # dcn3<bf16,2,32,2>
+    ("fused", "bf16", 0, 1, 48, 64, 20, 20, 3.0),          # dcn3<bf16,2,16,2>
+    ("fused", "bf16", 0, 1, 64, 32, 20, 36, 3.0),          # dcn3<bf16,1,32,2>
+    ("fused", "bf16", 0, 1, 48, 32, 16, 16, 0.5),          # dcn3<bf16,1,16,2>
+    ("fused", "f32", 0, 1, 64, 64, 20, 24, 3.0),           # parity mode
+    ("fused", "f32", 0, 1, 32, 32, 16, 16, 12.0),
+    ("stream", "bf16", 0, 2, 128, 64, 24, 40, 0.5),        # dcn3<bf16,2,16,1,WDMA>: two workgroups per CU
+    ("stream", "bf16", 0, 1, 256, 64, 16, 32, 3.0),
+    ("stream", "bf16", 0, 1, 64, 32, 20, 20, 12.0),        # dcn3<bf16,1,16,1,WDMA>
+    ("stream", "bf16", 0, 1, 128, 128, 16, 32, 3.0),       # dcn3<bf16,4,16,2,WDMA>
+    ("f16", "bf16", 0, 2, 64, 64, 24, 40, 0.5),            # dcn4<2,.,1,0> DENSE
+    ("f16", "bf16", 0, 1, 64, 64, 20, 20, 12.0),
+    ("f16", "bf16", 0x100, 1, 64, 64, 24, 40, 3.0),        # dcn4<2,.,0,0> one workgroup per CU
+    ("f16", "bf16", 0, 1, 64, 32, 20, 36, 3.0),            # dcn4<1,.,1,0>
+    ("f16", "bf16", 0x100, 1, 64, 32, 16, 16, 0.5),
+    ("updcn2", "bf16", 0, 2, 64, 64, 12, 20, 0.5),         # dcn4<2,.,1,1>: 2x up-sampling + add folded in
+    ("updcn2", "bf16", 0, 1, 64, 64, 10, 10, 12.0),
+    ("updcn4", "bf16", 0, 1, 64, 64, 6, 10, 3.0),          # 4x (ida_up.up_2: 8x8 stride-4 deconv)
+    ("updcn2", "bf16", 0, 1, 64, 32, 10, 18, 3.0),         # dcn4<1,.,1,1>
+    # selected the natural way by the workgroup count (>= 192 x 128-channel workgroups / >= 512 tiles)
+    ("fused", "bf16", 0, 12, 128, 128, 64, 64, 0.5),       # 192 workgroups -> MT = 4 without an override
+]
+
+
+def _dcn_built(case):
+    kind, dtype, ov, B, Ci, Co, H, W, oscale = case
+    x = rnd("x", (B, Ci, H, W))
+    a = float(np.sqrt(3.0 / (Ci * 9)))
+    w = rnd("w", (Co, Ci, 3, 3)) * (1.5 / np.sqrt(Ci * 9))
+    b = rnd("b", (Co,))
+    wo = rnd("wo", (27, Ci, 3, 3)) * (a * oscale * np.sqrt(3.0))      # offsets ~ N(0, oscale^2)-ish like synth weights
+    bo = rnd("bo", (27,), -0.1, 0.1)
+    skip = w_up = None
+    if dtype == "bf16":
+        w, wo = w.half().float(), wo.half().float()                       # DCN filters are fp16 in bf16 plans
+        x = bf16_round(x)
+    if kind.startswith("updcn"):
+        f = int(kind[-1])
+        skip = bf16_round(rnd("skip", (B, Ci, H * f, W * f)))
+        w_up = rnd("wup", (Ci, 1, 2 * f, 2 * f), 0.0, 0.5)
+        xin = (F.conv_transpose2d(x.double(), w_up.double(), None, stride=f, padding=f // 2, groups=Ci)
+               + skip.double()).float().half().float()                    # the folded sum is rounded once, to fp16
+        built = dcn_fused_op("updcn", x, w, b, wo, bo, dtype, ov, skip, w_up)
+    else:
+        xin = x.half().float() if kind == "f16" else x
+        built = dcn_fused_op(kind, xin if kind == "f16" else x, w, b, wo, bo, dtype, ov)
+    return xin, w, b, wo, bo, built
+
+
+@pytest.mark.parametrize("case", DCN_CASES, ids=lambda c: "%s-%s-%#x-%dx%d-%dx%d-o%g-b%d" % (c[0], c[1], c[2], c[4], c[5], c[6], c[7], c[8], c[3]))
+def test_dcn_fused_variant_matches_oracle(case):
+    kind, dtype = case[0], case[1]
+    xin, w, b, wo, bo, built = _dcn_built(case)
+    ref, om = dcn_fused_reference(xin, w, b, wo, bo)
+    got = built.run()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    # f32: exact fmaf chains, offsets from an fp32 conv (sampling positions move by ~1e-6 px).
+    # bf16: fp16 blend (2^-11 per sample) + f16 MFMA with fp32 accumulation + one bf16 rounding of the output (2^-9)
+    tol = 2e-4 * scale if dtype == "f32" else 1.2e-2 * scale
+    frac_far = float((om[:, :18].abs() > 1.0).float().mean())
+    assert err <= tol, "%s: max err %.3g > %.3g (scale %.2f, |offset|>1 for %.0f%%)" % (built.name, err, tol, scale, 100 * frac_far)
+    assert torch.equal(got, built.run()), built.name
+
+
+def test_dcn_auto_selection_reaches_mt4():
+    c = [c for c in DCN_CASES if c[3] == 12][0]
+    assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 4, 16, 2, 2, false>"
+
+
+# ---- the bench plan's kernel set -----------------------------------------------------------------------------
+def _plan_kernel_names(batch):
+    import h3d_amd  # noqa: F401
+    from h3d_amd import arch, synth
+    from h3d_amd.detector import MultiPoseDetector, Opt
+    opt = Opt(input_h=512, input_w=512, smpl=True, dtype="bf16")
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0)
+    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    plan = det.model.engine(torch.device(DEV)).plan(batch, 512, 512)
+    return {kernel_name(op) for op in plan.ops}
+
+
+def test_bench_plan_kernels_are_all_covered():
+    """tested-kernel-set >= bench-kernel-set: every conv / DeformConv instantiation of the batch-64 (bench.py,
+    BASELINE configs[2]) and batch-32 (configs[1]) plans has a per-op parity case above or in test_gpu_conv.py;
+    the remaining kernels (stem3, heads, max-pool, up-sample) have exactly one instantiation per dtype and are
+    compared at full size in test_gpu_fullsize.py."""
+    import test_gpu_conv
+    from gpu_helpers import conv as _  # noqa: F401
+    tested = {_conv2_built(c)[4].name for c in CONV2_CASES} | {_dcn_built(c)[5].name for c in DCN_CASES}
+    tested |= test_gpu_conv.conv_case_kernel_names("bf16")
+    single = ("stem3_kernel", "heads_kernel<", "maxpool_kernel<", "upadd_kernel<", "copy_kernel<")
+    for batch in (64, 32):
+        names = _plan_kernel_names(batch)
+        missing = sorted(n for n in names if n not in tested and not n.startswith(single))
+        assert not missing, "batch %d: no per-op parity case dispatches to %s" % (batch, missing)
+        torch.cuda.empty_cache()
