@@ -11,8 +11,16 @@
 //   geometry each half computes the sampling geometry of ITS taps only (no duplication) and the two
 //            halves exchange the results with one cross-half shuffle per value.
 //   phase B  dcn2's branch-free gather + fp16 blend + MFMA over the same chunks (csrc/dcn2.hip).
-//   pass 2   (rare) samples whose corners left the apron: offsets are re-broadcast from the phase-A
-//            accumulators, corners gathered from global memory.
+//   patches  (NP > 0, bf16 plans) samples whose corners left the apron do NOT leave the fast path: after the geometry
+//            every such (pixel, tap) takes a slot in a per-tile list (wave ballot + one LDS atomic per wave); at every
+//            phase-B stage thread e fetches the 4 corners of list entry e for the stage's channels from global memory
+//            (range-checked buffer loads: corners outside the image read as zero), blends them with the sample's own
+//            weights and drops the result into a "patch" pixel in front of the apron; the sample's gather offset points
+//            at that patch with weights (1, 0, 0, 0), so phase B stays branch free.  Cost ~ number of such samples,
+//            not "any lane in the wave" x all channels as in pass 2 (at 5 % of the samples pass 2 made the kernel 5x
+//            slower).  Samples beyond the NP slots of a tile fall through to pass 2.
+//   pass 2   (rare) samples whose corners left the apron and found no patch slot: offsets are re-broadcast from
+//            the phase-A accumulators, corners gathered from global memory.
 #include "common.h"
 #include "epilogue.h"
 #include "dcn_traits.h"
@@ -30,7 +38,7 @@ struct Dcn3Args {
     int G;     // WDMA: 32-row groups of the main filter image
 };
 
-template <typename T, int MT, int CK, int MARGIN, bool WDMA = false>
+template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0>
 struct Dcn3Cfg {
     static constexpr int ES = sizeof(T);
     static constexpr int SS = SE<T>::SS;
@@ -49,10 +57,17 @@ struct Dcn3Cfg {
     static constexpr int WSLOT = WDMA ? WPIECES * 1024 : BN * WB;
     // register-staged path: apron and filters are double buffered (stage s+1 is written while stage s is read), which
     // halves the barriers: the SQ counters showed these kernels parked ~43 % of the time on two barriers per stage
-    static constexpr int STAGE = LDS_H + WSLOT;                        // one stage buffer (non-WDMA)
-    static constexpr int LDS_MAIN = WDMA ? LDS_H + 2 * WSLOT : 2 * STAGE;
+    // patches (NP > 0): NP "patch pixels" of CK channels in FRONT of the apron of a stage buffer (a sample's gather offset
+    // may then be negative; its three zero-weighted corner reads land in the patch area or the apron: finite data)
+    static constexpr int PSLOT = CK * SS;
+    static constexpr int PB = NP ? (NP * PSLOT + 255) / 256 * 256 : 0;
+    static constexpr int STAGE = PB + LDS_H + WSLOT;                   // one stage buffer (non-WDMA)
+    static constexpr int LDS_MAIN = WDMA ? PB + LDS_H + 2 * WSLOT : 2 * STAGE;
+    static constexpr int LDS_DESC = NP ? NP * 16 + 16 : 0;             // sample list (16 B each) + the slot counter
     static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // epilogue.h tile_epilogue_lds regions
-    static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+    static constexpr int LDS = LDS_MAIN + LDS_DESC > LDS_EPI ? LDS_MAIN + LDS_DESC : LDS_EPI;
+    static_assert(NP == 0 || (WDMA && sizeof(T) == 2), "patches: bf16 plans with DMA'd filters");
+    static_assert(NP * (CK * SS / 16) <= 512, "one 16-byte patch entry per thread");
 };
 
 // WDMA (bf16 plans): the filters are stage-major fp16 LDS images (H3D_OP_DCN_FUSED_STREAM) copied by LDS-DMA into a
@@ -69,14 +84,22 @@ __device__ __forceinline__ void dcn3_issue_w(const char *base, int bytes, char *
     }
 }
 
-template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
-__global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kernel(Dcn3Args a)
+// one corner of a patch entry: 16 bytes at byte offset voff (+ soff, the stage's channel offset) of image `img`; an offset
+// beyond `bytes` (corner outside the image, idle thread) reads as zero
+__device__ __forceinline__ u32x4 dcn3_patch_corner(const char *img, int bytes, int voff, int soff)
 {
-    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA>;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)img, 0, bytes, 0x00020000);
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+
+template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false, int NP = 0>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
+__global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dcn3Args a)
+{
+    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP>;
     using X = SE<T>;
     constexpr int ES = C::ES, SS = C::SS;
     __shared__ __attribute__((aligned(16))) char smem[C::LDS];
-    char *s_w = smem + C::LDS_H;       // filters of stage buffer 0 (pass 2) / of the WDMA ring
+    char *s_w = smem + C::PB + C::LDS_H;       // filters of stage buffer 0 (pass 2) / of the WDMA ring
 
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
@@ -139,7 +162,7 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
     };
     auto store_stage = [&](int s) {
         if ((H3D_DBG(a) & 8) && s > 0) return;
-        char *s_h = smem + (WDMA ? 0 : (s & 1) * C::STAGE);
+        char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
         char *s_w = s_h + C::LDS_H;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -157,6 +180,14 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
         }
     };
 
+    if constexpr (NP > 0) {
+        // every byte a zero-weighted corner read of a patched sample can touch must hold a finite number (0 x NaN = NaN):
+        // the patch area and the apron are cleared once (pad slots and row tails are never written afterwards; the filter
+        // slots only ever hold finite fp16); the barriers of phase A order this before any use
+        for (int i = tid * 16; i < C::PB + C::LDS_H; i += C::THREADS * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+        if (tid == 0) *reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16) = 0;
+        __syncthreads();                       // ... and before stage 0's apron is stored
+    }
     // ================= phase A: offsets/mask = conv3x3(x; 27 filters) ===============================
     f32x16 aoffs;   // rows (i&3)+8(i>>2)+4h of the permuted offset conv for this lane's pixel
 #pragma unroll
@@ -171,7 +202,7 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
         __syncthreads();
         issue_w(s + 1);
         load_stage(s + 1);                       // s + 1 == nchunks is phase B's first stage
-        const char *s_h = smem + (WDMA ? 0 : (s & 1) * C::STAGE);
+        const char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -194,9 +225,11 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
     int boff[9];
     typename X::geo geo[9];
     bool slow = false;
+    [[maybe_unused]] int pmask = 0;          // NP: bit `tap` = this pixel's sample of that tap lives in a patch
     {
         int my_off[5];
         typename X::geo my_geo[5];
+        int my_pm = 0;
         const int tb = h ? 5 : 0;
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
@@ -207,21 +240,48 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
             const bool inside = live && tap < 9 && (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
             typename X::geo g = X::zero_geo();
             int off = 0;
+            bool want = false;               // inside the image, corners outside the apron
+            int hl = 0, wl = 0;
             if (inside) {
-                const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                hl = (int)floorf(h_im);
+                wl = (int)floorf(w_im);
                 const int ry = hl - hy0, rx = wl - hx0;
+                const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                g = X::make_geo(w4, dcn2_sigmoid(aoffs[3 * u + 2]));
                 if (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH) {
-                    const float lh = h_im - (float)hl, lw = w_im - (float)wl;
-                    const float hh = 1.f - lh, hw = 1.f - lw;
-                    const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-                    g = X::make_geo(w4, dcn2_sigmoid(aoffs[3 * u + 2]));
                     off = ry * C::RBH + rx * C::SBH;
                 } else {
-                    slow = true;
+                    want = true;
                 }
             }
+            if constexpr (NP > 0) {
+                const unsigned long long m = __ballot(want);
+                if (m) {                                             // wave-uniform: one LDS atomic per wave and tap
+                    int base = 0;
+                    if (l == 0) base = __hip_atomic_fetch_add(reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16), __popcll(m),
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (want && slot < NP) {
+                        if constexpr (sizeof(T) == 2)
+                            *reinterpret_cast<u32x4 *>(smem + C::LDS_MAIN + slot * 16) =
+                                u32x4{((uint32_t)hl << 16) | ((uint32_t)wl & 0xffffu), g.w01, g.w23, 0u};
+                        off = slot * C::PSLOT - C::PB;               // the patch pixel, relative to the apron base
+                        if constexpr (sizeof(T) == 2) { g.w01 = 0x00003c00u; g.w23 = 0u; }   // (1, 0 | 0, 0): the blend is done when the patch is filled
+                        my_pm |= 1 << u;
+                        want = false;
+                    }
+                }
+            }
+            if (want) { slow = true; g = X::zero_geo(); }
             my_off[u] = off;
             my_geo[u] = g;
+        }
+        if constexpr (NP > 0) {
+            const int o_pm = __shfl_xor(my_pm, 32);
+            pmask = h == 0 ? (my_pm | (o_pm << 5)) : (o_pm | (my_pm << 5));
         }
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
@@ -237,6 +297,48 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
         }
     }
 
+    // ---- patches: thread `tid` owns the 16-byte unit tid % VPP of list entry tid / VPP for the whole of phase B ----------
+    [[maybe_unused]] int pvoff[4] = {0x7ffffff0, 0x7ffffff0, 0x7ffffff0, 0x7ffffff0};
+    [[maybe_unused]] typename X::geo pgeo = X::zero_geo();
+    [[maybe_unused]] bool phas = false;
+    [[maybe_unused]] const int img_bytes = (int)((size_t)a.H * a.W * a.in_cs * ES);
+    if constexpr (NP > 0) {
+        __syncthreads();                                                 // the list is complete
+        const int nsl = min(*reinterpret_cast<const int *>(smem + C::LDS_MAIN + NP * 16), NP);
+        const int ps = tid / C::VPP, pv = tid - ps * C::VPP;
+        phas = ps < nsl;
+        if (phas) {
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(smem + C::LDS_MAIN + ps * 16);
+            const int hl = (int)d[0] >> 16, wl = (int)(short)(d[0] & 0xffffu);
+            if constexpr (sizeof(T) == 2) { pgeo.w01 = d[1]; pgeo.w23 = d[2]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = hl + (k >> 1), xx = wl + (k & 1);
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) pvoff[k] = ((yy * a.W + xx) * a.in_cs) * ES + pv * 16;
+            }
+        }
+    }
+    // my patch unit for stage s (c0 = its first channel): the 4 corner loads are issued BEFORE the barrier that frees the
+    // apron buffer (they touch no LDS), so their latency overlaps the barrier wait and the apron stores; blend + store after
+    [[maybe_unused]] u32x4 pst[4];
+    auto patch_issue = [&](int s) {
+        if constexpr (NP > 0 && sizeof(T) == 2) {
+            const int c0 = (s - nchunks) * CK;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pst[k] = dcn3_patch_corner(img, img_bytes, pvoff[k], c0 * ES);   // idle threads: out of range, zeros
+        }
+    };
+    auto patch_commit = [&](char *s_h) {
+        if constexpr (NP > 0 && sizeof(T) == 2) {
+            if (!phas) return;
+            typename X::frag v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k].v = __builtin_bit_cast(half8_t, X::convert16(pst[k]));
+            const typename X::frag o = X::blend(v, pgeo);
+            *reinterpret_cast<half8_t *>(s_h - C::PB + tid * 16) = o.v;      // entry tid/VPP, unit tid%VPP: PSLOT = VPP * 16
+        }
+    };
+
     // ================= phase B: deformable contraction (branch-free, apron samples) ==================
     f32x16 acc[MT][1];
 #pragma unroll
@@ -244,12 +346,14 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
     for (int s = nchunks; s < 2 * nchunks; ++s) {
+        patch_issue(s);
         if (WDMA) __syncthreads();
         store_stage(s);
+        patch_commit(smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE));
         if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
         if (s + 1 < 2 * nchunks) { issue_w(s + 1); load_stage(s + 1); }
-        const char *s_h = smem + (WDMA ? 0 : (s & 1) * C::STAGE);
+        const char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -313,7 +417,7 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
                 if (live && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
                     const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
                     const int ry = hl - hy0, rx = wl - hx0;
-                    if (!(ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH)) {
+                    if (!(ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH) && !((pmask >> tap) & 1)) {
                         any = true;
                         const float lh = h_im - (float)hl, lw = w_im - (float)wl;
                         const float hh = 1.f - lh, hw = 1.f - lw;
@@ -356,10 +460,10 @@ __global__ __launch_bounds__(512, (WDMA && MARGIN == 1) ? 4 : 2) void dcn3_kerne
     }
 }
 
-template <typename T, int MT, int CK, int MARGIN, bool WDMA = false>
+template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0>
 static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
 {
-    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA>;
+    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP>;
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     Dcn3Args a = a0;
     a.tiles_x = cdiv(a.W, 16);
@@ -367,20 +471,20 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (sizeof(T) == 2 && MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d, %d, %s>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN, epi,
-                        WDMA ? "true" : "false"))
+    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN, epi,
+                        WDMA ? "true" : "false", NP))
         return H3D_OK;
     if constexpr (sizeof(T) == 2 && MT >= 2) {
         if (epi == 2) {
-            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2, WDMA>), grid, dim3(C::THREADS), 0, st, a);
+            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2, WDMA, NP>), grid, dim3(C::THREADS), 0, st, a);
             H3D_CHECK_LAUNCH("dcn3_kernel");
             return H3D_OK;
         }
     }
     if (epi == 1)
-        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1, WDMA>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1, WDMA, NP>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0, WDMA>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0, WDMA, NP>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("dcn3_kernel");
     return H3D_OK;
 }
@@ -411,11 +515,18 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.dbg = op.reserved;
     a.G = op.wrows / 32;
     if (wdma) {
-        // <= 64 output channels: margin-1 apron, 16-channel stages, <= 128 VGPRs and 58 KB of LDS -> two workgroups
-        // (16 waves) per CU, one computing while the other waits at its stage barriers (as csrc/dcn4.hip DENSE)
-        if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 1, true>(a, st);
-        if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 1, true>(a, st);
-        return launch_dcn3_cfg<bf16_t, 4, 16, 2, true>(a, st);
+        if ((size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
+        if (op.reserved & 0x1000) {     // tuning override: round 1's configurations (no patches: every sample that leaves the apron goes through pass 2)
+            if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 1, true>(a, st);
+            if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 1, true>(a, st);
+            return launch_dcn3_cfg<bf16_t, 4, 16, 2, true>(a, st);
+        }
+        // <= 64 output channels: margin-2 apron, 16-channel stages, <= 128 VGPRs and 78 KB of LDS -> two workgroups
+        // (16 waves) per CU, one computing while the other waits at its stage barriers; 256 patch slots per tile.
+        // > 64: one workgroup per CU has the LDS for a margin-4 apron (26 x 26 pixels)
+        if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 2, true, 256>(a, st);
+        if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 2, true, 256>(a, st);
+        return launch_dcn3_cfg<bf16_t, 4, 16, 4, true, 256>(a, st);
     }
     if (op.dtype == H3D_BF16) {
         if (op.Cin % 32 == 0 && op.Cout <= 64) {

@@ -237,9 +237,12 @@ class Plan:
         fuse_heads=True,       # False: one conv3x3 + conv1x1 launch pair per head (debug/ablation)
         fuse_offsets=True,     # False: conv_offset_mask as its own launch + dcn2_kernel reading NHWC offsets
         stream_convs=True,     # False: 3x3 convs through the register-staged kernel (csrc/conv.hip)
-        stream_dcn=True,       # False: 64-channel node DeformConvs through csrc/dcn3.hip (bf16 input)
+        stream_dcn=False,      # True: 64-channel node DeformConvs through csrc/dcn4.hip (fp16 input, up-sampling folded in): 0.35 ms
+                               # per batch-64 step faster while the offsets stay below ~1 px, 5x SLOWER per launch at 2 px
+                               # (no patch slots: its LDS is full); default since round 2: csrc/dcn3.hip with patches
         stream_s2=True,        # False: stride-2 3x3 convs (Cin >= 64) through csrc/conv.hip
-        stream_dcn3=False,     # True: ALL remaining fused DeformConvs take their filters by LDS-DMA (no gain above 64 output channels)
+        stream_dcn3=True,      # ALL remaining fused DeformConvs take their filters by LDS-DMA (csrc/dcn3.hip WDMA: the variants with patches)
+        dcn_patches=True,      # False: round 1's WDMA configurations (no patch slots: samples that leave the apron go through pass 2)
         dense_dcn3=True,       # those with <= 64 output channels do: margin-1 apron, two workgroups per CU (csrc/dcn3.hip)
         dense_dcn3_min_tiles=512,   # ... when the layer has at least this many 16x16 tiles (two per CU)
         fuse_upnode=True,      # False: up-sample + add always as its own launch in front of the 64-channel node DeformConvs
@@ -420,7 +423,7 @@ class Plan:
                 out = self._alloc(x.H, x.W, cout)
             self._op(_lib.OP_DCN_FUSED_STREAM, in_=x.ptr, in2=woimg.data_ptr(), w=wimg.data_ptr(), bias=bias.data_ptr(),
                      out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
-                     stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
+                     stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows, reserved=0 if self.dcn_patches else 0x1000)
             return out
         if self.pw.use_dcn and self.fuse_offsets:
             wp, bp, cout, cin, k, rows = self.pw.conv(p + ".conv.weight", p + ".conv.bias", p + ".actf.0", as_half=True)

@@ -203,10 +203,14 @@ def test_stream_split_matches_single_stream():
         assert torch.equal(one[k], two[k]), k
 
 
-def _ab(m, xs, flag):
-    """heads with engine flag `flag` on (default) and off, plans rebuilt in between."""
+def _ab(m, xs, flag, **first):
+    """heads with engine flag `flag` on and off, plans rebuilt in between; `first`: flags to set before (e.g. the
+    csrc/dcn4.hip path is off by default since round 2)."""
     eng = m.engine(xs.device)
-    assert getattr(eng, flag)
+    for k, v in first.items():
+        setattr(eng, k, v)
+    setattr(eng, flag, True)
+    eng.plans.clear()
     on = {k: v.clone() for k, v in m(xs)[0].items()}
     setattr(eng, flag, False)
     eng.plans.clear()
@@ -242,7 +246,7 @@ def test_streamed_dcn_matches_dcn3(offset_scale, tol):
     on, off = _ab(m, xs, "stream_dcn")
     from h3d_amd import _lib
     kinds = [op.kind for op in m.engine(xs.device).plan(2, 96, 160).ops]
-    assert _lib.OP_UPDCN_F16 in kinds           # (dcn4 with the up-sample + add folded in: the default)
+    assert _lib.OP_UPDCN_F16 in kinds           # (dcn4 with the up-sample + add folded in)
     with torch.no_grad():
         ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(xs.cpu())[0]
     for k in HEADS:
@@ -266,6 +270,7 @@ def test_dcn4_two_workgroups_per_cu_matches_one(offset_scale):
     m = m.to(DEV).eval()
     xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=31)).to(DEV)
     m.engine(xs.device).fuse_upnode = False     # the one-workgroup variant exists for the fp16-input op only
+    m.engine(xs.device).stream_dcn = True       # csrc/dcn4.hip is an option since round 2, not the default
     dense = {k: v.clone() for k, v in m(xs)[0].items()}
     plan = m.engine(xs.device).plan(2, 96, 160)
     idx = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_DCN_FUSED_F16]
@@ -294,7 +299,7 @@ def test_fused_upsample_node_is_bit_identical(offset_scale):
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to(DEV).eval()
     xs = torch.from_numpy(synth.synth_images(3, 96, 160, seed=43)).to(DEV)
-    on, off = _ab(m, xs, "fuse_upnode")
+    on, off = _ab(m, xs, "fuse_upnode", stream_dcn=True)
     kinds = [op.kind for op in m.engine(xs.device).plan(3, 96, 160).ops]
     assert _lib.OP_UPDCN_F16 in kinds and _lib.OP_DCN_FUSED_F16 not in kinds
     for k in HEADS:
@@ -311,7 +316,6 @@ def test_dma_filter_dcn3_matches_register_staged(offset_scale, tol):
     m = m.to(DEV).eval()
     xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=31)).to(DEV)
     eng = m.engine(xs.device)
-    eng.stream_dcn3 = True            # off by default (no speed-up measured above 64 output channels); _ab leaves it on
     eng.dense_dcn3 = False            # so that "off" is the register-staged kernel on every layer
     eng.plans.clear()
     on, off = _ab(m, xs, "stream_dcn3")
@@ -334,7 +338,7 @@ def test_dense_dcn3_matches_register_staged(offset_scale, tol):
     m = m.to(DEV).eval()
     xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=41)).to(DEV)
     m.engine(xs.device).dense_dcn3_min_tiles = 0      # (the default engages it from 512 tiles per layer)
-    on, off = _ab(m, xs, "dense_dcn3")
+    on, off = _ab(m, xs, "dense_dcn3", stream_dcn3=False)
     kinds = [op.kind for op in m.engine(xs.device).plan(2, 96, 160).ops]
     assert _lib.OP_DCN_FUSED_STREAM in kinds and _lib.OP_DCN_FUSED in kinds
     with torch.no_grad():

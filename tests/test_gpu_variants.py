@@ -102,10 +102,16 @@ DCN_CASES = [
     ("fused", "bf16", 0, 1, 48, 32, 16, 16, 0.5),          # dcn3<bf16,1,16,2>
     ("fused", "f32", 0, 1, 64, 64, 20, 24, 3.0),           # parity mode
     ("fused", "f32", 0, 1, 32, 32, 16, 16, 12.0),
-    ("stream", "bf16", 0, 2, 128, 64, 24, 40, 0.5),        # dcn3<bf16,2,16,1,WDMA>: two workgroups per CU
-    ("stream", "bf16", 0, 1, 256, 64, 16, 32, 3.0),
-    ("stream", "bf16", 0, 1, 64, 32, 20, 20, 12.0),        # dcn3<bf16,1,16,1,WDMA>
-    ("stream", "bf16", 0, 1, 128, 128, 16, 32, 3.0),       # dcn3<bf16,4,16,2,WDMA>
+    ("stream", "bf16", 0, 2, 128, 64, 24, 40, 0.5),        # dcn3<bf16,2,16,2,WDMA,256>: two workgroups per CU, patch slots
+    ("stream", "bf16", 0, 1, 256, 64, 16, 32, 3.0),        #   ... 4-13 % of the samples in patches
+    ("stream", "bf16", 0, 2, 64, 64, 40, 24, 6.0),         #   ... more samples leave the apron than a tile has slots: patches AND pass 2
+    ("stream", "bf16", 0, 1, 64, 64, 16, 16, 40.0),        #   ... nearly every sample outside the apron or the image
+    ("stream", "bf16", 0, 1, 64, 32, 20, 20, 12.0),        # dcn3<bf16,1,16,2,WDMA,256>
+    ("stream", "bf16", 0, 1, 128, 128, 16, 32, 3.0),       # dcn3<bf16,4,16,4,WDMA,256>: margin-4 apron
+    ("stream", "bf16", 0, 1, 256, 256, 24, 24, 8.0),
+    ("stream", "bf16", 0x1000, 2, 128, 64, 24, 40, 0.5),   # round 1's configurations: dcn3<bf16,2,16,1,WDMA,0>
+    ("stream", "bf16", 0x1000, 1, 64, 32, 20, 20, 12.0),   # dcn3<bf16,1,16,1,WDMA,0>
+    ("stream", "bf16", 0x1000, 1, 128, 128, 16, 32, 3.0),  # dcn3<bf16,4,16,2,WDMA,0>
     ("f16", "bf16", 0, 2, 64, 64, 24, 40, 0.5),            # dcn4<2,.,1,0> DENSE
     ("f16", "bf16", 0, 1, 64, 64, 20, 20, 12.0),
     ("f16", "bf16", 0x100, 1, 64, 64, 24, 40, 3.0),        # dcn4<2,.,0,0> one workgroup per CU
@@ -163,7 +169,7 @@ def test_dcn_fused_variant_matches_oracle(case):
 
 def test_dcn_auto_selection_reaches_mt4():
     c = [c for c in DCN_CASES if c[3] == 12][0]
-    assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 4, 16, 2, 2, false>"
+    assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 4, 16, 2, 2, false, 0>"
 
 
 # ---- the bench plan's kernel set -----------------------------------------------------------------------------
