@@ -26,8 +26,16 @@ bool h3d_note_kernel(const char *fmt, ...);
 // tests they put every MFMA in its own basic block and wreck the schedule of the production kernel.
 #ifdef H3D_ABLATE
 #define H3D_DBG(a) ((a).dbg)
+// in-kernel phase stamps (profiling builds only): wave 0 of workgroup `wg` stores s_memtime at point `k`
+#define H3D_NSTAMP 8
+unsigned long long *h3d_stamp_buffer();     // device buffer [65536][H3D_NSTAMP] (ops.hip); kernels take it in their args
+#define H3D_STAMP(wg, k)                                                                                   \
+    do {                                                                                                   \
+        if (threadIdx.x == 0 && (wg) < 65536 && a.stamps) a.stamps[(wg) * H3D_NSTAMP + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
 #else
 #define H3D_DBG(a) 0
+#define H3D_STAMP(wg, k) do { } while (0)
 #endif
 #define H3D_FAIL(code, ...)        \
     do {                           \
@@ -168,6 +176,17 @@ __device__ __forceinline__ void stage_vectors(int tid, LD ld, ST st)
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// XCD-aware tile order.  Workgroup ids are dealt round robin to the 8 XCDs (id % 8), each with its own 4 MiB L2, so
+// with the plain order the four neighbours of a tile -- which share its halo / apron -- sit on four other dies and the
+// shared pixels are fetched into several L2s.  With mode 1 die x works on the contiguous id range [x * nb/8, (x+1) * nb/8).
+// (mode from the launcher: env H3D_XCD, read once; only when nb is a multiple of 8)
+int h3d_xcd_mode();
+__device__ __forceinline__ int h3d_tile_id(int bid, int nb, int mode)
+{
+    if (mode == 0 || (nb & 7)) return bid;
+    return (bid & 7) * (nb >> 3) + (bid >> 3);
+}
 
 // 16-byte NHWC channel vectors <-> fp32 (elementwise kernels, csrc/dcn4.hip's fused up-sample prologue)
 template <typename T>

@@ -28,6 +28,7 @@ struct Conv2Args {
     int Ho, Wo, Cout, out_cs, res_cs, relu, out_mode;
     int G, tiles_x, tiles_y;
     int dbg;   // ABLATE builds only (op.reserved >> 16): 1 = no DMA after stage 0, 2 = no fragment reads / MFMA
+    int xcd;   // h3d_tile_id mode
 };
 
 template <int MT, int WAVES, int S = 1, int SLOTS = 2, int NT = 1>
@@ -88,8 +89,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     const int l = tid & 63, r = l & 31, h = l >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform for the compiler too
     const int tiles = a.tiles_x * a.tiles_y;
-    const int b = blockIdx.x / tiles;
-    const int t = blockIdx.x - b * tiles;
+    const int bid = h3d_tile_id(blockIdx.x, gridDim.x, a.xcd);
+    const int b = bid / tiles;
+    const int t = bid - b * tiles;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int oy0 = ty * C::TH, ox0 = tx * 16;
     const int g0 = blockIdx.y * MT;                               // first 32-row group of this workgroup
@@ -191,6 +193,7 @@ static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
     Conv2Args a = a0;
     a.tiles_x = cdiv(a.Wo, 16);
     a.tiles_y = cdiv(a.Ho, C::TH);
+    a.xcd = h3d_xcd_mode();
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4)) ? 2 : lean ? 1 : 0;

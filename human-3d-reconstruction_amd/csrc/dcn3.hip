@@ -24,6 +24,7 @@
 #include "common.h"
 #include "epilogue.h"
 #include "dcn_traits.h"
+#include <type_traits>
 
 struct Dcn3Args {
     const char *in;
@@ -34,8 +35,10 @@ struct Dcn3Args {
     int B, H, W, Cin, in_cs;
     int Cout, out_cs, relu, out_mode, wrows;
     int tiles_x, tiles_y;
-    int dbg;   // profiling ablation (h3d_op.reserved): 1 no phase-A MFMA, 2 no gather/blend, 4 no phase-B MFMA, 8 stage once
+    int dbg;   // profiling ablation (h3d_op.reserved): 1 no phase-A MFMA, 2 no gather/blend, 4 no phase-B MFMA, 8 stage once, 16 no patch fill
     int G;     // WDMA: 32-row groups of the main filter image
+    int xcd;   // h3d_tile_id mode
+    unsigned long long *stamps;   // profiling builds: in-kernel phase stamps (common.h H3D_STAMP)
 };
 
 template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0>
@@ -104,8 +107,9 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
     const int tiles = a.tiles_x * a.tiles_y;
-    const int b = blockIdx.x / tiles;
-    const int t = blockIdx.x - b * tiles;
+    const int bid = h3d_tile_id(blockIdx.x, gridDim.x, a.xcd);
+    const int b = bid / tiles;
+    const int t = bid - b * tiles;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int oy0 = ty * 16, ox0 = tx * 16;
     const int hy0 = oy0 - 1 - MARGIN, hx0 = ox0 - 1 - MARGIN;
@@ -180,6 +184,48 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         }
     };
 
+    // ---- D2 (WDMA with patches): the apron loads run TWO stages ahead in phase A.  A stage of phase A is 9 MFMAs per
+    //      wave (~0.3k cycles), a global load takes 2-4k: one stage of distance (the pipeline above) left every stage
+    //      waiting for its apron (in-kernel stamps: phase A 26 % of a tile for 33 % of its MFMAs).  Two register sets,
+    //      stage s in set s & 1 (the loops are unrolled by two, so Cin % 32 == 0); loads are range-checked buffer loads
+    //      (outside the image: zeros, no branch), so every wave issues exactly NV of them per stage and the wait for the
+    //      filter DMA of stage s can be counted: only the NV loads of stage s+1 were issued after it.
+    constexpr bool D2 = WDMA && NP > 0 && sizeof(T) == 2;
+    [[maybe_unused]] int avoff[NV], adst[NV];
+    [[maybe_unused]] u32x4 stg2[D2 ? 2 : 1][NV];
+    if constexpr (D2) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * C::THREADS;
+            const int v = i % C::VPP, pix = i / C::VPP;
+            const int iy = pix / C::HH, ix = pix - iy * C::HH;
+            const int gy = hy0 + iy, gx = hx0 + ix;
+            avoff[j] = (i < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((gy * a.W + gx) * a.in_cs) * ES + v * 16 : 0x7ffffff0;
+            adst[j] = i < NH ? iy * C::RBH + ix * C::SBH + v * 16 : -1;
+        }
+    }
+    [[maybe_unused]] const int img_bytes = (int)((size_t)a.H * a.W * a.in_cs * ES);
+    auto load2 = [&](int s, auto P) {
+        if constexpr (D2) {
+            constexpr int q = decltype(P)::value;
+            const int c0 = (s < nchunks ? s : s - nchunks) * CK;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) stg2[q][j] = dcn3_patch_corner(img, img_bytes, avoff[j], c0 * ES);
+        }
+    };
+    auto store2 = [&](auto P) {
+        if constexpr (D2) {
+            constexpr int q = decltype(P)::value;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if (adst[j] >= 0) *reinterpret_cast<u32x4 *>(smem + C::PB + adst[j]) = X::convert16(stg2[q][j]);
+        }
+    };
+    [[maybe_unused]] constexpr std::integral_constant<int, 0> I0{};
+    [[maybe_unused]] constexpr std::integral_constant<int, 1> I1{};
+    [[maybe_unused]] constexpr int WAIT_NV = 0x0f70 | (NV & 15) | ((NV >> 4) << 14);     // s_waitcnt vmcnt(NV)
+
+    H3D_STAMP(blockIdx.x, 6);
     if constexpr (NP > 0) {
         // every byte a zero-weighted corner read of a patched sample can touch must hold a finite number (0 x NaN = NaN):
         // the patch area and the apron are cleared once (pad slots and row tails are never written afterwards; the filter
@@ -188,20 +234,13 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         if (tid == 0) *reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16) = 0;
         __syncthreads();                       // ... and before stage 0's apron is stored
     }
+    H3D_STAMP(blockIdx.x, 0);
     // ================= phase A: offsets/mask = conv3x3(x; 27 filters) ===============================
     f32x16 aoffs;   // rows (i&3)+8(i>>2)+4h of the permuted offset conv for this lane's pixel
 #pragma unroll
     for (int i = 0; i < 16; ++i) aoffs[i] = 0.f;
     const int bconv = (MARGIN + py) * C::RBH + (MARGIN + px) * C::SBH + 8 * h * SS;   // tap (0,0) of the plain conv
-    issue_w(0);
-    load_stage(0);
-    for (int s = 0; s < nchunks; ++s) {
-        if (WDMA && s) __syncthreads();          // (single apron buffer)
-        store_stage(s);
-        if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // the filters of stage s have landed too
-        __syncthreads();
-        issue_w(s + 1);
-        load_stage(s + 1);                       // s + 1 == nchunks is phase B's first stage
+    auto computeA = [&](int s) {
         const char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
@@ -214,6 +253,33 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                 if (H3D_DBG(a) & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, fb);
             }
         }
+    };
+    if constexpr (D2) {
+        issue_w(0);
+        load2(0, I0);
+        load2(1, I1);                            // (nchunks is even: stage 1 exists)
+        auto stepA = [&](int s, auto P) {
+            if (s) __syncthreads();              // (single apron buffer)
+            store2(P);
+            __builtin_amdgcn_s_waitcnt(WAIT_NV); // the filters of stage s have landed; the apron of stage s+1 may still fly
+            __syncthreads();
+            issue_w(s + 1);
+            load2(s + 2, P);                     // s + 2 < 2 nchunks: phase B's first two stages are fetched here too
+            computeA(s);
+        };
+        for (int s = 0; s < nchunks; s += 2) { stepA(s, I0); stepA(s + 1, I1); }
+    } else {
+    issue_w(0);
+    load_stage(0);
+    for (int s = 0; s < nchunks; ++s) {
+        if (WDMA && s) __syncthreads();          // (single apron buffer)
+        store_stage(s);
+        if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // the filters of stage s have landed too
+        __syncthreads();
+        issue_w(s + 1);
+        load_stage(s + 1);                       // s + 1 == nchunks is phase B's first stage
+        computeA(s);
+    }
     }
     {   // + bias (permuted like the rows)
         const float *bo = a.bias + a.wrows;
@@ -221,6 +287,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
     }
 
+    H3D_STAMP(blockIdx.x, 1);
     // ================= geometry: my taps (h=0: 0..4, h=1: 5..8), then cross-half exchange ===========
     int boff[9];
     typename X::geo geo[9];
@@ -301,7 +368,6 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     [[maybe_unused]] int pvoff[4] = {0x7ffffff0, 0x7ffffff0, 0x7ffffff0, 0x7ffffff0};
     [[maybe_unused]] typename X::geo pgeo = X::zero_geo();
     [[maybe_unused]] bool phas = false;
-    [[maybe_unused]] const int img_bytes = (int)((size_t)a.H * a.W * a.in_cs * ES);
     if constexpr (NP > 0) {
         __syncthreads();                                                 // the list is complete
         const int nsl = min(*reinterpret_cast<const int *>(smem + C::LDS_MAIN + NP * 16), NP);
@@ -323,6 +389,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     [[maybe_unused]] u32x4 pst[4];
     auto patch_issue = [&](int s) {
         if constexpr (NP > 0 && sizeof(T) == 2) {
+            if (H3D_DBG(a) & 16) return;
             const int c0 = (s - nchunks) * CK;
 #pragma unroll
             for (int k = 0; k < 4; ++k) pst[k] = dcn3_patch_corner(img, img_bytes, pvoff[k], c0 * ES);   // idle threads: out of range, zeros
@@ -330,7 +397,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     };
     auto patch_commit = [&](char *s_h) {
         if constexpr (NP > 0 && sizeof(T) == 2) {
-            if (!phas) return;
+            if (!phas || (H3D_DBG(a) & 16)) return;
             typename X::frag v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k].v = __builtin_bit_cast(half8_t, X::convert16(pst[k]));
@@ -339,20 +406,14 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         }
     };
 
+    H3D_STAMP(blockIdx.x, 2);
     // ================= phase B: deformable contraction (branch-free, apron samples) ==================
     f32x16 acc[MT][1];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
-    for (int s = nchunks; s < 2 * nchunks; ++s) {
-        patch_issue(s);
-        if (WDMA) __syncthreads();
-        store_stage(s);
-        patch_commit(smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE));
-        if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        if (s + 1 < 2 * nchunks) { issue_w(s + 1); load_stage(s + 1); }
+    auto computeB = [&](int s) {
         const char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
@@ -383,8 +444,37 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                 for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb[kk]);
             }
         }
+    };
+    if constexpr (D2) {
+        // one stage of distance from here on (the accumulators are live now); stage nchunks+1 is already in flight
+        auto stepB = [&](int s, auto P, auto Q) {
+            patch_issue(s);
+            __syncthreads();
+            store2(P);
+            patch_commit(smem + C::PB);
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // (the patch loads were the youngest: nothing older is pending either)
+            __syncthreads();
+            if (s + 1 < 2 * nchunks) {
+                issue_w(s + 1);
+                if (s != nchunks) load2(s + 1, Q);
+            }
+            computeB(s);
+        };
+        for (int s = nchunks; s < 2 * nchunks; s += 2) { stepB(s, I0, I1); stepB(s + 1, I1, I0); }
+    } else {
+    for (int s = nchunks; s < 2 * nchunks; ++s) {
+        patch_issue(s);
+        if (WDMA) __syncthreads();
+        store_stage(s);
+        patch_commit(smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE));
+        if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (s + 1 < 2 * nchunks) { issue_w(s + 1); load_stage(s + 1); }
+        computeB(s);
+    }
     }
 
+    H3D_STAMP(blockIdx.x, 3);
     // ================= pass 2 (rare): samples whose corners left the apron ===========================
     if (__syncthreads_or(slow ? 1 : 0)) {
         for (int c0 = 0; c0 < a.Cin; c0 += CK) {
@@ -449,6 +539,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         }
     }
 
+    H3D_STAMP(blockIdx.x, 4);
     EpiArgs e;
     e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
@@ -458,6 +549,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     } else {
         tile_epilogue<T, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }
+    H3D_STAMP(blockIdx.x, 5);
 }
 
 template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0>
@@ -468,6 +560,12 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     Dcn3Args a = a0;
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, 16);
+    a.xcd = h3d_xcd_mode();
+#ifdef H3D_ABLATE
+    a.stamps = h3d_stamp_buffer();
+#else
+    a.stamps = nullptr;
+#endif
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (sizeof(T) == 2 && MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
@@ -516,7 +614,9 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.G = op.wrows / 32;
     if (wdma) {
         if ((size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
-        if (op.reserved & 0x1000) {     // tuning override: round 1's configurations (no patches: every sample that leaves the apron goes through pass 2)
+        if ((op.reserved & 0x1000) || op.Cin % 32) {     // tuning override: round 1's configurations (no patches: every sample that
+                                                         // leaves the apron goes through pass 2); also Cin = 16 (mod 32): the
+                                                         // patch variants' pipeline is unrolled by two stages
             if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 1, true>(a, st);
             if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 1, true>(a, st);
             return launch_dcn3_cfg<bf16_t, 4, 16, 2, true>(a, st);

@@ -574,7 +574,7 @@ extern "C" int h3d_multi_pose_post_process(const float *dets, const float *c, co
                                            int out_h, int out_w, float *out, void *stream)
 {
     if (!dets || !c || !s || !out) H3D_FAIL(H3D_ERR_ARG, "post_process: null pointer");
-    if (B <= 0 || K <= 0 || J <= 0 || out_h <= 0 || out_w <= 0) H3D_FAIL(H3D_ERR_SHAPE, "post_process: bad shape");
+    if (B <= 0 || K <= 0 || J < 0 || out_h <= 0 || out_w <= 0) H3D_FAIL(H3D_ERR_SHAPE, "post_process: bad shape");
     const int total = B * K;
     hipLaunchKernelGGL(post_process_kernel, dim3(cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream, dets, c, s, K, J,
                        out_h, out_w, total, out);

@@ -41,6 +41,7 @@ struct HeadsArgs {
     int B, H, W, in_cs;
     int tiles_x, tiles_y;
     int dbg;   // profiling ablation (h3d_op.reserved): 1 = skip the weight loads after the prologue
+    int xcd;   // h3d_tile_id mode
 };
 
 template <typename T, int TH>
@@ -184,8 +185,9 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63, r = l & 31, h = l >> 5;
     const int tiles = a.tiles_x * a.tiles_y;
-    const int b = blockIdx.x / tiles;
-    const int t = blockIdx.x - b * tiles;
+    const int bid = h3d_tile_id(blockIdx.x, gridDim.x, a.xcd);
+    const int b = bid / tiles;
+    const int t = bid - b * tiles;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
     const int oy0 = ty * TH, ox0 = tx * C::TW;
     const int slabs = a.head_conv / HC_SLAB;
@@ -426,6 +428,7 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
     HeadsArgs a;
     a.in = (const char *)op.in; a.w1 = (const char *)op.w; a.b1 = op.bias;
     a.dbg = op.reserved & 0xff;
+    a.xcd = h3d_xcd_mode();
     a.nheads = d->nheads; a.head_conv = op.Cout; a.B = op.B; a.H = op.H; a.W = op.W; a.in_cs = op.in_cs;
     for (int i = 0; i < d->nheads; ++i) {
         if (!d->head[i].w2 || !d->head[i].b2 || !d->head[i].out) H3D_FAIL(H3D_ERR_ARG, "heads: head %d null pointer", i);

@@ -24,6 +24,25 @@ bool h3d_note_kernel(const char *fmt, ...)
     return g_dry;
 }
 
+#ifdef H3D_ABLATE
+unsigned long long *h3d_stamp_buffer()
+{
+    static unsigned long long *buf = [] { void *p = nullptr; (void)hipMalloc(&p, sizeof(unsigned long long) * 65536 * H3D_NSTAMP); return (unsigned long long *)p; }();
+    return buf;
+}
+// profiling builds only (not declared in include/h3d.h): copy the phase stamps of the last launch to the host
+extern "C" int h3d_debug_stamps(unsigned long long *dst, int n)
+{
+    return hipMemcpy(dst, h3d_stamp_buffer(), sizeof(unsigned long long) * n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
+int h3d_xcd_mode()
+{
+    static const int mode = [] { const char *e = getenv("H3D_XCD"); return e ? atoi(e) : 1; }();   // on unless H3D_XCD=0
+    return mode;
+}
+
 extern "C" const char *h3d_last_error(void) { return g_err; }
 extern "C" int h3d_abi_version(void) { return H3D_ABI_VERSION; }
 

@@ -17,6 +17,7 @@ from .model import dla_net
 from .utils import _transpose_and_gather_feat
 
 MULTI_POSE_HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}   # opts.py:248-258
+CTDET_HEADS = {"hm": 80, "wh": 2, "reg": 2}                                                  # opts.py:241-247
 SMPL_HEADS = {"pose": 72, "shape": 10}
 
 
@@ -40,15 +41,25 @@ class Opt:
         for k, v in kw.items():
             setattr(self, k, v)
         self.output_h, self.output_w = self.input_h // self.down_ratio, self.input_w // self.down_ratio
-        heads = {"hm": 1, "wh": 2, "hps": 34}
-        if self.reg_offset:
-            heads["reg"] = 2
-        if self.hm_hp:
-            heads["hm_hp"] = 17
-        if self.reg_hp_offset:
-            heads["hp_offset"] = 2
-        if self.smpl:
-            heads.update(SMPL_HEADS)
+        if self.task == "ctdet":                               # opts.py:241-247
+            self.num_classes = getattr(self, "num_classes", 80)
+            self.cat_spec_wh = getattr(self, "cat_spec_wh", False)
+            heads = {"hm": self.num_classes, "wh": 2 if not self.cat_spec_wh else 2 * self.num_classes}
+            if self.reg_offset:
+                heads["reg"] = 2
+        elif self.task == "multi_pose":                        # opts.py:248-258
+            self.num_classes = 1
+            heads = {"hm": 1, "wh": 2, "hps": 34}
+            if self.reg_offset:
+                heads["reg"] = 2
+            if self.hm_hp:
+                heads["hm_hp"] = 17
+            if self.reg_hp_offset:
+                heads["hp_offset"] = 2
+            if self.smpl:
+                heads.update(SMPL_HEADS)
+        else:
+            raise ValueError("task not defined!")              # opts.py:260
         self.heads = heads
 
 
@@ -90,6 +101,72 @@ class MultiPoseDetector:
             res["results"] = multi_pose_post_process(dets, meta["c"], meta["s"], out["hm"].shape[2],
                                                      out["hm"].shape[3])
         return res
+
+
+class CtdetDetector:
+    """The `ctdet` branch of the reference's task dispatch (trains/trainer.py:444-455): model -> `_sigmoid(hm)`
+    (loss-module side effect, trainer.py:93) -> `ctdet_decode(hm, wh, reg, cat_spec_wh, K)` [B,K,6] -> optional
+    `ctdet_post_process` (utils/post_process.py:24-38).  Same engine, kernels and factory as the multi_pose detector;
+    only the head table and the assemble step differ."""
+
+    def __init__(self, opt, state_dict=None, device="cuda"):
+        if opt.task != "ctdet":
+            raise ValueError("task not defined!")
+        self.opt = opt
+        self.device = torch.device(device)
+        self.model = dla_net(opt.heads, 34, opt.head_conv, opt.down_ratio, opt.not_use_dcn, dtype=opt.dtype)
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict, strict=True)
+        self.model.to(self.device).eval()
+
+    @torch.no_grad()
+    def run(self, images, meta=None):
+        """images [B,3,H,W] fp32 on the device -> dict(dets [B,K,6] = box, score, class; heads; optional results =
+        the reference's per-image {class id (1-based): [[x1, y1, x2, y2, score], ...]} when meta={'c','s'})."""
+        from .utils import _sigmoid
+        opt = self.opt
+        out = self.model(images)[0]
+        hm = _sigmoid(out["hm"].clone())
+        dets = decode.ctdet_decode(hm, out["wh"], reg=out.get("reg") if opt.reg_offset else None,
+                                   cat_spec_wh=opt.cat_spec_wh, K=opt.K)
+        res = {"dets": dets, "heads": out}
+        if meta is not None:
+            res["results"] = ctdet_post_process(dets, meta["c"], meta["s"], out["hm"].shape[2], out["hm"].shape[3],
+                                                out["hm"].shape[1])
+        return res
+
+
+def make_detector(opt, state_dict=None, device="cuda", **kw):
+    """Task plugin dispatch by string, as the reference (`opt.task`, trains/trainer.py:331-342, 444-472)."""
+    if opt.task == "multi_pose":
+        return MultiPoseDetector(opt, state_dict, device=device, **kw)
+    if opt.task == "ctdet":
+        return CtdetDetector(opt, state_dict, device=device)
+    raise ValueError("task not defined!")
+
+
+def ctdet_post_process(dets, c, s, h, w, num_classes):
+    """reference utils/post_process.py:24-38: dets [B,K,6] (output-res px) -> per image {1-based class id:
+    [[x1, y1, x2, y2, score], ...]} in original-image pixels.  The affine map runs on the device
+    (h3d_multi_pose_post_process with J = 0); the per-class grouping is the reference's host-side dict."""
+    _lib.require_cuda(dets)
+    dets = dets.contiguous().float()
+    B, K, D = dets.shape
+    if D != 6:
+        raise RuntimeError("ctdet_post_process: dets [B,K,6] expected, got %s" % (tuple(dets.shape),))
+    c = torch.as_tensor(c, dtype=torch.float32, device=dets.device).contiguous().view(B, 2)
+    s = torch.as_tensor(s, dtype=torch.float32, device=dets.device).contiguous().view(-1)
+    if s.numel() == 2 * B:
+        s = s.view(B, 2)[:, 0].contiguous()
+    out = torch.empty(B, K, 5, dtype=torch.float32, device=dets.device)
+    _lib.check(_lib.lib().h3d_multi_pose_post_process(_lib.ptr(dets), _lib.ptr(c), _lib.ptr(s), B, K, 0, int(h), int(w),
+                                                      _lib.ptr(out), _lib.stream_ptr()), "ctdet_post_process")
+    boxes = out.cpu().numpy()
+    classes = dets[:, :, 5].cpu().numpy()
+    ret = []
+    for i in range(B):
+        ret.append({j + 1: boxes[i, classes[i] == j].tolist() for j in range(num_classes)})
+    return ret
 
 
 def run_frames(detector, frames):

@@ -233,7 +233,8 @@ int h3d_preprocess(const uint8_t *images, int B, int h, int w, int row_bytes, co
                    const float *mean, const float *stdv, int res_h, int res_w, float *out, void *stream);
 
 /* multi_pose_post_process (utils/post_process.py:41-52 + utils/image.py:19-68, inv affine with
- * rot = 0): dets [B,K,40] (output-res px) + c [B,2], s [B] -> out [B,K,39] image px. */
+ * rot = 0): dets [B,K,40] (output-res px) + c [B,2], s [B] -> out [B,K,39] image px.
+ * J = 0 is the transform of ctdet_post_process (utils/post_process.py:24-38): dets [B,K,6] -> out [B,K,5] (box, score). */
 int h3d_multi_pose_post_process(const float *dets, const float *c, const float *s, int B, int K,
                                 int J, int out_h, int out_w, float *out, void *stream);
 

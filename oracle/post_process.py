@@ -64,3 +64,20 @@ def multi_pose_post_process(dets, c, s, h, w):
         out.append(np.concatenate([bbox.reshape(-1, 4), dets[i, :, 4:5], pts.reshape(-1, 34)],
                                   axis=1).astype(np.float32))
     return out
+
+
+def ctdet_post_process(dets, c, s, h, w, num_classes):
+    """utils/post_process.py:24-38: dets [B,K,6] -> per image {1-based class id: [[x1,y1,x2,y2,score], ...]}."""
+    dets = np.array(dets, dtype=np.float32, copy=True)
+    ret = []
+    for i in range(dets.shape[0]):
+        top = {}
+        p0 = transform_preds(dets[i, :, 0:2], c[i], s[i], (w, h))
+        p1 = transform_preds(dets[i, :, 2:4], c[i], s[i], (w, h))
+        box = np.concatenate([p0, p1], axis=1).astype(np.float32)
+        classes = dets[i, :, -1]
+        for j in range(num_classes):
+            inds = classes == j
+            top[j + 1] = np.concatenate([box[inds], dets[i, inds, 4:5].astype(np.float32)], axis=1).tolist()
+        ret.append(top)
+    return ret

@@ -170,3 +170,39 @@ def test_full_size_batch_properties():
     ref = odec.multi_pose_decode(h["hm"][:2], h["wh"][:2], h["hps"][:2], h["reg"][:2], h["hm_hp"][:2],
                                  h["hp_offset"][:2], K=100)
     np.testing.assert_array_equal(dets[:2].cpu().numpy(), ref)
+
+
+def test_ctdet_task_entry_end_to_end():
+    # the `ctdet` branch of the task dispatch (trains/trainer.py:444-455): heads of opts.py:241-247 through the same
+    # engine, `_sigmoid` + ctdet_decode bit-exact against the oracle on the GPU's own heads, ctdet_post_process
+    # (utils/post_process.py:24-38) against its restatement
+    from h3d_amd import arch
+    from h3d_amd.detector import CtdetDetector, MultiPoseDetector, Opt, ctdet_post_process, make_detector
+    opt = Opt(task="ctdet", input_h=128, input_w=160, dtype="f32", K=40, num_classes=80)
+    assert opt.heads == {"hm": 80, "wh": 2, "reg": 2}
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=1.25)
+    det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    assert isinstance(det, CtdetDetector)
+    assert isinstance(make_detector(Opt(task="multi_pose"), device=DEV), MultiPoseDetector)
+    with pytest.raises(ValueError, match="task not defined"):
+        Opt(task="ddd")
+    xs = torch.from_numpy(synth.synth_images(2, 128, 160, seed=5)).to(DEV)
+    c = np.array([[80.0, 64.0], [100.5, 70.25]], np.float32)
+    s = np.array([160.0, 300.0], np.float32)
+    res = det.run(xs, meta={"c": c, "s": s})
+    heads = {k: v.cpu().numpy() for k, v in res["heads"].items()}
+    # (the device's expf and numpy's differ by an ulp on some scores: decode the GPU's own _sigmoid output, whose parity
+    #  with the reference's is pinned by the golden sigmoid.npz in test_sigmoid_and_gather)
+    ref = odec.ctdet_decode(utils._sigmoid(res["heads"]["hm"].clone()).cpu().numpy(), heads["wh"], heads["reg"], K=40)
+    np.testing.assert_array_equal(res["dets"].cpu().numpy(), ref)
+    exp = opost.ctdet_post_process(ref, c, s, 32, 40, 80)
+    got = res["results"]
+    assert len(got) == 2 and set(got[0]) == set(range(1, 81))
+    for i in range(2):
+        for k in range(1, 81):
+            assert len(got[i][k]) == len(exp[i][k])
+            if exp[i][k]:
+                np.testing.assert_allclose(np.array(got[i][k]), np.array(exp[i][k]), rtol=1e-5, atol=2e-3)
+    assert sum(len(v) for v in got[0].values()) == 40
+    again = ctdet_post_process(res["dets"], c, s, 32, 40, 80)
+    assert again == got

@@ -109,6 +109,7 @@ DCN_CASES = [
     ("stream", "bf16", 0, 1, 64, 32, 20, 20, 12.0),        # dcn3<bf16,1,16,2,WDMA,256>
     ("stream", "bf16", 0, 1, 128, 128, 16, 32, 3.0),       # dcn3<bf16,4,16,4,WDMA,256>: margin-4 apron
     ("stream", "bf16", 0, 1, 256, 256, 24, 24, 8.0),
+    ("stream", "bf16", 0, 1, 48, 64, 20, 20, 3.0),         # Cin = 16 (mod 32): falls back to the configuration without patches
     ("stream", "bf16", 0x1000, 2, 128, 64, 24, 40, 0.5),   # round 1's configurations: dcn3<bf16,2,16,1,WDMA,0>
     ("stream", "bf16", 0x1000, 1, 64, 32, 20, 20, 12.0),   # dcn3<bf16,1,16,1,WDMA,0>
     ("stream", "bf16", 0x1000, 1, 128, 128, 16, 32, 3.0),  # dcn3<bf16,4,16,2,WDMA,0>

@@ -74,3 +74,20 @@ def test_post_process_is_scale_and_shift_for_centred_crop():
     np.testing.assert_allclose(out[:, 4], dets[0, :, 4])
     exp_pts = (dets[0, :, 5:39].reshape(-1, 2) - 64.0) * 5.0 + c[0]
     np.testing.assert_allclose(out[:, 5:], exp_pts.reshape(-1, 34), rtol=1e-5, atol=1e-3)
+
+
+def test_ctdet_post_process_groups_by_class_and_is_scale_and_shift():
+    # utils/post_process.py:24-38: box corners through the inverse crop affine, grouped per 1-based class id
+    rng = np.random.default_rng(3)
+    dets = np.zeros((2, 6, 6), np.float32)
+    dets[:, :, :4] = rng.uniform(0, 128, (2, 6, 4))
+    dets[:, :, 4] = rng.uniform(0, 1, (2, 6))
+    dets[:, :, 5] = np.array([[0, 2, 2, 1, 0, 2], [1, 1, 1, 1, 1, 1]], np.float32)
+    c = np.array([[256.0, 256.0], [300.0, 200.0]], np.float32)
+    s = np.array([512.0, 640.0], np.float32)
+    out = opost.ctdet_post_process(dets, c, s, 128, 128, 3)
+    assert [len(out[0][k]) for k in (1, 2, 3)] == [2, 1, 3] and [len(out[1][k]) for k in (1, 2, 3)] == [0, 6, 0]
+    row = np.array(out[0][2][0])                               # image 0, class id 2 = detection 3
+    exp = (dets[0, 3, :4] - 64.0) * (512.0 / 128.0) + 256.0
+    np.testing.assert_allclose(row[:4], exp, rtol=1e-6, atol=1e-3)
+    assert abs(row[4] - dets[0, 3, 4]) < 1e-7

@@ -7,7 +7,7 @@ from h3d_amd.detector import MultiPoseDetector, Opt
 from bench import kernel_name, op_flops
 dev = torch.device("cuda:0")
 opt = Opt(input_h=512, input_w=512, smpl=True, dtype="bf16")
-sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0)
+sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=float(sys.argv[3]) if len(sys.argv) > 3 else 1.25)
 det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 x = torch.from_numpy(synth.synth_images(1, 512, 512)).to(dev).expand(B, 3, 512, 512).contiguous()
@@ -15,9 +15,9 @@ det.run(x); torch.cuda.synchronize()
 plan = det.model.engine(dev).plan(B, 512, 512)
 n = len(plan.ops)
 ms = (ctypes.c_float * n)()
-KIND = {'dcn': _lib.OP_DCN, 'heads': _lib.OP_HEADS, 'dcnf': _lib.OP_DCN_FUSED, 'dcn4': _lib.OP_DCN_FUSED_F16, 'updcn': _lib.OP_UPDCN_F16}[sys.argv[2] if len(sys.argv) > 2 else 'dcn']
+KIND = {'dcn': _lib.OP_DCN, 'heads': _lib.OP_HEADS, 'dcnf': _lib.OP_DCN_FUSED, 'dcns': _lib.OP_DCN_FUSED_STREAM, 'dcn4': _lib.OP_DCN_FUSED_F16, 'updcn': _lib.OP_UPDCN_F16}[sys.argv[2] if len(sys.argv) > 2 else 'dcn']
 idx = [i for i, op in enumerate(plan.ops) if op.kind == KIND]
-for dbg in ((0, 1) if KIND == _lib.OP_HEADS else (0, 1, 2, 3, 4) if KIND == _lib.OP_UPDCN_F16 else (0, 0x100, 1, 2, 3, 4, 0x101, 0x102, 0x103, 0x104) if KIND == _lib.OP_DCN_FUSED_F16 else (0, 1, 2, 4, 6, 7, 8, 15)):
+for dbg in ((0, 1) if KIND == _lib.OP_HEADS else (0, 1, 2, 3, 4) if KIND == _lib.OP_UPDCN_F16 else (0, 0x100, 1, 2, 3, 4, 0x101, 0x102, 0x103, 0x104) if KIND == _lib.OP_DCN_FUSED_F16 else (0, 1, 2, 4, 6, 7, 8, 15, 16, 31)):
     for i in idx:
         plan.op_array[i].reserved = dbg
     tot = np.zeros(n)
