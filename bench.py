@@ -180,6 +180,43 @@ def dcn_pass2_fraction(det, images2, dev):
             "mean_abs_offset_px": round(float(np.mean(mean_abs)), 3)}
 
 
+def boundary_op_times(batch, dev):
+    """The literal drop-in operator (`_ext.dcn_v2_forward`, DCNv2/src/dcn_v2.h:9-23 -> h3d_dcn_v2_forward_ws) on the 16
+    DeformConv shapes of the network at this batch: NCHW fp32 operands in, NCHW fp32 out, HIP events on the
+    current stream around the call (layout conversion inside the workspace included).  Not part of the timed step: the
+    engine path never materialises offsets or NCHW tensors."""
+    from h3d_amd import dcn_v2
+    res = {}
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for prefix, o, ins, ups in arch.ida_specs():
+        lvl = {"dla_up.ida_0": 32, "dla_up.ida_1": 64, "dla_up.ida_2": 128, "ida_up": 128}[prefix]     # output side at 512 x 512
+        for k, (ci, f) in enumerate(zip(ins, ups), start=1):
+            for name, cin, hw in (("proj_%d" % k, ci, lvl // f), ("node_%d" % k, o, lvl)):
+                key = "%dx%d@%d" % (cin, o, hw)
+                if key in res:
+                    res[key]["n"] += 1
+                    continue
+                x = torch.randn(batch, cin, hw, hw, generator=g).to(dev)
+                w = (torch.randn(o, cin, 3, 3, generator=g) * (1.0 / (3 * cin ** 0.5))).to(dev)
+                b = torch.zeros(o, device=dev)
+                off = (torch.randn(batch, 18, hw, hw, generator=g) * 1.5).to(dev)
+                m = torch.rand(batch, 9, hw, hw, generator=g).to(dev)
+                for _ in range(2):
+                    dcn_v2.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    dcn_v2.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 3
+                res[key] = {"n": 1, "ms": round(ms, 3), "tflops": round(2.0 * batch * hw * hw * o * cin * 9 / ms / 1e9, 1)}
+                del x, w, off, m
+    tot = sum(v["ms"] * v["n"] for v in res.values())
+    return {"dtype": "f32 (v_mfma_f32_32x32x2_f32, peak 157 TFLOP/s)", "batch": batch, "layers": sum(v["n"] for v in res.values()),
+            "total_ms": round(tot, 3), "shapes": res}
+
+
 def _free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
         so.bind(("127.0.0.1", 0))
@@ -381,6 +418,9 @@ def main():
                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             print("[bench] kernels %s" % json.dumps(line["kernels"]), file=sys.stderr, flush=True)
             line["dcn_pass2"] = dcn_pass2_fraction(det, images[:2].contiguous(), dev)
+            if world == 1:
+                line["boundary_op"] = boundary_op_times(min(args.batch, 16), dev)
+                print("[bench] boundary_op %s" % json.dumps(line["boundary_op"]), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
             keep = {}
             line["cpu_baseline"] = cpu_baseline(opt, sd, keep=keep)

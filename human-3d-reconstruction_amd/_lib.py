@@ -51,6 +51,7 @@ class H3dUpdcnDesc(ctypes.Structure):
 # name -> argtypes (restype is int unless noted); also the export list the CPU test checks
 SIGNATURES = {
     "h3d_dcn_v2_forward": [c_vp] * 6 + [c_i] * 14 + [c_vp],
+    "h3d_dcn_v2_forward_ws": [c_vp] * 6 + [c_i] * 14 + [c_vp, ctypes.c_size_t, c_vp],
     "h3d_dcn_fused_ck": [c_i, c_i],
     "h3d_smpl_coef_pack": [c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "h3d_smpl_verts3": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],
@@ -101,6 +102,8 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the export is missing
             fn.argtypes = args
             fn.restype = c_i
+        L.h3d_dcn_v2_workspace_bytes.argtypes = [c_i] * 5
+        L.h3d_dcn_v2_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

@@ -347,3 +347,89 @@ extern "C" int h3d_dcn_v2_forward(const float *input, const float *weight, const
     H3D_CHECK_LAUNCH("dcn_nchw_kernel");
     return H3D_OK;
 }
+
+
+// ================================================================================================
+// Operator boundary, fast path for the configuration the model uses (model.py:355: 3x3, stride 1, pad 1, dilation 1,
+// deformable_group 1) when C % 16 == 0: the reference's operands (NCHW fp32, separate offset / mask tensors, OIHW
+// weights) are re-laid once into the network kernels' layout inside a caller-provided workspace -- input -> NHWC,
+// (offset | mask) -> [B,H,W,32], weights -> [rows][9][C] -- and the contraction runs on csrc/dcn2.hip's fp32 kernel
+// (LDS apron gather, sampling geometry once per pixel instead of once per pixel AND channel as
+// dcn_v2_im2col_cuda.cu:170-172 does, exact fmaf chains on v_mfma_f32_32x32x2_f32), which writes the NCHW output itself.
+int h3d_launch_dcn2(const h3d_op &op, hipStream_t st);
+
+__global__ void dcn_om_pack_kernel(const float *__restrict__ off, const float *__restrict__ mask, float *__restrict__ om, int HW, size_t total)
+{
+    // thread = pixel: 27 coalesced channel reads (consecutive threads = consecutive pixels), one 128-byte row written
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t b = i / HW, n = i - b * HW;
+    f32x4 row[8];
+#pragma unroll
+    for (int c = 0; c < 18; ++c) row[c >> 2][c & 3] = off[(b * 18 + c) * HW + n];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) row[(18 + c) >> 2][(18 + c) & 3] = mask[(b * 9 + c) * HW + n];
+#pragma unroll
+    for (int c = 27; c < 32; ++c) row[c >> 2][c & 3] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) reinterpret_cast<f32x4 *>(om + i * 32)[q] = row[q];
+}
+
+__global__ void dcn_w_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ wp, float *__restrict__ bp,
+                                  int Cout, int C, int rows)
+{
+    // wp [rows][9][C] <- w [Cout][C][3][3]; rows beyond Cout are zero
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)rows * 9 * C;
+    if (i < (size_t)rows) bp[i] = i < (size_t)Cout ? bias[i] : 0.f;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int tap = (int)((i / C) % 9);
+    const int o = (int)(i / ((size_t)9 * C));
+    wp[i] = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+}
+
+static size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t h3d_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout)
+{
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    const size_t rows = ((size_t)Cout + 127) / 128 * 128, px = (size_t)B * H * W;
+    return ws_align(px * C * 4) + ws_align(px * 32 * 4) + ws_align(rows * 9 * C * 4) + ws_align(rows * 4);
+}
+
+extern "C" int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *bias, const float *offset,
+                                     const float *mask, float *output, int B, int C, int H, int W, int Cout, int kernel_h,
+                                     int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dilation_h,
+                                     int dilation_w, int deformable_group, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const bool fast = kernel_h == 3 && kernel_w == 3 && stride_h == 1 && stride_w == 1 && pad_h == 1 && pad_w == 1 &&
+                      dilation_h == 1 && dilation_w == 1 && deformable_group == 1 && C > 0 && C % 16 == 0 && H <= 32767 && W <= 32767;
+    if (!fast || !workspace || workspace_bytes < h3d_dcn_v2_workspace_bytes(B, C, H, W, Cout))
+        return h3d_dcn_v2_forward(input, weight, bias, offset, mask, output, B, C, H, W, Cout, kernel_h, kernel_w, stride_h, stride_w,
+                                  pad_h, pad_w, dilation_h, dilation_w, deformable_group, stream);
+    if (!input || !weight || !bias || !offset || !mask || !output) H3D_FAIL(H3D_ERR_ARG, "dcn_v2_forward: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) H3D_FAIL(H3D_ERR_SHAPE, "dcn_v2_forward: non-positive dimension");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = (Cout + 127) / 128 * 128;
+    const size_t px = (size_t)B * H * W;
+    char *ws = (char *)workspace;
+    float *x_nhwc = (float *)ws;                ws += ws_align(px * C * 4);
+    float *om = (float *)ws;                    ws += ws_align(px * 32 * 4);
+    float *wp = (float *)ws;                    ws += ws_align((size_t)rows * 9 * C * 4);
+    float *bp = (float *)ws;
+    int rc = h3d_nchw_f32_to_nhwc(input, x_nhwc, H3D_F32, B, C, H, W, C, stream);
+    if (rc != H3D_OK) return rc;
+    hipLaunchKernelGGL(dcn_om_pack_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, offset, mask, om, H * W, px);
+    H3D_CHECK_LAUNCH("dcn_om_pack_kernel");
+    const size_t wtotal = (size_t)rows * 9 * C;
+    hipLaunchKernelGGL(dcn_w_pack_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, st, weight, bias, wp, bp, Cout, C, rows);
+    H3D_CHECK_LAUNCH("dcn_w_pack_kernel");
+    h3d_op op = {};
+    op.kind = H3D_OP_DCN; op.dtype = H3D_F32;
+    op.in = x_nhwc; op.in2 = om; op.w = wp; op.bias = bp; op.out = output;
+    op.B = B; op.H = H; op.W = W; op.Cin = C; op.in_cs = C; op.in2_cs = 32; op.Ho = H; op.Wo = W; op.Cout = Cout; op.out_cs = Cout;
+    op.ksize = 3; op.stride = 1; op.relu = 0; op.out_mode = H3D_OUT_NCHW_F32; op.wrows = rows;
+    op.reserved = 0x800;                        // the mask operand is final (the reference applies the sigmoid in DCN.forward, dcn_v2.py:124)
+    return h3d_launch_dcn2(op, st);
+}

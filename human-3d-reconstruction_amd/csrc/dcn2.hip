@@ -30,6 +30,7 @@ struct Dcn2Args {
     int Cout, out_cs, relu, out_mode;
     int tiles_x, tiles_y;
     int dbg;   // ablation switches for profiling (h3d_op.reserved): 1 = stage only chunk 0, 2 = no gather/blend, 4 = no MFMA
+    int mask_final;   // om[18..26] is the mask itself, not its logit (operator boundary h3d_dcn_v2_forward_ws; op.reserved & 0x800)
 };
 
 template <typename T, int MT, int CK, int MARGIN, int NT_>
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
                     const float lh = h_im - (float)hl, lw = w_im - (float)wl;
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-                    g = X::make_geo(w4, dcn2_sigmoid(omv[18 + tap]));
+                    g = X::make_geo(w4, a.mask_final ? omv[18 + tap] : dcn2_sigmoid(omv[18 + tap]));
                     off += ry * C::RBH + rx * C::SBH;
                 } else {
                     slow = true;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
                     const float lh = h_im - (float)hl, lw = w_im - (float)wl;
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-                    const typename X::geo g = X::make_geo(w4, dcn2_sigmoid(omp[18 + tap]));
+                    const typename X::geo g = X::make_geo(w4, a.mask_final ? omp[18 + tap] : dcn2_sigmoid(omp[18 + tap]));
                     const bool okh0 = hl >= 0, okh1 = hl + 1 <= a.H - 1, okw0 = wl >= 0, okw1 = wl + 1 <= a.W - 1;
                     const bool ok[4] = {okh0 && okw0, okh0 && okw1, okh1 && okw0, okh1 && okw1};
                     const int pix[4] = {hl * a.W + wl, hl * a.W + wl + 1, (hl + 1) * a.W + wl, (hl + 1) * a.W + wl + 1};
@@ -321,6 +322,7 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st)
     a.om_cs = op.in2_cs; a.Cout = op.Cout; a.out_cs = op.out_cs; a.relu = op.relu; a.out_mode = op.out_mode;
     a.tiles_x = a.tiles_y = 0;
     a.dbg = op.reserved;
+    a.mask_final = (op.reserved >> 11) & 1;
     if (op.dtype == H3D_BF16) {
         if (op.Cin % 32 == 0 && op.Cout <= 64) {
             if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 32, 2, 2>(a, st);

@@ -40,10 +40,17 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
         raise RuntimeError("bias has %d elements, expected %d" % (bias.numel(), Cout))
     out = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=input.device)
     with torch.cuda.device(input.device):
-        rc = _lib.lib().h3d_dcn_v2_forward(
+        # the model's configuration (3x3 s1 p1 d1 dg1, C % 16 == 0) runs on the LDS-apron + MFMA kernel, which wants a
+        # workspace (the reference allocates `columns` / `ones` itself, dcn_v2_cuda.cu:90-103; here torch's caching
+        # allocator does, stream-ordered); everything else takes the general kernel and needs none
+        fast = ((kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, deformable_group)
+                == (3, 3, 1, 1, 1, 1, 1, 1, 1) and C % 16 == 0)
+        nws = int(_lib.lib().h3d_dcn_v2_workspace_bytes(B, C, H, W, Cout)) if fast else 0
+        ws = torch.empty(nws, dtype=torch.uint8, device=input.device) if nws else None
+        rc = _lib.lib().h3d_dcn_v2_forward_ws(
             _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(out),
             B, C, H, W, Cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
-            deformable_group, _lib.stream_ptr())
+            deformable_group, _lib.ptr(ws), nws, _lib.stream_ptr())
     _lib.check(rc, "dcn_v2_forward")
     return out
 

@@ -57,6 +57,19 @@ int h3d_dcn_v2_forward(const float *input, const float *weight, const float *bia
                        int pad_h, int pad_w, int dilation_h, int dilation_w,
                        int deformable_group, void *stream);
 
+/* The same operator with a caller-provided device workspace of h3d_dcn_v2_workspace_bytes(...) bytes (the reference
+ * callee allocates its own scratch: `columns`, `ones`, pointer tables, dcn_v2_cuda.cu:90-103).  For the configuration the
+ * model uses (model.py:355: 3x3, stride 1, pad 1, dilation 1, deformable_group 1) and C % 16 == 0 the operands are re-laid
+ * into the network kernels' layout inside the workspace and the contraction runs on the LDS-apron + fp32-MFMA kernel
+ * (csrc/dcn2.hip); every other configuration (or a NULL / short workspace) takes h3d_dcn_v2_forward's general kernel. */
+size_t h3d_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout);
+int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *bias,
+                          const float *offset, const float *mask, float *output,
+                          int B, int C, int H, int W, int Cout,
+                          int kernel_h, int kernel_w, int stride_h, int stride_w,
+                          int pad_h, int pad_w, int dilation_h, int dilation_w,
+                          int deformable_group, void *workspace, size_t workspace_bytes, void *stream);
+
 /* =====================================================================================
  * 2. Network ops (DLA-34 + DLAUp/IDAUp + heads, model.py:32-61,148-222,286-292,346-415,475-489)
  *    on the internal layout: activations NHWC (channels-last) of element type f32 or bf16,
