@@ -254,6 +254,11 @@ template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipSt
         if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 16, 16>(a, st);
         return launch_conv_cfg<bf16_t, 1, 1, 4, 16, 16>(a, st);
     }
+    if (op.ksize == 1 && op.stride == 2) {        // the 1x1 stride-2 skip convs of the Hourglass / ResNet residual blocks
+        if (co <= 32) return launch_conv_cfg<bf16_t, 1, 2, 1, 16, 8>(a, st);
+        if (co <= 64) return launch_conv_cfg<bf16_t, 1, 2, 2, 16, 8>(a, st);
+        return launch_conv_cfg<bf16_t, 1, 2, 4, 16, 8>(a, st);
+    }
     H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv: ksize=%d stride=%d not covered (k in {1,3}, stride in {1,2})",
              op.ksize, op.stride);
 }
@@ -272,6 +277,10 @@ template <> int launch_conv_t<float>(const h3d_op &op, const ConvArgs &a, hipStr
     if (op.ksize == 1 && op.stride == 1) {
         if (co <= 32) return launch_conv_cfg<float, 1, 1, 1, 16, 16>(a, st);
         return launch_conv_cfg<float, 1, 1, 2, 16, 16>(a, st);
+    }
+    if (op.ksize == 1 && op.stride == 2) {
+        if (co <= 32) return launch_conv_cfg<float, 1, 2, 1, 16, 8>(a, st);
+        return launch_conv_cfg<float, 1, 2, 2, 16, 8>(a, st);
     }
     H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv: ksize=%d stride=%d not covered (k in {1,3}, stride in {1,2})",
              op.ksize, op.stride);

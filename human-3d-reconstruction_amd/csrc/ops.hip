@@ -57,6 +57,7 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st);
 int h3d_launch_dcn4(const h3d_op &op, hipStream_t st);
 int h3d_launch_updcn(const h3d_op &op, hipStream_t st);
 int h3d_launch_stem3(const h3d_op &op, hipStream_t st);
+int h3d_launch_extra(const h3d_op &op, hipStream_t st);
 
 static int run_one(const h3d_op &op, int i, hipStream_t st);
 
@@ -126,6 +127,9 @@ static int run_one(const h3d_op &op, int i, hipStream_t st)
     case H3D_OP_MAXPOOL:
     case H3D_OP_UPADD:
     case H3D_OP_COPY: rc = h3d_launch_elementwise(op, st); break;
+    case H3D_OP_IM2COL:
+    case H3D_OP_MAXPOOL3:
+    case H3D_OP_DEPTH2SPACE: rc = h3d_launch_extra(op, st); break;
     default: h3d_set_error("op %d: unknown kind %d", i, op.kind); return H3D_ERR_ARG;
     }
     if (rc != H3D_OK) {

@@ -21,7 +21,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, arch
+from . import _lib, arch, arch_hg
 from ._lib import H3dOp
 
 _TORCH_DT = {"bf16": torch.bfloat16, "f32": torch.float32}
@@ -51,11 +51,13 @@ class View:
 class PackedWeights:
     """BN-folded, re-laid-out weights on the device (built once per state_dict/dtype)."""
 
-    def __init__(self, state_dict, heads, use_dcn, dtype, device, head_conv=256):
+    def __init__(self, state_dict, heads, use_dcn, dtype, device, head_conv=256, arch_name="dla34"):
         self.heads, self.use_dcn, self.dtype, self.device = dict(heads), use_dcn, dtype, device
         self.head_conv = head_conv
+        self.arch = arch_name
         self.sd = {k: _t(v) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
-        missing = [k for k in arch.state_dict_shapes(heads, use_dcn, head_conv)
+        shapes = arch_hg.state_dict_shapes(heads) if arch_name == "hourglass" else arch.state_dict_shapes(heads, use_dcn, head_conv)
+        missing = [k for k in shapes
                    if not k.endswith("num_batches_tracked") and k not in self.sd]
         if missing:
             raise KeyError("state_dict is missing %d keys, e.g. %s" % (len(missing), missing[:3]))
@@ -220,6 +222,28 @@ class PackedWeights:
                            torch.cat(b1).float().contiguous().to(self.device), per)
         return self.t[key]
 
+    def nearest_up_key(self, c):
+        """Nearest-neighbour x2 up-sampling (Hourglass `nn.Upsample(scale_factor=2)`) as the depthwise
+        ConvTranspose2d(k=4, s=2, p=1) the up-sample + add kernel evaluates: taps (1..2, 1..2) = 1, the rest 0 --
+        output row y reads input row (y + 1 - ky) / 2 for ky = 1 (y even) or 2 (y odd), i.e. row y // 2."""
+        key = "__nearest_up2__.%d" % c
+        if key not in self.sd:
+            w = torch.zeros(c, 1, 4, 4)
+            w[:, 0, 1:3, 1:3] = 1.0
+            self.sd[key] = w
+        return key
+
+    def im2col_key(self, wkey, kpad=160):
+        """[Cout,3,7,7] stem filters as a 1x1 conv over H3D_OP_IM2COL patches: [Cout,kpad,1,1], k = c*49 + ky*7 + kx."""
+        key = wkey + "#im2col"
+        if key not in self.sd:
+            w = self.sd[wkey]
+            co, k = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
+            wp = torch.zeros(co, kpad, 1, 1)
+            wp[:, :k, 0, 0] = w.reshape(co, k)
+            self.sd[key] = wp
+        return key
+
     def up(self, wkey):
         key = ("up", wkey)
         if key not in self.t:
@@ -260,6 +284,9 @@ class Plan:
         for k, v in self.FLAGS.items():
             setattr(self, k, flags.get(k, v))
         self.stream_s2_min_cin = 64     # measured: the 32-channel stride-2 layer is faster on csrc/conv.hip (0.136 vs 0.165 ms)
+        if pw.arch == "hourglass" and (H % 128 or W % 128):
+            raise RuntimeError("Hourglass-104: input height/width must be multiples of 128 (got %dx%d): the published test "
+                               "code pads to (x|127)+1" % (H, W))
         if H % 32 or W % 32:
             raise RuntimeError("input height/width must be multiples of 32 (got %dx%d): the reference pads "
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
@@ -270,7 +297,11 @@ class Plan:
         self.keep = []          # tensors the ops point into
         self.images = torch.empty(B, 3, H, W, dtype=torch.float32, device=pw.device)
         self.outputs = {}
-        self._lower()
+        self.all_outputs = None         # Hourglass: one head dict per stack (outputs = the last one)
+        if pw.arch == "hourglass":
+            self._lower_hourglass()
+        else:
+            self._lower()
         self.op_array = (H3dOp * len(self.ops))(*self.ops)
 
     # -- buffer / op helpers --------------------------------------------------------------------
@@ -538,6 +569,58 @@ class Plan:
                 self.conv(feat, head + ".weight", bkey=head + ".bias", relu=False,
                           out_mode=_lib.OUT_NCHW_F32, out_tensor=o)
 
+    # -- Hourglass-104 (arch_hg.py; published CenterNet `exkp`) ---------------------------------------------------------
+    def _hg_residual(self, x, p, cin, cout, stride):
+        """residual: relu(bn2(conv2(relu(bn1(conv1(x))))) + skip(x)), skip = 1x1 conv + BN when stride / width change."""
+        t = self.conv(x, p + ".conv1.weight", bn=p + ".bn1", stride=stride)
+        skip = x
+        if arch_hg.residual_has_skip(cin, cout, stride):
+            skip = self.conv(x, p + ".skip.0.weight", bn=p + ".skip.1", stride=stride, relu=False)
+        return self.conv(t, p + ".conv2.weight", bn=p + ".bn2", res=skip)
+
+    def _hg_seq(self, x, p, kind, cin, cout, modules):
+        for j, (ci, co, st) in enumerate(arch_hg.layer_specs(kind, cin, cout, modules)):
+            x = self._hg_residual(x, "%s.%d" % (p, j), ci, co, st)
+        return x
+
+    def _hg_kp(self, x, p, n, dims, modules):
+        up1 = self._hg_seq(x, p + ".up1", "layer", dims[0], dims[0], modules[0])
+        low1 = self._hg_seq(x, p + ".low1", "hg", dims[0], dims[1], modules[0])
+        if n > 1:
+            low2 = self._hg_kp(low1, p + ".low2", n - 1, dims[1:], modules[1:])
+        else:
+            low2 = self._hg_seq(low1, p + ".low2", "layer", dims[1], dims[1], modules[1])
+        low3 = self._hg_seq(low2, p + ".low3", "revr", dims[1], dims[0], modules[0])
+        return self.upadd(low3, up1, self.pw.nearest_up_key(dims[0]))       # up1 + nearest x2 of low3
+
+    def _lower_hourglass(self):
+        B, H, W = self.B, self.H, self.W
+        nstack = 2
+        # pre.0: Conv2d(3, 128, 7, stride 2, pad 3) + BN + ReLU as im2col (csrc/extra.hip) + the MFMA 1x1 conv
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        patches = self._alloc(Ho, Wo, 160)
+        self._op(_lib.OP_IM2COL, in_=self.images.data_ptr(), out=patches.ptr, H=H, W=W, Cin=3, in_cs=3, Ho=Ho, Wo=Wo, Cout=160,
+                 out_cs=patches.cs, ksize=7, stride=2)
+        inter = self.conv(patches, self.pw.im2col_key("pre.0.conv.weight"), bn="pre.0.bn")
+        inter = self._hg_residual(inter, "pre.1", arch_hg.PRE_DIM, arch_hg.DIMS[0], 2)
+        self.all_outputs = []
+        for i in range(nstack):
+            kp = self._hg_kp(inter, "kps.%d" % i, arch_hg.N, arch_hg.DIMS, arch_hg.MODULES)
+            cnv = self.conv(kp, "cnvs.%d.conv.weight" % i, bn="cnvs.%d.bn" % i)
+            out = {}
+            for head, c in self.pw.heads.items():
+                o = torch.empty(B, c, cnv.H, cnv.W, dtype=torch.float32, device=self.pw.device)
+                t = self.conv(cnv, "%s.%d.0.conv.weight" % (head, i), bkey="%s.%d.0.conv.bias" % (head, i))
+                self.conv(t, "%s.%d.1.weight" % (head, i), bkey="%s.%d.1.bias" % (head, i), relu=False,
+                          out_mode=_lib.OUT_NCHW_F32, out_tensor=o)
+                out[head] = o
+            self.all_outputs.append(out)
+            if i < nstack - 1:
+                a = self.conv(inter, "inters_.%d.0.weight" % i, bn="inters_.%d.1" % i, relu=False)
+                inter = self.conv(cnv, "cnvs_.%d.0.weight" % i, bn="cnvs_.%d.1" % i, res=a)       # relu(inters_(inter) + cnvs_(cnv))
+                inter = self._hg_residual(inter, "inters.%d" % i, arch_hg.DIMS[0], arch_hg.DIMS[0], 1)
+        self.outputs = self.all_outputs[-1]
+
     def retarget_outputs(self, views):
         """Point the head outputs at caller-provided contiguous [B,C,H,W] fp32 views (sub-batch plans)."""
         for h, v in views.items():
@@ -568,14 +651,14 @@ class DLAEngine:
     (fresh views of the plan's output buffers; they are overwritten by the next forward of the
     same shape, like any static-graph runtime -- clone to keep)."""
 
-    def __init__(self, state_dict, heads, use_dcn, dtype="bf16", device="cuda", head_conv=256):
+    def __init__(self, state_dict, heads, use_dcn, dtype="bf16", device="cuda", head_conv=256, arch_name="dla34"):
         if dtype not in _TORCH_DT:
             raise ValueError("dtype must be 'bf16' or 'f32'")
         _lib.lib()                                     # fail loudly now if the HIP library is missing
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("Not implemented on the CPU")
-        self.pw = PackedWeights(state_dict, heads, use_dcn, dtype, self.device, head_conv)
+        self.pw = PackedWeights(state_dict, heads, use_dcn, dtype, self.device, head_conv, arch_name)
         self.plans = {}
         for k, v in Plan.FLAGS.items():   # lowering switches, see Plan.FLAGS (changing one requires plans.clear())
             setattr(self, k, v)
@@ -596,7 +679,7 @@ class DLAEngine:
         if images.dim() != 4 or images.shape[1] != 3:
             raise RuntimeError("expected images [B,3,H,W], got %s" % (tuple(images.shape),))
         B, _, H, W = images.shape
-        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 8:
+        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 8 and self.pw.arch == "dla34":
             return self._forward_split(images)
         plan = self.plan(B, H, W)
         with torch.cuda.device(self.device):

@@ -11,7 +11,7 @@ import math
 import torch
 from torch import nn
 
-from . import arch
+from . import arch, arch_hg
 from .engine import DLAEngine
 
 
@@ -58,6 +58,11 @@ def _init_tensor(key, shape, heads):
 
 
 class DLASeg(nn.Module):
+    arch_name = "dla34"
+
+    def _shapes(self):
+        return arch.state_dict_shapes(self.heads, self.use_dcn, self.head_conv)
+
     def __init__(self, heads, head_conv=256, use_dcn=True, dtype="bf16"):
         super().__init__()
         self.heads = dict(heads)
@@ -65,7 +70,7 @@ class DLASeg(nn.Module):
         self.use_dcn = use_dcn
         self.compute_dtype = dtype
         self._engine = None
-        shapes = arch.state_dict_shapes(self.heads, use_dcn, head_conv)
+        shapes = self._shapes()
         pending_bias = {}
         for key, shape in shapes.items():
             t = _init_tensor(key, shape, self.heads)
@@ -109,7 +114,7 @@ class DLASeg(nn.Module):
     def engine(self, device):
         if self._engine is None or self._engine.device != torch.device(device):
             sd = {k: v for k, v in self.state_dict().items()}
-            self._engine = DLAEngine(sd, self.heads, self.use_dcn, self.compute_dtype, device, self.head_conv)
+            self._engine = DLAEngine(sd, self.heads, self.use_dcn, self.compute_dtype, device, self.head_conv, self.arch_name)
         return self._engine
 
     def forward(self, x):
@@ -118,7 +123,11 @@ class DLASeg(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
         with torch.no_grad():
-            return [dict(self.engine(x.device)(x))]
+            out = self.engine(x.device)(x)
+            return self._wrap(x, out)
+
+    def _wrap(self, x, out):
+        return [dict(out)]
 
 
 def dla_net(heads, num_layers=34, head_conv=256, down_ratio=4, not_use_dcn=False, dtype="bf16"):
@@ -130,3 +139,36 @@ def dla_net(heads, num_layers=34, head_conv=256, down_ratio=4, not_use_dcn=False
         raise ValueError("down_ratio %d: the multi_pose path uses 4 (opts.py)" % down_ratio)
     print("==> Use DeformConv." if not not_use_dcn else "==> Do not use DeformConv.")
     return DLASeg(heads, head_conv=head_conv, use_dcn=not not_use_dcn, dtype=dtype)
+
+
+class HourglassNet(DLASeg):
+    """Hourglass-104 (`exkp`, two stacks) with the published CenterNet state_dict names (arch_hg.py).  `forward(x)` returns
+    one head dict per stack, like the published `exkp.forward`; inference uses the last one (`model(x)[-1]`)."""
+    arch_name = "hourglass"
+
+    def _shapes(self):
+        return arch_hg.state_dict_shapes(self.heads)
+
+    def _wrap(self, x, out):
+        B, _, H, W = x.shape
+        plan = self.engine(x.device).plan(B, H, W)
+        return [dict(o) for o in plan.all_outputs]
+
+
+def hourglass_net(heads, num_stacks=2, dtype="bf16"):
+    """`get_large_hourglass_net(num_layers, heads, head_conv)` of the published CenterNet code (the reference parses
+    `--arch hourglass`, opts.py:61-63, but has no such factory): Hourglass-104, two stacks, head_conv = 256 built in."""
+    if num_stacks != 2:
+        raise ValueError("Hourglass-104 as published has 2 stacks")
+    return HourglassNet(heads, head_conv=256, use_dcn=False, dtype=dtype)
+
+
+def create_model(arch_name, heads, head_conv=256, not_use_dcn=False, dtype="bf16"):
+    """`--arch` dispatch (opts.py:61-63: 'dla_34 | hourglass | resdcn_101'; the reference ignores it and always builds
+    dla_net, trains/trainer.py:165)."""
+    name = arch_name.replace("-", "_")
+    if name in ("dla_34", "dla34"):
+        return dla_net(heads, 34, head_conv, 4, not_use_dcn, dtype=dtype)
+    if name in ("hourglass", "hourglass_104", "hg"):
+        return hourglass_net(heads, 2, dtype=dtype)
+    raise ValueError("arch %r not supported (dla_34 | hourglass)" % arch_name)

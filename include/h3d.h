@@ -105,6 +105,11 @@ enum {
                            stride f in {2, 4}) + skip add evaluated while the DeformConv's input tile is staged, then
                            DCN_FUSED_F16's kernel.  in = x at the LOW resolution H x W, Ho x Wo = f * (H x W), stride = f,
                            in2 = HOST pointer to h3d_updcn_desc; bf16 plans, 64 channels                               */
+    /* ops of the other backbones (BASELINE configs 4, 5: Hourglass-104, ResNet-101-DCN; csrc/extra.hip) */
+    H3D_OP_IM2COL = 15,      /* 7x7 stride-2 pad-3 stem conv as im2col: in = NCHW fp32 images [B,Cin,H,W] -> out [B,Ho,Wo,Cout] patches,
+                                channel k = c*ks*ks + ky*ks + kx, zero from Cin*ks*ks up to Cout (a multiple of 16): feeds a 1x1 H3D_OP_CONV */
+    H3D_OP_MAXPOOL3 = 16,    /* nn.MaxPool2d(3, stride 2, padding 1): Ho = (H-1)/2+1                                        */
+    H3D_OP_DEPTH2SPACE = 17, /* [B,H,W,4*Cout] -> [B,2H,2W,Cout]: channel group 2*py+px -> output pixel (2y+py, 2x+px)        */
     H3D_OP_HEADS = 7    /* all output heads fused: Conv3x3(64->head_conv)+ReLU+Conv1x1(->C) per head
                            (model.py:451-460, 485-489); in2 = HOST pointer to h3d_heads_desc          */
 };
