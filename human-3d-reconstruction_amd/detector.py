@@ -13,7 +13,7 @@ single RCCL collective of the sharded path.
 import torch
 
 from . import _lib, decode, smpl as _smpl
-from .model import dla_net
+from .model import create_model
 from .utils import _transpose_and_gather_feat
 
 MULTI_POSE_HEADS = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}   # opts.py:248-258
@@ -26,8 +26,8 @@ class Opt:
 
     def __init__(self, **kw):
         self.task = "multi_pose"
-        self.arch = "dla_34"
-        self.head_conv = 256
+        self.arch = "dla_34"              # opts.py:61-63: dla_34 | hourglass | resdcn_101
+        self.head_conv = 256              # (the published code uses 64 for the non-DLA backbones: create_model maps 256 -> 64 for resdcn)
         self.down_ratio = 4
         self.K = 100
         self.not_use_dcn = False
@@ -69,7 +69,7 @@ class MultiPoseDetector:
             raise ValueError("task not defined!")          # trains/trainer.py:472
         self.opt = opt
         self.device = torch.device(device)
-        self.model = dla_net(opt.heads, 34, opt.head_conv, opt.down_ratio, opt.not_use_dcn, dtype=opt.dtype)
+        self.model = create_model(opt.arch, opt.heads, opt.head_conv, opt.not_use_dcn, dtype=opt.dtype)
         if state_dict is not None:
             self.model.load_state_dict(state_dict, strict=True)
         self.model.to(self.device).eval()
@@ -82,7 +82,7 @@ class MultiPoseDetector:
         """images [B,3,H,W] fp32 on the device -> dict(dets [B,K,40], inds [B,K], optional
         verts [B,N,6890,3] / joints, optional results [B,K,39] in image px when meta={'c','s'})."""
         opt = self.opt
-        out = self.model(images)[0]
+        out = self.model(images)[-1]          # (Hourglass returns one dict per stack: inference uses the last)
         dets, aux = decode.multi_pose_decode_logits(
             out["hm"], out["wh"], out["hps"], reg=out.get("reg") if opt.reg_offset else None,
             hm_hp=out.get("hm_hp") if opt.hm_hp else None,
@@ -114,7 +114,7 @@ class CtdetDetector:
             raise ValueError("task not defined!")
         self.opt = opt
         self.device = torch.device(device)
-        self.model = dla_net(opt.heads, 34, opt.head_conv, opt.down_ratio, opt.not_use_dcn, dtype=opt.dtype)
+        self.model = create_model(opt.arch, opt.heads, opt.head_conv, opt.not_use_dcn, dtype=opt.dtype)
         if state_dict is not None:
             self.model.load_state_dict(state_dict, strict=True)
         self.model.to(self.device).eval()
@@ -125,7 +125,7 @@ class CtdetDetector:
         the reference's per-image {class id (1-based): [[x1, y1, x2, y2, score], ...]} when meta={'c','s'})."""
         from .utils import _sigmoid
         opt = self.opt
-        out = self.model(images)[0]
+        out = self.model(images)[-1]
         hm = _sigmoid(out["hm"].clone())
         dets = decode.ctdet_decode(hm, out["wh"], reg=out.get("reg") if opt.reg_offset else None,
                                    cat_spec_wh=opt.cat_spec_wh, K=opt.K)

@@ -21,7 +21,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib, arch, arch_hg
+from . import _lib, arch, arch_hg, arch_res
 from ._lib import H3dOp
 
 _TORCH_DT = {"bf16": torch.bfloat16, "f32": torch.float32}
@@ -56,12 +56,26 @@ class PackedWeights:
         self.head_conv = head_conv
         self.arch = arch_name
         self.sd = {k: _t(v) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
-        shapes = arch_hg.state_dict_shapes(heads) if arch_name == "hourglass" else arch.state_dict_shapes(heads, use_dcn, head_conv)
+        shapes = (arch_hg.state_dict_shapes(heads) if arch_name == "hourglass" else
+                  arch_res.state_dict_shapes(heads, head_conv) if arch_name == "resdcn101" else
+                  arch.state_dict_shapes(heads, use_dcn, head_conv))
         missing = [k for k in shapes
                    if not k.endswith("num_batches_tracked") and k not in self.sd]
         if missing:
             raise KeyError("state_dict is missing %d keys, e.g. %s" % (len(missing), missing[:3]))
         self.t = {}
+        if arch_name == "resdcn101":
+            # the DCN of up-sampling stage i is `deconv_layers.{6i}` (weight, bias, conv_offset_mask.*) followed by the
+            # BatchNorm `deconv_layers.{6i+1}`: alias them to the key pattern the DeformConv lowering reads
+            # (`p.conv.*`, `p.actf.0.*` of the DLA neck, model.py:346-362)
+            for i in range(len(arch_res.DECONV)):
+                p, bn = "deconv_layers.%d" % (6 * i), "deconv_layers.%d" % (6 * i + 1)
+                for a, b in ((".conv.weight", ".weight"), (".conv.bias", ".bias"),
+                             (".conv.conv_offset_mask.weight", ".conv_offset_mask.weight"),
+                             (".conv.conv_offset_mask.bias", ".conv_offset_mask.bias")):
+                    self.sd[p + a] = self.sd[p + b]
+                for leaf in ("weight", "bias", "running_mean", "running_var"):
+                    self.sd["%s.actf.0.%s" % (p, leaf)] = self.sd["%s.%s" % (bn, leaf)]
 
     def _fold(self, w, b, bn):
         """conv(+bias) followed by eval BatchNorm `bn` -> (w', b')."""
@@ -233,6 +247,27 @@ class PackedWeights:
             self.sd[key] = w
         return key
 
+    def deconv4_as_conv3(self, wkey, bn):
+        """ConvTranspose2d(C, C, 4, stride 2, padding 1, bias=False) + BatchNorm `bn` as ONE 3x3 conv with 4C output
+        channels followed by H3D_OP_DEPTH2SPACE: output pixel (2y+py, 2x+px) only sees inputs (y+dy, x+dx) with
+        dy in {-1, 0} (py = 0) or {0, 1} (py = 1) through kernel row ky = py + 1 - 2 dy, so group g = 2 py + px of the
+        3x3 filters is that 2x2 sub-kernel, zero elsewhere (2.25x the transposed conv's MACs, all of them on the MFMA conv
+        kernel).  -> (weight key [4C, C, 3, 3], BatchNorm prefix with the statistics repeated per group)."""
+        key, bkey = wkey + "#conv3", bn + "#x4"
+        if key not in self.sd:
+            w = self.sd[wkey]                                    # [Cin, Cout, 4, 4]
+            ci, co = w.shape[0], w.shape[1]
+            w3 = torch.zeros(4, co, ci, 3, 3)
+            for py in range(2):
+                for px in range(2):
+                    for dy in ((-1, 0) if py == 0 else (0, 1)):
+                        for dx in ((-1, 0) if px == 0 else (0, 1)):
+                            w3[2 * py + px, :, :, dy + 1, dx + 1] = w[:, :, py + 1 - 2 * dy, px + 1 - 2 * dx].t()
+            self.sd[key] = w3.reshape(4 * co, ci, 3, 3)
+            for leaf in ("weight", "bias", "running_mean", "running_var"):
+                self.sd["%s.%s" % (bkey, leaf)] = self.sd["%s.%s" % (bn, leaf)].repeat(4)
+        return key, bkey
+
     def im2col_key(self, wkey, kpad=160):
         """[Cout,3,7,7] stem filters as a 1x1 conv over H3D_OP_IM2COL patches: [Cout,kpad,1,1], k = c*49 + ky*7 + kx."""
         key = wkey + "#im2col"
@@ -300,6 +335,8 @@ class Plan:
         self.all_outputs = None         # Hourglass: one head dict per stack (outputs = the last one)
         if pw.arch == "hourglass":
             self._lower_hourglass()
+        elif pw.arch == "resdcn101":
+            self._lower_resdcn()
         else:
             self._lower()
         self.op_array = (H3dOp * len(self.ops))(*self.ops)
@@ -535,6 +572,11 @@ class Plan:
         self._ida(ys, "ida_up", 0, 3)
         feat = ys[-1]
         self.feat = feat
+        self._lower_heads(feat)
+
+    def _lower_heads(self, feat):
+        """Output heads on the 64-channel map (model.py:451-460, 485-489; the ResNet-DCN heads have the same form)."""
+        B = self.B
         Ho, Wo = feat.H, feat.W
         fused = (self.pw.head_conv > 0 and self.pw.head_conv % 64 == 0 and feat.C == 64 and
                  len(self.pw.heads) <= _lib.HEADS_MAX and max(self.pw.heads.values()) <= 96 and self.fuse_heads)
@@ -568,6 +610,33 @@ class Plan:
             else:
                 self.conv(feat, head + ".weight", bkey=head + ".bias", relu=False,
                           out_mode=_lib.OUT_NCHW_F32, out_tensor=o)
+
+    # -- ResNet-101-DCN (arch_res.py; published CenterNet `resnet_dcn.py`) ---------------------------------------------------
+    def _lower_resdcn(self):
+        B, H, W = self.B, self.H, self.W
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        patches = self._alloc(Ho, Wo, 160)                   # conv1 7x7/2 as im2col + 1x1 conv (csrc/extra.hip)
+        self._op(_lib.OP_IM2COL, in_=self.images.data_ptr(), out=patches.ptr, H=H, W=W, Cin=3, in_cs=3, Ho=Ho, Wo=Wo, Cout=160,
+                 out_cs=patches.cs, ksize=7, stride=2)
+        x = self.conv(patches, self.pw.im2col_key("conv1.weight"), bn="bn1")
+        y = self._alloc((x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1, x.C)
+        self._op(_lib.OP_MAXPOOL3, in_=x.ptr, out=y.ptr, H=x.H, W=x.W, Cin=x.C, in_cs=x.cs, Ho=y.H, Wo=y.W, Cout=x.C, out_cs=y.cs,
+                 ksize=3, stride=2)
+        x = y
+        for p, cin, planes, stride, down in arch_res.blocks(101):
+            t = self.conv(x, p + ".conv1.weight", bn=p + ".bn1")
+            t = self.conv(t, p + ".conv2.weight", bn=p + ".bn2", stride=stride)
+            res = self.conv(x, p + ".downsample.0.weight", bn=p + ".downsample.1", stride=stride, relu=False) if down else x
+            x = self.conv(t, p + ".conv3.weight", bn=p + ".bn3", res=res)
+        for i, planes in enumerate(arch_res.DECONV):
+            x = self._deform(x, "deconv_layers.%d" % (6 * i))                # DCN + BN + ReLU
+            wkey, bn = self.pw.deconv4_as_conv3("deconv_layers.%d.weight" % (6 * i + 3), "deconv_layers.%d" % (6 * i + 4))
+            t = self.conv(x, wkey, bn=bn)                                      # [B,H,W,4C], BN + ReLU folded / fused
+            x = self._alloc(2 * t.H, 2 * t.W, planes)
+            self._op(_lib.OP_DEPTH2SPACE, in_=t.ptr, out=x.ptr, H=t.H, W=t.W, Cin=4 * planes, in_cs=t.cs, Ho=x.H, Wo=x.W,
+                     Cout=planes, out_cs=x.cs, ksize=1, stride=1)
+        self.feat = x
+        self._lower_heads(x)
 
     # -- Hourglass-104 (arch_hg.py; published CenterNet `exkp`) ---------------------------------------------------------
     def _hg_residual(self, x, p, cin, cout, stride):

@@ -11,7 +11,7 @@ import math
 import torch
 from torch import nn
 
-from . import arch, arch_hg
+from . import arch, arch_hg, arch_res
 from .engine import DLAEngine
 
 
@@ -163,6 +163,23 @@ def hourglass_net(heads, num_stacks=2, dtype="bf16"):
     return HourglassNet(heads, head_conv=256, use_dcn=False, dtype=dtype)
 
 
+class PoseResNetDCN(DLASeg):
+    """ResNet-101-DCN (`resnet_dcn.py` PoseResNet of the published CenterNet code, arch_res.py): same head dict output as
+    DLASeg.forward."""
+    arch_name = "resdcn101"
+
+    def _shapes(self):
+        return arch_res.state_dict_shapes(self.heads, self.head_conv)
+
+
+def resdcn_net(heads, num_layers=101, head_conv=64, dtype="bf16"):
+    """`get_pose_net(num_layers, heads, head_conv)` of the published `resnet_dcn.py` (`--arch resdcn_101`,
+    experiments/ctdet_coco_resdcn101.sh:3); head_conv is 64 for every non-DLA arch there."""
+    if num_layers != 101:
+        raise ValueError("resdcn_%d: only the 101-layer variant named by BASELINE configs[4] is built" % num_layers)
+    return PoseResNetDCN(heads, head_conv=head_conv, use_dcn=True, dtype=dtype)
+
+
 def create_model(arch_name, heads, head_conv=256, not_use_dcn=False, dtype="bf16"):
     """`--arch` dispatch (opts.py:61-63: 'dla_34 | hourglass | resdcn_101'; the reference ignores it and always builds
     dla_net, trains/trainer.py:165)."""
@@ -171,4 +188,6 @@ def create_model(arch_name, heads, head_conv=256, not_use_dcn=False, dtype="bf16
         return dla_net(heads, 34, head_conv, 4, not_use_dcn, dtype=dtype)
     if name in ("hourglass", "hourglass_104", "hg"):
         return hourglass_net(heads, 2, dtype=dtype)
-    raise ValueError("arch %r not supported (dla_34 | hourglass)" % arch_name)
+    if name in ("resdcn_101", "resdcn101"):
+        return resdcn_net(heads, 101, 64 if head_conv in (256, -1) else head_conv, dtype=dtype)
+    raise ValueError("arch %r not supported (dla_34 | hourglass | resdcn_101)" % arch_name)

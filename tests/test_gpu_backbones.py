@@ -143,3 +143,52 @@ def test_hourglass_bf16_within_bf16_arithmetic_and_deterministic():
     for o, a in zip(outs, again):
         for k in HG_HEADS:
             assert torch.equal(o[k], a[k]), k
+
+
+RES_HEADS = {"hm": 80, "wh": 2, "reg": 2}
+
+
+def _res(dtype):
+    from h3d_amd import arch_res
+    sd = synth.synth_state_dict(arch_res.state_dict_shapes(RES_HEADS), seed=0, gain=0.9, offset_scale=1.0)
+    m = model.resdcn_net(RES_HEADS, dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.to(DEV).eval(), sd
+
+
+def test_resdcn_f32_matches_oracle():
+    from oracle import resdcn as ores
+    m, sd = _res("f32")
+    xs = synth.synth_images(1, 128, 160, seed=5)
+    out = m(torch.from_numpy(xs).to(DEV))[0]
+    with torch.no_grad():
+        ref = ores.ResDCNOracle(sd, RES_HEADS)(torch.from_numpy(xs))[0]
+    for k in RES_HEADS:
+        scale = max(1.0, float(ref[k].abs().max()))
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=0, atol=2e-3 * scale, err_msg=k)
+
+
+def test_resdcn_bf16_within_bf16_arithmetic_and_ctdet_detector():
+    from oracle import resdcn as ores
+    from h3d_amd.detector import Opt, make_detector
+    m, sd = _res("bf16")
+    xs = synth.synth_images(2, 128, 160, seed=7)
+    x = torch.from_numpy(xs).to(DEV)
+    out = {k: v.clone() for k, v in m(x)[0].items()}
+    with torch.no_grad():
+        ref = ores.ResDCNOracle(sd, RES_HEADS)(torch.from_numpy(xs))[0]
+        emu = ores.ResDCNOracle(sd, RES_HEADS, emulate_bf16=True)(torch.from_numpy(xs))[0]
+    for k in RES_HEADS:
+        got = out[k].cpu().numpy()
+        emax, erms = float(np.abs(got - ref[k].numpy()).max()), float(np.sqrt(np.mean((got - ref[k].numpy()) ** 2)))
+        tmax, trms = float((emu[k] - ref[k]).abs().max()), float(torch.sqrt(torch.mean((emu[k] - ref[k]) ** 2)))
+        assert emax <= 3.0 * tmax + 1e-3 and erms <= 1.5 * trms + 1e-4, (k, emax, erms, tmax, trms)
+    again = m(x)[0]
+    for k in RES_HEADS:
+        assert torch.equal(out[k], again[k]), k
+    # config 5 end to end: --arch resdcn_101 --task ctdet through the task / arch dispatch
+    opt = Opt(task="ctdet", arch="resdcn_101", input_h=128, input_w=160, dtype="bf16", K=20)
+    det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    res = det.run(x, meta={"c": np.array([[80.0, 64.0]] * 2, np.float32), "s": np.array([160.0, 160.0], np.float32)})
+    assert res["dets"].shape == (2, 20, 6) and len(res["results"]) == 2 and set(res["results"][0]) == set(range(1, 81))
+    assert torch.equal(res["heads"]["hm"], out["hm"])

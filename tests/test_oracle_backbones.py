@@ -52,3 +52,40 @@ def test_hourglass_oracle_shapes_and_identities():
     cols = F.unfold(x, 7, padding=3, stride=2)                                   # [1, 147, L], same k order
     y = (w.reshape(128, 147) @ cols[0]).reshape(1, 128, 64, 128)
     np.testing.assert_allclose(y.numpy(), F.conv2d(x, w, None, 2, 3).numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_resdcn_table_and_oracle():
+    from h3d_amd import arch_res
+    from oracle import resdcn as ores
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    shapes = arch_res.state_dict_shapes(heads)
+    assert abs(_nparams(arch_res.state_dict_shapes({})) - 49.5e6) < 0.6e6             # ResNet-101 trunk 42.5 M + DCN / deconv stages
+    m = model.resdcn_net(heads)
+    assert set(m.state_dict()) == set(shapes) and m.arch_name == "resdcn101"
+    assert shapes["layer3.22.conv2.weight"] == (256, 256, 3, 3) and shapes["layer1.0.downsample.0.weight"] == (256, 64, 1, 1)
+    assert shapes["deconv_layers.0.conv_offset_mask.weight"] == (27, 2048, 3, 3) and shapes["deconv_layers.15.weight"] == (64, 64, 4, 4)
+    assert model.create_model("resdcn_101", heads).head_conv == 64
+    sd = synth.synth_state_dict(shapes, seed=0, gain=0.9)
+    x = torch.from_numpy(synth.synth_images(1, 64, 96))
+    with torch.no_grad():
+        out = ores.ResDCNOracle(sd, heads)(x)[0]
+    assert out["hm"].shape == (1, 80, 16, 24) and all(torch.isfinite(v).all() for v in out.values())
+
+
+def test_transposed_conv_as_conv3_plus_depth2space_identity():
+    # engine.PackedWeights.deconv4_as_conv3: ConvTranspose2d(C, C, 4, 2, 1) + BN == conv3x3 with 4C outputs + pixel shuffle
+    from h3d_amd import engine
+    C = 8
+    w = torch.from_numpy(synth.uniform("wt", (C, C, 4, 4), -1, 1))
+    bn = {"bn.weight": torch.from_numpy(synth.uniform("g", (C,), 0.5, 1.5)), "bn.bias": torch.from_numpy(synth.uniform("b", (C,), -1, 1)),
+          "bn.running_mean": torch.from_numpy(synth.uniform("m", (C,), -1, 1)), "bn.running_var": torch.from_numpy(synth.uniform("v", (C,), 0.5, 2))}
+    pw = object.__new__(engine.PackedWeights)
+    pw.sd = dict(bn, **{"up.weight": w})
+    wkey, bkey = pw.deconv4_as_conv3("up.weight", "bn")
+    x = torch.from_numpy(synth.uniform("x", (2, C, 5, 7), -1, 1))
+    ref = F.batch_norm(F.conv_transpose2d(x, w, None, stride=2, padding=1), bn["bn.running_mean"], bn["bn.running_var"],
+                       bn["bn.weight"], bn["bn.bias"], False, 0.0, 1e-5)
+    y = F.batch_norm(F.conv2d(x, pw.sd[wkey], None, 1, 1), pw.sd[bkey + ".running_mean"], pw.sd[bkey + ".running_var"],
+                     pw.sd[bkey + ".weight"], pw.sd[bkey + ".bias"], False, 0.0, 1e-5)
+    y = y.reshape(2, 2, 2, C, 5, 7).permute(0, 3, 4, 1, 5, 2).reshape(2, C, 10, 14)             # depth2space, group g = 2 py + px
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
