@@ -293,6 +293,11 @@ def main():
     ap.add_argument("--weight-gain", type=float, default=1.25,
                     help="gain of the synthetic conv weights (h3d_amd.synth): 1.25 keeps the signal alive through DLA-34, so "
                          "the heat map has separated peaks and index_match means something; 1.0 = round 1's weights")
+    ap.add_argument("--arch", default="dla_34", choices=["dla_34", "hourglass", "resdcn_101"],
+                    help="dla_34 = the headline workload (BASELINE configs[1]/[2]); hourglass = configs[3] (multi_pose, 512x512, "
+                         "16 images per GPU); resdcn_101 = configs[4] (ctdet, 768x768, 32 images per GPU): per-GPU shard of the "
+                         "8-GPU batch, network + decode, no SMPL stage, no CPU baseline")
+    ap.add_argument("--size", type=int, default=0, help="input height = width (default 512; 768 for resdcn_101)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="launcher + collective plumbing only, gloo on CPU (tests)")
@@ -316,12 +321,29 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
 
-    opt = Opt(input_h=512, input_w=512, smpl=True, smpl_people=args.people, dtype=args.dtype, K=100)
-    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, offset_scale=args.offset_scale, gain=args.weight_gain)
-    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
+    dla = args.arch == "dla_34"
+    size = args.size or (768 if args.arch == "resdcn_101" else 512)
+    if dla:
+        opt = Opt(input_h=size, input_w=size, smpl=True, smpl_people=args.people, dtype=args.dtype, K=100)
+        sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, offset_scale=args.offset_scale, gain=args.weight_gain)
+        det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
+        gflop_img = arch.conv_flops(opt.heads, True, size, size) / 1e9
+    else:
+        from h3d_amd import arch_hg, arch_res
+        from h3d_amd.detector import make_detector
+        if args.arch == "hourglass":
+            opt = Opt(arch="hourglass", input_h=size, input_w=size, dtype=args.dtype, K=100)
+            shapes, gain = arch_hg.state_dict_shapes(opt.heads), 0.8
+            gflop_img = arch_hg.conv_flops(opt.heads, size, size) / 1e9
+        else:
+            opt = Opt(arch="resdcn_101", task="ctdet", input_h=size, input_w=size, dtype=args.dtype, K=100)
+            shapes, gain = arch_res.state_dict_shapes(opt.heads, 64), 0.9
+            gflop_img = arch_res.conv_flops(opt.heads, size, size) / 1e9
+        sd = synth.synth_state_dict(shapes, seed=0, offset_scale=args.offset_scale, gain=gain)
+        det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
     det.model.engine(dev).streams = args.streams
-    images = torch.from_numpy(synth.synth_images(1, 512, 512, seed=317 + rank)).to(dev)
-    images = images.expand(args.batch, 3, 512, 512).contiguous()
+    images = torch.from_numpy(synth.synth_images(1, size, size, seed=317 + rank)).to(dev)
+    images = images.expand(args.batch, 3, size, size).contiguous()
     images += 0.01 * torch.arange(args.batch, device=dev, dtype=torch.float32).view(-1, 1, 1, 1)   # distinct images
 
     def step():
@@ -334,9 +356,9 @@ def main():
     t_setup = time.perf_counter()
     eng = det.model.engine(dev)
     if args.streams <= 1:                       # (the sub-batch plans of --streams N are built by the first step)
-        eng.plan(args.batch, 512, 512)
+        eng.plan(args.batch, size, size)
     from h3d_amd import smpl as _smpl
-    if det.smpl_model._dev is None:
+    if dla and det.smpl_model._dev is None:
         det.smpl_model._dev = _smpl._device_pack(det.smpl_model, dev)
     torch.cuda.synchronize()
     t_built = time.perf_counter()
@@ -362,13 +384,12 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert out.shape == (world * args.batch, 100, 40)
+    assert out.shape == (world * args.batch, 100, 6 if args.arch == "resdcn_101" else 40)
     if rank == 0:
         print("[bench] %d GPU(s): %.1f images/s, %.3f ms/step" % (world, world * args.batch * args.steps / dt,
                                                                  1e3 * dt / args.steps), file=sys.stderr, flush=True)
 
     if rank == 0:
-        gflop_img = arch.conv_flops(opt.heads, True) / 1e9
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else 157.3
         line = {
             "metric": METRIC,
@@ -377,8 +398,12 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "DLA-34+DCNv2 multi_pose + pose/shape heads -> sigmoid/NMS/top-100 decode -> "
-                                   "SMPL 6890-vert LBS; 512x512, batch %d per GPU (BASELINE configs[2])" % args.batch,
+            "config": {"workload": ("DLA-34+DCNv2 multi_pose + pose/shape heads -> sigmoid/NMS/top-100 decode -> "
+                                    "SMPL 6890-vert LBS; 512x512, batch %d per GPU (BASELINE configs[2])" % args.batch) if dla else
+                                   ("Hourglass-104 multi_pose -> decode; %dx%d, batch %d per GPU (BASELINE configs[3]: 128 over 8 GPUs = 16)"
+                                    % (size, size, args.batch)) if args.arch == "hourglass" else
+                                   ("ResNet-101-DCN ctdet -> decode; %dx%d, batch %d per GPU (BASELINE configs[4]: 256 over 8 GPUs = 32; "
+                                    "bf16 where the config says fp16)" % (size, size, args.batch)),
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch, "K": 100,
                        "smpl_people_per_image": args.people, "conv_gflop_per_image": round(gflop_img, 2),
                        "parallelism": "dp%d (image shards, one all-gather of dets)" % world,
@@ -386,7 +411,7 @@ def main():
         }
         line["model_tflops"] = round(gflop_img * line["value"] / 1e3 / world, 1)      # per GPU
         if not args.no_roofline:
-            plan = det.model.engine(dev).plan(args.batch, 512, 512)
+            plan = det.model.engine(dev).plan(args.batch, size, size)
             groups = per_kernel_profile(plan, iters=3)
             total_ms = sum(g["ms"] for g in groups.values())
             name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
@@ -417,11 +442,12 @@ def main():
                                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             print("[bench] kernels %s" % json.dumps(line["kernels"]), file=sys.stderr, flush=True)
-            line["dcn_pass2"] = dcn_pass2_fraction(det, images[:2].contiguous(), dev)
-            if world == 1:
+            if dla:
+                line["dcn_pass2"] = dcn_pass2_fraction(det, images[:2].contiguous(), dev)
+            if world == 1 and dla:
                 line["boundary_op"] = boundary_op_times(min(args.batch, 16), dev)
                 print("[bench] boundary_op %s" % json.dumps(line["boundary_op"]), file=sys.stderr, flush=True)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and dla:
             keep = {}
             line["cpu_baseline"] = cpu_baseline(opt, sd, keep=keep)
             # the checker's second use: the same 2 images through the GPU path, indices compared with the oracle's
