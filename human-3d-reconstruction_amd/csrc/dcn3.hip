@@ -296,6 +296,8 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     {
         int my_off[5];
         typename X::geo my_geo[5];
+        bool my_want[5];
+        uint32_t my_hw[5];
         int my_pm = 0;
         const int tb = h ? 5 : 0;
 #pragma unroll
@@ -323,29 +325,42 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                     want = true;
                 }
             }
-            if constexpr (NP > 0) {
-                const unsigned long long m = __ballot(want);
-                if (m) {                                             // wave-uniform: one LDS atomic per wave and tap
-                    int base = 0;
-                    if (l == 0) base = __hip_atomic_fetch_add(reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16), __popcll(m),
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (want && slot < NP) {
-                        if constexpr (sizeof(T) == 2)
-                            *reinterpret_cast<u32x4 *>(smem + C::LDS_MAIN + slot * 16) =
-                                u32x4{((uint32_t)hl << 16) | ((uint32_t)wl & 0xffffu), g.w01, g.w23, 0u};
-                        off = slot * C::PSLOT - C::PB;               // the patch pixel, relative to the apron base
-                        if constexpr (sizeof(T) == 2) { g.w01 = 0x00003c00u; g.w23 = 0u; }   // (1, 0 | 0, 0): the blend is done when the patch is filled
-                        my_pm |= 1 << u;
-                        want = false;
-                    }
-                }
-            }
-            if (want) { slow = true; g = X::zero_geo(); }
+            my_want[u] = want;
+            my_hw[u] = ((uint32_t)hl << 16) | ((uint32_t)wl & 0xffffu);
             my_off[u] = off;
             my_geo[u] = g;
         }
+        if constexpr (NP > 0) {
+            // patch slots: ONE LDS atomic per wave for all five taps (the slots of tap u follow those of taps < u)
+            unsigned long long m[5];
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { m[u] = __ballot(my_want[u]); cnt += __popcll(m[u]); }
+            if (cnt) {                                               // wave-uniform
+                int base = 0;
+                if (l == 0) base = __hip_atomic_fetch_add(reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16), cnt,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
+                    base += __popcll(m[u]);
+                    if (my_want[u] && slot < NP) {
+                        if constexpr (sizeof(T) == 2) {
+                            *reinterpret_cast<u32x4 *>(smem + C::LDS_MAIN + slot * 16) = u32x4{my_hw[u], my_geo[u].w01, my_geo[u].w23, 0u};
+                            my_geo[u].w01 = 0x00003c00u;             // (1, 0 | 0, 0): the blend is done when the patch is filled
+                            my_geo[u].w23 = 0u;
+                        }
+                        my_off[u] = slot * C::PSLOT - C::PB;         // the patch pixel, relative to the apron base
+                        my_pm |= 1 << u;
+                        my_want[u] = false;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u)
+            if (my_want[u]) { slow = true; my_geo[u] = X::zero_geo(); }
         if constexpr (NP > 0) {
             const int o_pm = __shfl_xor(my_pm, 32);
             pmask = h == 0 ? (my_pm | (o_pm << 5)) : (o_pm | (my_pm << 5));
@@ -365,22 +380,26 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     }
 
     // ---- patches: thread `tid` owns the 16-byte unit tid % VPP of list entry tid / VPP for the whole of phase B ----------
-    [[maybe_unused]] int pvoff[4] = {0x7ffffff0, 0x7ffffff0, 0x7ffffff0, 0x7ffffff0};
+    [[maybe_unused]] int pbase = 0, pok = 0;       // byte offset of corner (hl, wl) of my entry's unit; bit k of pok: corner k inside the image
     [[maybe_unused]] typename X::geo pgeo = X::zero_geo();
     [[maybe_unused]] bool phas = false;
+    [[maybe_unused]] bool overflow = false;
     if constexpr (NP > 0) {
         __syncthreads();                                                 // the list is complete
-        const int nsl = min(*reinterpret_cast<const int *>(smem + C::LDS_MAIN + NP * 16), NP);
+        const int nwant = *reinterpret_cast<const int *>(smem + C::LDS_MAIN + NP * 16);
+        overflow = nwant > NP;                                           // workgroup-uniform: some sample found no slot
+        const int nsl = min(nwant, NP);
         const int ps = tid / C::VPP, pv = tid - ps * C::VPP;
         phas = ps < nsl;
         if (phas) {
             const u32x4 d = *reinterpret_cast<const u32x4 *>(smem + C::LDS_MAIN + ps * 16);
             const int hl = (int)d[0] >> 16, wl = (int)(short)(d[0] & 0xffffu);
             if constexpr (sizeof(T) == 2) { pgeo.w01 = d[1]; pgeo.w23 = d[2]; }
+            pbase = ((hl * a.W + wl) * a.in_cs) * ES + pv * 16;          // (may be negative: only used for corners inside the image)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int yy = hl + (k >> 1), xx = wl + (k & 1);
-                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) pvoff[k] = ((yy * a.W + xx) * a.in_cs) * ES + pv * 16;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) pok |= 1 << k;
             }
         }
     }
@@ -392,7 +411,10 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             if (H3D_DBG(a) & 16) return;
             const int c0 = (s - nchunks) * CK;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pst[k] = dcn3_patch_corner(img, img_bytes, pvoff[k], c0 * ES);   // idle threads: out of range, zeros
+            for (int k = 0; k < 4; ++k) {
+                const int voff = pbase + ((k & 1) + (k >> 1) * a.W) * a.in_cs * ES;
+                pst[k] = dcn3_patch_corner(img, img_bytes, ((pok >> k) & 1) ? voff : 0x7ffffff0, c0 * ES);   // idle threads / corners outside: zeros
+            }
         }
     };
     auto patch_commit = [&](char *s_h) {
@@ -406,6 +428,11 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         }
     };
 
+    // Everything from here to the stores, as a function of "is pass 2 compiled in": with patches (NP > 0) a tile needs
+    // pass 2 only when it ran out of slots, which is known NOW (workgroup-uniform) -- and only pass 2 reads the phase-A
+    // accumulators `aoffs` again.  Instantiated twice, the common branch does not keep them alive through phase B (they
+    // were spilled around it: 13 scratch stores + loads per thread and tile, half of the kernel's HBM write traffic).
+    auto tail = [&](auto P2) {
     H3D_STAMP(blockIdx.x, 2);
     // ================= phase B: deformable contraction (branch-free, apron samples) ==================
     f32x16 acc[MT][1];
@@ -476,7 +503,28 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
 
     H3D_STAMP(blockIdx.x, 3);
     // ================= pass 2 (rare): samples whose corners left the apron ===========================
-    if (__syncthreads_or(slow ? 1 : 0)) {
+    bool do_p2 = false;
+    if constexpr (decltype(P2)::value) do_p2 = NP > 0 ? overflow : (bool)__syncthreads_or(slow ? 1 : 0);
+    if constexpr (decltype(P2)::value) if (do_p2) {
+        if constexpr (D2 && MT < 4) {
+            // Under the 128-VGPR cap the phase-A accumulators would be spilled around phase B just for this rare path
+            // (13 scratch stores + loads per thread and tile: half of the kernel's HBM write traffic).  Recomputed instead:
+            // the offset convolution once more, unpipelined -- only tiles that ran out of patch slots come here.
+#pragma unroll
+            for (int i = 0; i < 16; ++i) aoffs[i] = 0.f;
+            for (int s = 0; s < nchunks; ++s) {
+                __syncthreads();
+                issue_w(s);
+                load2(s, I0);
+                store2(I0);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                __syncthreads();
+                computeA(s);
+            }
+            const float *bo = a.bias + a.wrows;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
+        }
         for (int c0 = 0; c0 < a.Cin; c0 += CK) {
             __syncthreads();
             if constexpr (WDMA) {
@@ -548,6 +596,16 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
     } else {
         tile_epilogue<T, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    }
+    };
+    // (only where registers allow: under the 128-VGPR cap of the two-workgroups-per-CU variants the second copy of
+    //  phase B made the allocation worse -- 64 -> 64 @128x128: 0.238 -> 0.283 ms -- while the 128-channel variants gained
+    //  13-18 %: 0.184 -> 0.160 ms on 256 -> 256 @32x32)
+    if constexpr (NP > 0 && MT >= 4) {
+        if (overflow) tail(std::true_type{});
+        else tail(std::false_type{});
+    } else {
+        tail(std::true_type{});
     }
     H3D_STAMP(blockIdx.x, 5);
 }
