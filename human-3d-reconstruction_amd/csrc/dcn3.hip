@@ -525,6 +525,80 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
 #pragma unroll
             for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
         }
+        if constexpr (D2) {
+            // The tile ran out of patch slots.  Pass 2 as round 1 wrote it takes one global round trip per tap and chunk
+            // (9 x Cin/16 serialised latencies: 5x the tile's time at 5 % of the samples).  Here the geometry of the nine taps
+            // is computed once, and per chunk the corner loads of TB taps are in flight together (range-checked buffer
+            // loads: lanes without a pending sample read zeros, no branch); a wave skips the taps none of its lanes needs.
+            // Registers spill in this branch under the 128-VGPR cap -- it is the rare path.
+            constexpr int TB = 3;
+            int qb[9], qok[9], wmask = 0;
+            typename X::geo qg[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ti = tap / 3, tj = tap - ti * 3;
+                const int src = (tap < 5) ? r : r + 32, u = (tap < 5) ? tap : tap - 5;
+                const float d_h = __shfl(aoffs[3 * u], src), d_w = __shfl(aoffs[3 * u + 1], src), d_m = __shfl(aoffs[3 * u + 2], src);
+                const float h_im = (float)(oy - 1 + ti) + d_h, w_im = (float)(ox - 1 + tj) + d_w;
+                qb[tap] = 0; qok[tap] = 0; qg[tap] = X::zero_geo();
+                bool pend = false;
+                if (live && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+                    const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+                    const int ry = hl - hy0, rx = wl - hx0;
+                    if (!(ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH) && !((pmask >> tap) & 1)) {
+                        pend = true;
+                        const float lh = h_im - (float)hl, lw = w_im - (float)wl;
+                        const float hh = 1.f - lh, hw = 1.f - lw;
+                        const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                        qg[tap] = X::make_geo(w4, dcn2_sigmoid(d_m));
+                        qb[tap] = ((hl * a.W + wl) * a.in_cs + 8 * h) * ES;
+                        qok[tap] = (hl >= 0 && wl >= 0 ? 1 : 0) | (hl >= 0 && wl + 1 <= a.W - 1 ? 2 : 0) |
+                                   (hl + 1 <= a.H - 1 && wl >= 0 ? 4 : 0) | (hl + 1 <= a.H - 1 && wl + 1 <= a.W - 1 ? 8 : 0);
+                    }
+                }
+                if (__any(pend)) wmask |= 1 << tap;
+            }
+            const int pxb = a.in_cs * ES, rowb = a.W * pxb;
+            u32x4 pv[TB][4];
+            for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+                auto fetch = [&](int t0) {
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        if (!((wmask >> (t0 + j)) & 1)) continue;                // wave-uniform
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            pv[j][k] = dcn3_patch_corner(img, img_bytes, ((qok[t0 + j] >> k) & 1) ? qb[t0 + j] + (k & 1) * pxb + (k >> 1) * rowb : 0x7ffffff0, c0 * ES);
+                    }
+                };
+                __syncthreads();
+                dcn3_issue_w<C::WPIECES>(a.w, main_bytes, s_w, ((c0 / CK) * a.G + (int)blockIdx.y * MT) * C::WGRP, l * 16, wvu);
+                fetch(0);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                __syncthreads();
+#pragma unroll
+                for (int t0 = 0; t0 < 9; t0 += TB) {
+                    typename X::frag fbs[TB];
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        if (!((wmask >> (t0 + j)) & 1)) continue;
+                        typename X::frag v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k].v = __builtin_bit_cast(half8_t, X::convert16(pv[j][k]));
+                        fbs[j] = X::blend(v, qg[t0 + j]);
+                    }
+                    if (t0 + TB < 9) fetch(t0 + TB);                               // the next taps fly while these are multiplied
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        if (!((wmask >> (t0 + j)) & 1)) continue;
+                        typename X::frag fa[MT];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + ((t0 + j) * CK) * SS);
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fbs[j]);
+                    }
+                }
+            }
+        } else
         for (int c0 = 0; c0 < a.Cin; c0 += CK) {
             __syncthreads();
             if constexpr (WDMA) {
@@ -684,6 +758,10 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
         // > 64: one workgroup per CU has the LDS for a margin-4 apron (26 x 26 pixels)
         if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 2, true, 256>(a, st);
         if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 2, true, 256>(a, st);
+        // a layer whose 128-channel workgroups would leave CUs idle (16 x 16 maps at batch 64: 128 workgroups on 256 CUs)
+        // runs 64-channel workgroups instead: twice the gather / blend work, on CUs that had nothing to do
+        const long wgs4 = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
+        if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) return launch_dcn3_cfg<bf16_t, 2, 16, 2, true, 256>(a, st);
         return launch_dcn3_cfg<bf16_t, 4, 16, 4, true, 256>(a, st);
     }
     if (op.dtype == H3D_BF16) {

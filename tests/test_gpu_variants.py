@@ -107,8 +107,10 @@ DCN_CASES = [
     ("stream", "bf16", 0, 2, 64, 64, 40, 24, 6.0),         #   ... more samples leave the apron than a tile has slots: patches AND pass 2
     ("stream", "bf16", 0, 1, 64, 64, 16, 16, 40.0),        #   ... nearly every sample outside the apron or the image
     ("stream", "bf16", 0, 1, 64, 32, 20, 20, 12.0),        # dcn3<bf16,1,16,2,WDMA,256>
-    ("stream", "bf16", 0, 1, 128, 128, 16, 32, 3.0),       # dcn3<bf16,4,16,4,WDMA,256>: margin-4 apron
-    ("stream", "bf16", 0, 1, 256, 256, 24, 24, 8.0),
+    ("stream", "bf16", 0x400, 1, 128, 128, 16, 32, 3.0),   # dcn3<bf16,4,16,4,WDMA,256>: margin-4 apron (0x400: also for a small grid)
+    ("stream", "bf16", 0x400, 1, 256, 256, 24, 24, 8.0),
+    ("stream", "bf16", 0, 1, 256, 256, 16, 16, 3.0),       # small grid: 64-channel workgroups on a 256-channel layer (grid.y = 4)
+    ("stream", "bf16", 0, 12, 128, 128, 64, 64, 0.5),      # >= 192 workgroups: the 128-channel variant without an override
     ("stream", "bf16", 0, 1, 48, 64, 20, 20, 3.0),         # Cin = 16 (mod 32): falls back to the configuration without patches
     ("stream", "bf16", 0x1000, 2, 128, 64, 24, 40, 0.5),   # round 1's configurations: dcn3<bf16,2,16,1,WDMA,0>
     ("stream", "bf16", 0x1000, 1, 64, 32, 20, 20, 12.0),   # dcn3<bf16,1,16,1,WDMA,0>
@@ -169,8 +171,12 @@ def test_dcn_fused_variant_matches_oracle(case):
 
 
 def test_dcn_auto_selection_reaches_mt4():
-    c = [c for c in DCN_CASES if c[3] == 12][0]
+    c = [c for c in DCN_CASES if c[3] == 12 and c[0] == "fused"][0]
     assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 4, 16, 2, 2, false, 0>"
+    c = [c for c in DCN_CASES if c[3] == 12 and c[0] == "stream"][0]
+    assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 4, 16, 4, 2, true, 256>"
+    c = [c for c in DCN_CASES if c[0] == "stream" and c[2] == 0 and c[4:8] == (256, 256, 16, 16)][0]      # 1 tile x 2 groups: small grid
+    assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 2, 16, 2, 2, true, 256>"
 
 
 # ---- the bench plan's kernel set -----------------------------------------------------------------------------
