@@ -107,9 +107,53 @@ class DCN(DCNv2):
             self.conv_offset_mask.weight.zero_()
             self.conv_offset_mask.bias.zero_()
 
+    def _fused_ok(self, input):
+        return (self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and self.dilation == (1, 1)
+                and self.deformable_groups == 1 and self.in_channels % 16 == 0 and input.is_cuda
+                and input.dtype == torch.float32 and input.dim() == 4)
+
+    def _packed(self, device):
+        """Weights in the layout of the fused DeformConv kernel (csrc/dcn3.hip, fp32), cached until a parameter changes."""
+        from . import engine
+        ps = (self.weight, self.bias, self.conv_offset_mask.weight, self.conv_offset_mask.bias)
+        key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (str(device),)
+        if getattr(self, "_pack_key", None) != key:
+            pw = object.__new__(engine.PackedWeights)
+            pw.sd = {"w": self.weight.detach().float().cpu(), "b": self.bias.detach().float().cpu(),
+                     "ow": self.conv_offset_mask.weight.detach().float().cpu(), "ob": self.conv_offset_mask.bias.detach().float().cpu()}
+            pw.dtype, pw.device, pw.t = "f32", torch.device(device), {}
+            wp, bp, cout, cin, k, rows = pw.conv("w", "b", None, as_half=True)
+            wo, bo = pw.offset_conv("ow", "ob", rows)
+            self._pack = (wp, wo, torch.cat([bp.cpu(), bo]).contiguous().to(device), rows)
+            self._pack_key = key
+        return self._pack
+
     def forward(self, input):
-        # the small offset/mask conv of a stand-alone DCN goes through torch here; inside the
-        # DLA-34 engine (engine.py) it is the HIP conv kernel writing NHWC fp32 offsets directly
+        """conv_offset_mask -> chunk/cat/sigmoid -> dcn_v2_conv (dcn_v2.py:118-128).  In the configuration the model uses
+        (model.py:355) all of it is ONE launch of the fused DeformConv kernel in fp32 parity mode (offsets and mask never
+        reach memory); other configurations compute the offset conv with torch and call the operator."""
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): call under torch.no_grad()")
+        if not input.is_cuda:
+            raise RuntimeError("Not implemented on the CPU")
+        if self._fused_ok(input):
+            from ._lib import H3dOp
+            x = input.contiguous()
+            B, C, H, W = x.shape
+            wp, wo, bias, rows = self._packed(x.device)
+            with torch.cuda.device(x.device):
+                xn = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+                out = torch.empty(B, self.out_channels, H, W, dtype=torch.float32, device=x.device)
+                L = _lib.lib()
+                _lib.check(L.h3d_nchw_f32_to_nhwc(_lib.ptr(x), _lib.ptr(xn), _lib.H3D_F32, B, C, H, W, C, _lib.stream_ptr()), "DCN: to NHWC")
+                op = H3dOp()
+                op.kind, op.dtype, op.B, op.H, op.W, op.Ho, op.Wo = _lib.OP_DCN_FUSED, _lib.H3D_F32, B, H, W, H, W
+                op.in_, op.in2, op.w, op.bias, op.out = xn.data_ptr(), wo.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr()
+                op.Cin, op.in_cs, op.Cout, op.out_cs, op.ksize, op.stride, op.relu = C, C, self.out_channels, self.out_channels, 3, 1, 0
+                op.out_mode, op.wrows = _lib.OUT_NCHW_F32, rows
+                arr = (H3dOp * 1)(op)
+                _lib.check(L.h3d_run_ops(arr, 1, _lib.stream_ptr()), "DCN.forward")
+            return out
         out = self.conv_offset_mask(input)
         o1, o2, mask = torch.chunk(out, 3, dim=1)
         offset = torch.cat((o1, o2), dim=1)

@@ -129,6 +129,28 @@ def test_dcn_module_fresh_is_half_conv():
     assert set(mod.state_dict()) == {"weight", "bias", "conv_offset_mask.weight", "conv_offset_mask.bias"}
 
 
+def test_dcn_module_model_configuration_is_one_fused_launch_and_matches_oracle():
+    # DCN(chi, cho, (3,3), 1, 1, 1, 1) as model.py:355 builds it, with a trained-like conv_offset_mask: the stand-alone module
+    # runs the fused DeformConv kernel in fp32 (no torch conv), checked against DCN.forward restated (oracle.dcn_module_forward)
+    torch.manual_seed(0)
+    mod = dcn_v2.DCN(64, 48, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV).eval()
+    with torch.no_grad():
+        mod.conv_offset_mask.weight.copy_(rnd("ow", (27, 64, 3, 3)).to(DEV) * 0.08)
+        mod.conv_offset_mask.bias.copy_(rnd("ob", (27,)).to(DEV) * 0.3)
+        mod.bias.copy_(rnd("b", (48,)).to(DEV))
+    x = rnd("x", (2, 64, 20, 28))
+    with torch.no_grad():
+        y = mod(x.to(DEV)).cpu()
+        ref = odcn.dcn_module_forward(x, mod.weight.cpu(), mod.bias.cpu(), mod.conv_offset_mask.weight.cpu(),
+                                      mod.conv_offset_mask.bias.cpu(), acc_dtype=torch.float64)
+        np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=0, atol=2e-4)
+        # a parameter update invalidates the cached pack
+        mod.bias.add_(1.0)
+        y2 = mod(x.to(DEV)).cpu()
+    np.testing.assert_allclose(y2.numpy(), (ref + 1.0).numpy(), rtol=0, atol=2e-4)
+    assert mod._fused_ok(x.to(DEV)) and not dcn_v2.DCN(16, 8, (3, 3), 2, 1).to(DEV)._fused_ok(x.to(DEV))
+
+
 NET_CASES = [(2, 64, 64, 16, 16), (1, 128, 64, 24, 40), (1, 256, 128, 16, 16), (1, 512, 256, 8, 8), (1, 32, 16, 20, 20)]
 
 
