@@ -78,7 +78,7 @@ __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, cons
     }
 }
 
-template <int MT, int WAVES, int EPI, int S = 1, int SLOTS = 2, int NT = 1>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
+template <int MT, int WAVES, int EPI, int S = 1, int SLOTS = 2, int NT = 1, bool PIPE = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
 __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 {
     using C = Conv2Cfg<MT, WAVES, S, SLOTS, NT>;
@@ -158,6 +158,31 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
         cslot = cslot + 1 == SLOTS ? 0 : cslot + 1;
         pslot = pslot + 1 == SLOTS ? 0 : pslot + 1;
         if (H3D_DBG(a) & 2) continue;
+        if constexpr (PIPE) {
+            // fragments of tap t+1 are read while tap t is multiplied: left to itself hipcc keeps 24 fragment registers and
+            // waits (lgkmcnt(1)) in front of every MFMA pair for a read issued two instructions earlier; with two fragment
+            // sets (40 registers) and the issue order pinned by sched_group_barrier the wait becomes lgkmcnt(MT + NT)
+            typename E::frag fb[2][NT], fa[2][MT];
+            auto rd = [&](int tap, int q) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) fb[q][n] = E::lds_frag(sl + boff + (2 * n * S + dy) * C::ROWB + dx * 48);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[q][m] = E::lds_frag(sl + aoff + m * C::WGRP + tap * 32);
+            };
+            rd(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) rd(tap + 1, (tap + 1) & 1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[tap & 1][m], fb[tap & 1][n]);
+                if (tap + 1 < 9) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            }
+        } else {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - 3 * dy;
@@ -172,6 +197,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 #pragma unroll
                 for (int n = 0; n < NT; ++n) E::mma(acc[m][n], fa[m], fb[n]);
         }
+        }
     }
 
     EpiArgs e;
@@ -185,7 +211,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     }
 }
 
-template <int MT, int WAVES, int S = 1, int SLOTS = 2, int NT = 1>
+template <int MT, int WAVES, int S = 1, int SLOTS = 2, int NT = 1, bool PIPE = false>
 static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
 {
     using C = Conv2Cfg<MT, WAVES, S, SLOTS, NT>;
@@ -197,6 +223,14 @@ static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4)) ? 2 : lean ? 1 : 0;
+    if constexpr (PIPE) {
+        if (epi == 2) {
+            if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d, %d, %d, true>", MT, WAVES, epi, S, SLOTS, NT)) return H3D_OK;
+            hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S, SLOTS, NT, true>), grid, dim3(C::THREADS), 0, st, a);
+            H3D_CHECK_LAUNCH("conv2_kernel");
+            return H3D_OK;
+        }
+    }
     if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d, %d, %d>", MT, WAVES, epi, S, SLOTS, NT)) return H3D_OK;
     if (epi == 2)
         hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
@@ -262,17 +296,23 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
         case 0x5408: return launch_conv2_cfg<4, 8, 1, 1>(a, st);      // 0x5...: ONE ring slot
         case 0x5208: return launch_conv2_cfg<2, 8, 1, 1>(a, st);
         case 0x5108: return launch_conv2_cfg<1, 8, 1, 1>(a, st);
+        case 0x6410: return launch_conv2_cfg<4, 16, 1, 2, 1, true>(a, st);   // 0x6...: fragment reads one tap ahead (PIPE)
+        case 0x6408: return launch_conv2_cfg<4, 8, 1, 2, 1, true>(a, st);
+        case 0x6208: return launch_conv2_cfg<2, 8, 1, 2, 1, true>(a, st);
+        case 0x6404: return launch_conv2_cfg<4, 4, 1, 2, 1, true>(a, st);
         case 0x1: break;           // 1 = auto configuration (used with the ablation bits)
         default: H3D_FAIL(H3D_ERR_ARG, "conv_stream: unknown tuning override %#x", op.reserved);
         }
     }
+    // the three configurations a batch-64 plan selects read their fragments one tap ahead (PIPE): -2 % each (tools/ab_conv.py
+    // 6410 6408 6208, same process: 0.548 -> 0.538 ms on the seven 128 -> 128 @64x64 launches, 0.296 -> 0.289 on 64 -> 64 @128x128)
     if (gq >= 4) {
-        if (op.Ho % 32 == 0 && nblk(32, 4) >= 256) return launch_conv2_cfg<4, 16>(a, st);   // 16 waves: 32 x 16 px share one weight stream
-        if (nblk(16, 4) >= 256) return launch_conv2_cfg<4, 8>(a, st);
+        if (op.Ho % 32 == 0 && nblk(32, 4) >= 256) return launch_conv2_cfg<4, 16, 1, 2, 1, true>(a, st);   // 16 waves: 32 x 16 px share one weight stream
+        if (nblk(16, 4) >= 256) return launch_conv2_cfg<4, 8, 1, 2, 1, true>(a, st);
         return launch_conv2_cfg<4, 4>(a, st);
     }
     if (gq >= 2) {
-        if (nblk(16, 2) >= 256) return launch_conv2_cfg<2, 8>(a, st);
+        if (nblk(16, 2) >= 256) return launch_conv2_cfg<2, 8, 1, 2, 1, true>(a, st);
         return launch_conv2_cfg<2, 4>(a, st);
     }
     if (op.Cin == 16 && nblk(16, 1) >= 256) return launch_conv2_cfg<1, 8, 1, 1>(a, st);   // one stage: no ring

@@ -35,6 +35,10 @@ CONV2_CASES = [
     (0x5108, 2, 16, 16, 40, 40, 1, True, False, 0, 0),     # <1,8,1,1>: one stage, no ring
     (0x5208, 1, 64, 64, 24, 24, 1, True, True, 0, 0),      # <2,8,1,1>: one ring slot
     (0x5408, 1, 64, 128, 24, 24, 1, True, False, 0, 0),    # <4,8,1,1>
+    (0x6410, 2, 64, 128, 40, 24, 1, True, True, 0, 0),     # <4,16,PIPE>: fragment reads one tap ahead, forced on a ragged tensor
+    (0x6408, 1, 128, 128, 24, 40, 1, True, False, 0, 0),   # <4,8,PIPE>
+    (0x6208, 2, 64, 64, 24, 40, 1, True, True, 64, 64),    # <2,8,PIPE> inside concat buffers
+    (0x6404, 1, 96, 128, 12, 24, 1, False, False, 0, 0),   # <4,4,PIPE>
     (0x3208, 1, 96, 64, 24, 24, 1, True, False, 0, 0),     # three ring slots (counted vmcnt wait)
     (0x3108, 1, 96, 32, 24, 24, 1, True, False, 0, 0),
     (0x3404, 1, 96, 128, 12, 24, 1, True, False, 0, 0),
@@ -85,7 +89,7 @@ def test_conv_stream_variant_matches_torch(case):
 
 def test_conv_stream_auto_selection_reaches_the_wide_variants():
     names = {_conv2_built(c)[4].name for c in CONV2_CASES if c[0] == 0 and c[6] == 1}
-    assert {"conv2_kernel<4, 16, 2, 1, 2, 1>", "conv2_kernel<4, 8, 2, 1, 2, 1>", "conv2_kernel<2, 8, 2, 1, 2, 1>"} <= names, names
+    assert {"conv2_kernel<4, 16, 2, 1, 2, 1, true>", "conv2_kernel<4, 8, 2, 1, 2, 1, true>", "conv2_kernel<2, 8, 2, 1, 2, 1, true>"} <= names, names
 
 
 # ---- csrc/dcn3.hip, csrc/dcn4.hip ------------------------------------------------------------------------
