@@ -14,6 +14,9 @@ What is recorded
   decode_*.npz         reference `_nms/_topk/_topk_channel/multi_pose_decode/ctdet_decode`
                        (models/decode.py) outputs on synthetic post-sigmoid heads.
   sigmoid.npz          reference `_sigmoid` (models/utils.py:8-10) on a logit ramp.
+  utils_flip_gather.npz  reference `_gather_feat`, `_transpose_and_gather_feat` (models/utils.py:12-27) and the flip-test helpers
+                       `flip_tensor`, `flip_lr`, `flip_lr_off` (models/utils.py:29-51) on synthetic maps (inputs are
+                       regenerated from h3d_amd.synth by the tests; the fixture holds outputs only).
 """
 import json
 import os
@@ -111,9 +114,32 @@ def gen_sigmoid():
     np.savez_compressed(os.path.join(OUT, "sigmoid.npz"), x=x, y=y.numpy())
 
 
+FLIP_IDX = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]      # opts.py:250 (COCO left/right joints)
+
+
+def gen_utils():
+    hm = torch.from_numpy(synth.uniform("flip_hm", (2, 17, 6, 10), -1.0, 1.0, 11))
+    hps = torch.from_numpy(synth.uniform("flip_hps", (2, 34, 6, 10), -1.0, 1.0, 11))
+    feat = torch.from_numpy(synth.uniform("gather_feat", (2, 5, 6, 7), -1.0, 1.0, 11))
+    ind = torch.tensor([[0, 41, 7, 7], [3, 3, 20, 40]], dtype=torch.int64)
+    rec = {
+        "flip_tensor": ref_utils.flip_tensor(hm).numpy(),
+        "flip_lr": ref_utils.flip_lr(hm, FLIP_IDX).numpy(),
+        "flip_lr_off": ref_utils.flip_lr_off(hps, FLIP_IDX).numpy(),
+        "transpose_and_gather": ref_utils._transpose_and_gather_feat(feat, ind).numpy(),
+        "gather": ref_utils._gather_feat(feat.permute(0, 2, 3, 1).contiguous().view(2, 42, 5), ind).numpy(),
+    }
+    np.savez_compressed(os.path.join(OUT, "utils_flip_gather.npz"), **rec)
+    print("utils_flip_gather:", {k: v.shape for k, v in rec.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--utils-only" in sys.argv:
+        gen_utils()
+        raise SystemExit(0)
     gen_sigmoid()
+    gen_utils()
     gen_decode()
     gen_dla()
     print("golden vectors written to", OUT)

@@ -206,3 +206,16 @@ def test_ctdet_task_entry_end_to_end():
     assert sum(len(v) for v in got[0].values()) == 40
     again = ctdet_post_process(res["dets"], c, s, 32, 40, 80)
     assert again == got
+
+
+def test_gather_and_flip_helpers_match_reference_golden(golden_dir):
+    # h3d_gather_feat / the device-resident flip helpers against OUTPUTS OF THE REFERENCE's models/utils.py:12-51
+    from test_oracle_golden import FLIP_IDX, _utils_inputs
+    g = np.load(os.path.join(golden_dir, "utils_flip_gather.npz"))
+    hm, hps, feat, ind = _utils_inputs()
+    fd, idd = torch.from_numpy(feat).to(DEV), torch.from_numpy(ind).to(DEV)
+    assert np.array_equal(utils._transpose_and_gather_feat(fd, idd).cpu().numpy(), g["transpose_and_gather"])
+    assert np.array_equal(utils._gather_feat(fd.permute(0, 2, 3, 1).reshape(2, 42, 5).contiguous(), idd).cpu().numpy(), g["gather"])
+    assert np.array_equal(utils.flip_tensor(torch.from_numpy(hm).to(DEV)).cpu().numpy(), g["flip_tensor"])
+    assert np.array_equal(utils.flip_lr(torch.from_numpy(hm).to(DEV), FLIP_IDX).cpu().numpy(), g["flip_lr"])
+    assert np.array_equal(utils.flip_lr_off(torch.from_numpy(hps).to(DEV), FLIP_IDX).cpu().numpy(), g["flip_lr_off"])

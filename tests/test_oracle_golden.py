@@ -109,3 +109,31 @@ def test_ctdet_decode_matches_reference(golden_dir):
         np.testing.assert_array_equal(clses[b], g["topk_clses"][b])
     dets = odec.ctdet_decode(hm, wh, reg=reg, K=K)
     np.testing.assert_array_equal(dets, g["dets"])
+
+
+FLIP_IDX = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
+
+
+def _utils_inputs():
+    hm = synth.uniform("flip_hm", (2, 17, 6, 10), -1.0, 1.0, 11)
+    hps = synth.uniform("flip_hps", (2, 34, 6, 10), -1.0, 1.0, 11)
+    feat = synth.uniform("gather_feat", (2, 5, 6, 7), -1.0, 1.0, 11)
+    ind = np.array([[0, 41, 7, 7], [3, 3, 20, 40]], dtype=np.int64)
+    return hm, hps, feat, ind
+
+
+def test_flip_and_gather_restatements_match_reference_outputs(golden_dir):
+    # models/utils.py:12-51 run in the build container (oracle/gen_golden.py --utils-only): pins oracle/decode.py's
+    # flip_tensor / flip_lr / flip_lr_off / gather_nchw bit for bit (pure data movement)
+    g = np.load(os.path.join(golden_dir, "utils_flip_gather.npz"))
+    hm, hps, feat, ind = _utils_inputs()
+    assert np.array_equal(odec.flip_tensor(hm), g["flip_tensor"])
+    assert np.array_equal(odec.flip_lr(hm, FLIP_IDX), g["flip_lr"])
+    assert np.array_equal(odec.flip_lr_off(hps, FLIP_IDX), g["flip_lr_off"])
+    assert np.array_equal(odec.gather_nchw(feat, ind), g["transpose_and_gather"])
+    assert np.array_equal(g["gather"], g["transpose_and_gather"])
+    # and the product's host helpers (torch, device-agnostic data movement) against the same fixtures
+    from h3d_amd import utils
+    assert np.array_equal(utils.flip_tensor(torch.from_numpy(hm)).numpy(), g["flip_tensor"])
+    assert np.array_equal(utils.flip_lr(torch.from_numpy(hm), FLIP_IDX).numpy(), g["flip_lr"])
+    assert np.array_equal(utils.flip_lr_off(torch.from_numpy(hps), FLIP_IDX).numpy(), g["flip_lr_off"])
