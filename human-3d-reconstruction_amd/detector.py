@@ -78,11 +78,12 @@ class MultiPoseDetector:
             self.smpl_model = _smpl.SMPLModel.synthetic()
 
     @torch.no_grad()
-    def run(self, images, meta=None):
+    def run(self, images, meta=None, slot=0):
         """images [B,3,H,W] fp32 on the device -> dict(dets [B,K,40], inds [B,K], optional
-        verts [B,N,6890,3] / joints, optional results [B,K,39] in image px when meta={'c','s'})."""
+        verts [B,N,6890,3] / joints, optional results [B,K,39] in image px when meta={'c','s'}).
+        slot: plan-buffer copy (model.forward); consecutive batches issued on different HIP streams alternate slots."""
         opt = self.opt
-        out = self.model(images)[-1]          # (Hourglass returns one dict per stack: inference uses the last)
+        out = self.model(images, slot)[-1]    # (Hourglass returns one dict per stack: inference uses the last)
         dets, aux = decode.multi_pose_decode_logits(
             out["hm"], out["wh"], out["hps"], reg=out.get("reg") if opt.reg_offset else None,
             hm_hp=out.get("hm_hp") if opt.hm_hp else None,
@@ -120,12 +121,12 @@ class CtdetDetector:
         self.model.to(self.device).eval()
 
     @torch.no_grad()
-    def run(self, images, meta=None):
+    def run(self, images, meta=None, slot=0):
         """images [B,3,H,W] fp32 on the device -> dict(dets [B,K,6] = box, score, class; heads; optional results =
         the reference's per-image {class id (1-based): [[x1, y1, x2, y2, score], ...]} when meta={'c','s'})."""
         from .utils import _sigmoid
         opt = self.opt
-        out = self.model(images)[-1]
+        out = self.model(images, slot)[-1]
         hm = _sigmoid(out["hm"].clone())
         dets = decode.ctdet_decode(hm, out["wh"], reg=out.get("reg") if opt.reg_offset else None,
                                    cat_spec_wh=opt.cat_spec_wh, K=opt.K)

@@ -736,21 +736,23 @@ class DLAEngine:
     def _flags(self):
         return {k: getattr(self, k) for k in Plan.FLAGS}
 
-    def plan(self, B, H, W):
-        key = (B, H, W)
+    def plan(self, B, H, W, slot=0):
+        """slot: independent copies of the plan (own activation and output buffers, shared packed weights) so that
+        consecutive batches can be in flight on different HIP streams (bench.py --pipeline)."""
+        key = (B, H, W) if slot == 0 else (B, H, W, slot)
         if key not in self.plans:
             with torch.cuda.device(self.device):
                 self.plans[key] = Plan(self.pw, B, H, W, **self._flags())
         return self.plans[key]
 
-    def forward(self, images):
+    def forward(self, images, slot=0):
         _lib.require_cuda(images)
         if images.dim() != 4 or images.shape[1] != 3:
             raise RuntimeError("expected images [B,3,H,W], got %s" % (tuple(images.shape),))
         B, _, H, W = images.shape
         if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 8 and self.pw.arch == "dla34":
             return self._forward_split(images)
-        plan = self.plan(B, H, W)
+        plan = self.plan(B, H, W, slot)
         with torch.cuda.device(self.device):
             if images.dtype == torch.float32 and images.is_contiguous():
                 plan.op_array[0].in_ = images.data_ptr()       # read the caller's batch in place

@@ -117,16 +117,18 @@ class DLASeg(nn.Module):
             self._engine = DLAEngine(sd, self.heads, self.use_dcn, self.compute_dtype, device, self.head_conv, self.arch_name)
         return self._engine
 
-    def forward(self, x):
+    def forward(self, x, slot=0):
+        """slot (extension): which copy of the launch plan's buffers to use; batches on different HIP streams must use
+        different slots (the head tensors returned are the plan's output buffers)."""
         if self.training:
             raise RuntimeError("h3d_amd.DLASeg is inference-only (BatchNorm is folded): call .eval()")
         if not x.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
         with torch.no_grad():
-            out = self.engine(x.device)(x)
-            return self._wrap(x, out)
+            out = self.engine(x.device).forward(x, slot)
+            return self._wrap(x, out, slot)
 
-    def _wrap(self, x, out):
+    def _wrap(self, x, out, slot=0):
         return [dict(out)]
 
 
@@ -149,9 +151,9 @@ class HourglassNet(DLASeg):
     def _shapes(self):
         return arch_hg.state_dict_shapes(self.heads)
 
-    def _wrap(self, x, out):
+    def _wrap(self, x, out, slot=0):
         B, _, H, W = x.shape
-        plan = self.engine(x.device).plan(B, H, W)
+        plan = self.engine(x.device).plan(B, H, W, slot)
         return [dict(o) for o in plan.all_outputs]
 
 

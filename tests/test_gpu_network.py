@@ -388,3 +388,28 @@ def test_forward_is_deterministic_and_batch_position_independent(offset_scale):
         again = m(xs)[0]
         for k in first:
             assert torch.equal(first[k], again[k]), k
+
+
+def test_plan_slots_on_two_streams_give_identical_results():
+    # bench.py --pipeline 2: consecutive batches alternate between two HIP streams, each with its own copy of the plan's
+    # buffers (engine.plan(..., slot)); interleaved launches of both slots must not disturb each other
+    opt = Opt(input_h=128, input_w=192, dtype="bf16", K=40, smpl=True, smpl_people=8)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=1.25)
+    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    xa = torch.from_numpy(synth.synth_images(4, 128, 192, seed=1)).to(DEV)
+    xb = torch.from_numpy(synth.synth_images(4, 128, 192, seed=2)).to(DEV)
+    ra = {k: v.clone() for k, v in det.run(xa).items() if k in ("dets", "verts")}
+    rb = {k: v.clone() for k, v in det.run(xb).items() if k in ("dets", "verts")}
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for i in range(6):
+        with torch.cuda.stream(streams[i % 2]):
+            r = det.run(xa if i % 2 == 0 else xb, slot=i % 2)
+            outs.append((r["dets"].clone(), r["verts"].clone()))
+    torch.cuda.synchronize()
+    for i, (d, v) in enumerate(outs):
+        ref = ra if i % 2 == 0 else rb
+        assert torch.equal(d, ref["dets"]) and torch.equal(v, ref["verts"]), i
+    eng = det.model.engine(torch.device(DEV))
+    assert eng.plan(4, 128, 192, 0) is not eng.plan(4, 128, 192, 1)
