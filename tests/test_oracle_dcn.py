@@ -124,3 +124,33 @@ def test_shape_smoke_dg2():
     y = odcn.dcn_v2_forward(x, w, torch.zeros(64), torch.zeros(2, 36, 16, 16),
                             torch.ones(2, 18, 16, 16), 3, 3, 1, 1, 1, 1, 1, 1, 2)
     assert y.shape == (2, 64, 16, 16)
+
+
+def test_sampling_rule_agrees_with_scipy_map_coordinates():
+    """The reference's CUDA DCNv2 cannot be built here, and it has no CPU path: besides the reference's own known answer and the
+    derived identities above, the restatement's whole sampling rule -- bilinear weights from floor(), corners outside the
+    image contribute zero, samples at h_im <= -1 or >= H vanish (dcn_v2_im2col_cuda.cu:25-54, 163-185) -- is cross-checked
+    against an INDEPENDENT implementation: scipy.ndimage.map_coordinates(order=1, mode='grid-constant', cval=0) is exactly
+    "bilinear interpolation of the zero-extended image" (scipy's plain 'constant' does not blend across the edge).  Offsets are large enough to leave the image on every side."""
+    from scipy import ndimage
+    rng = np.random.default_rng(0)
+    B, C, H, W, Co = 2, 3, 9, 11, 4
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = rng.standard_normal((Co, C, 3, 3)).astype(np.float32) * 0.3
+    b = rng.standard_normal(Co).astype(np.float32)
+    off = rng.uniform(-4.0, 4.0, (B, 18, H, W)).astype(np.float32)
+    m = rng.uniform(0.0, 1.0, (B, 9, H, W)).astype(np.float32)
+    got = odcn.dcn_v2_forward(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), torch.from_numpy(off),
+                              torch.from_numpy(m), 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64).numpy()
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    want = np.zeros((B, Co, H, W))
+    for bi in range(B):
+        for t in range(9):
+            i, j = divmod(t, 3)
+            py = ys - 1 + i + off[bi, 2 * t].astype(np.float64)          # channel 2t = dh, 2t+1 = dw (im2col.cu:170-171)
+            px = xs - 1 + j + off[bi, 2 * t + 1].astype(np.float64)
+            for c in range(C):
+                s = ndimage.map_coordinates(x[bi, c].astype(np.float64), [py, px], order=1, mode="grid-constant", cval=0.0)
+                want[bi] += w[:, c, i, j][:, None, None] * (s * m[bi, t])[None]
+        want[bi] += b[:, None, None]
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)

@@ -91,3 +91,35 @@ def test_ctdet_post_process_groups_by_class_and_is_scale_and_shift():
     exp = (dets[0, 3, :4] - 64.0) * (512.0 / 128.0) + 256.0
     np.testing.assert_allclose(row[:4], exp, rtol=1e-6, atol=1e-3)
     assert abs(row[4] - dets[0, 3, 4]) < 1e-7
+
+
+def test_rodrigues_agrees_with_scipy_rotation_vectors():
+    # no SMPL code exists in the reference; scipy.spatial.transform is an independent implementation of the axis-angle ->
+    # matrix map (same convention as SMPL's Rodrigues formula): pins the sign / axis conventions of oracle.smpl.rodrigues
+    from scipy.spatial.transform import Rotation
+    th = np.random.default_rng(0).normal(0, 1.2, (64, 3))
+    np.testing.assert_allclose(osmpl.rodrigues(th), Rotation.from_rotvec(th).as_matrix(), atol=1e-6)
+
+
+def test_lbs_of_a_one_bone_chain_is_a_rigid_transform_composition():
+    # hand-built two-joint model: vertex fully bound to joint 1 -> v' = G0 G1 applied in the kinematic order of the
+    # published formulation (world transform of joint 1 = T(j0) R0 T(j1 - j0) R1, minus the rest pose)
+    from scipy.spatial.transform import Rotation
+    m = _model()
+    V = m["v_template"].shape[0]
+    mm = dict(m)
+    mm["posedirs"] = np.zeros_like(m["posedirs"])
+    mm["shapedirs"] = np.zeros_like(m["shapedirs"])
+    w = np.zeros_like(m["weights"])
+    w[:, 1] = 1.0                                       # every vertex follows joint 1 (child of the root)
+    mm["weights"] = w
+    th = np.zeros((1, 24, 3))
+    th[0, 0] = [0.3, -0.4, 0.2]
+    th[0, 1] = [-0.5, 0.1, 0.7]
+    v, j = osmpl.lbs(np.zeros((1, 10)), th.reshape(1, 72), mm)
+    jr = m["J_regressor"] @ m["v_template"]             # rest joints
+    assert int(m["parents"][1]) == 0
+    R0, R1 = Rotation.from_rotvec(th[0, 0]).as_matrix(), Rotation.from_rotvec(th[0, 1]).as_matrix()
+    want = (R0 @ (R1 @ (m["v_template"] - jr[1]).T + (jr[1] - jr[0])[:, None])).T + jr[0]
+    np.testing.assert_allclose(v[0], want, atol=1e-6)
+    assert v.shape == (1, V, 3)
