@@ -35,6 +35,8 @@ class Opt:
         self.reg_offset = True
         self.hm_hp = True
         self.reg_hp_offset = True
+        self.flip_test = False        # opts.py:89 (declared by the reference, used by nothing there): see MultiPoseDetector.run
+        self.flip_idx = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]       # opts.py:250
         self.smpl = False             # north_star extension: pose/shape heads + LBS
         self.smpl_people = None       # meshes per image (None = K)
         self.dtype = "bf16"
@@ -83,7 +85,10 @@ class MultiPoseDetector:
         verts [B,N,6890,3] / joints, optional results [B,K,39] in image px when meta={'c','s'}).
         slot: plan-buffer copy (model.forward); consecutive batches issued on different HIP streams alternate slots."""
         opt = self.opt
-        out = self.model(images, slot)[-1]    # (Hourglass returns one dict per stack: inference uses the last)
+        if opt.flip_test:
+            out = self._flip_test_heads(images, slot)
+        else:
+            out = self.model(images, slot)[-1]    # (Hourglass returns one dict per stack: inference uses the last)
         dets, aux = decode.multi_pose_decode_logits(
             out["hm"], out["wh"], out["hps"], reg=out.get("reg") if opt.reg_offset else None,
             hm_hp=out.get("hm_hp") if opt.hm_hp else None,
@@ -168,6 +173,37 @@ def ctdet_post_process(dets, c, s, h, w, num_classes):
     for i in range(B):
         ret.append({j + 1: boxes[i, classes[i] == j].tolist() for j in range(num_classes)})
     return ret
+
+
+def _flip_test_heads(self, images, slot=0):
+    """`--flip_test` (opts.py:89; the reference declares the option and ships the helpers `flip_tensor / flip_lr /
+    flip_lr_off`, models/utils.py:29-51, but no caller): the published CenterNet multi_pose recipe the helpers were written
+    for -- run the batch and its mirror image, average `hm` and `wh` with the mirrored maps flipped back, `hps` with
+    `flip_lr_off` (x offsets negated, left/right joints swapped), `hm_hp` with `flip_lr`; `reg` / `hp_offset` come from the
+    un-flipped pass.  Heat maps are averaged AFTER `_sigmoid`, so the returned `hm` / `hm_hp` are logits of the average."""
+    from .utils import _sigmoid, flip_lr, flip_lr_off, flip_tensor
+    B = images.shape[0]
+    out = self.model(torch.cat([images, torch.flip(images, [3])], 0).contiguous(), slot)[-1]
+    idx = self.opt.flip_idx
+    res = {}
+    for k, v in out.items():
+        a, b = v[:B], v[B:]
+        if k in ("hm", "hm_hp"):
+            pa = _sigmoid(a.clone())
+            pb = _sigmoid(b.clone())
+            pb = flip_tensor(pb) if k == "hm" else flip_lr(pb, idx)
+            p = (pa + pb) / 2
+            res[k] = torch.log(p / (1 - p))
+        elif k == "wh":
+            res[k] = (a + flip_tensor(b)) / 2
+        elif k == "hps":
+            res[k] = (a + flip_lr_off(b, idx)) / 2
+        else:
+            res[k] = a.contiguous()
+    return res
+
+
+MultiPoseDetector._flip_test_heads = _flip_test_heads
 
 
 def run_frames(detector, frames):

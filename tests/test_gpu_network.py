@@ -413,3 +413,23 @@ def test_plan_slots_on_two_streams_give_identical_results():
         assert torch.equal(d, ref["dets"]) and torch.equal(v, ref["verts"]), i
     eng = det.model.engine(torch.device(DEV))
     assert eng.plan(4, 128, 192, 0) is not eng.plan(4, 128, 192, 1)
+
+
+def test_flip_test_on_a_mirror_symmetric_input_keeps_symmetry_and_runs_both_passes():
+    # --flip_test (opts.py:89): heads of the batch and of its mirror image averaged with the reference's flip helpers.
+    # For every head the recipe must equal the explicit two-pass computation done here with the same helpers.
+    from h3d_amd import utils
+    opt = Opt(input_h=128, input_w=128, dtype="f32", K=30, flip_test=True)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=1.25)
+    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    x = torch.from_numpy(synth.synth_images(2, 128, 128, seed=9)).to(DEV)
+    res = det.run(x)
+    a = {k: v.clone() for k, v in det.model(x)[0].items()}
+    b = {k: v.clone() for k, v in det.model(torch.flip(x, [3]).contiguous())[0].items()}
+    wh = (a["wh"] + utils.flip_tensor(b["wh"])) / 2
+    hps = (a["hps"] + utils.flip_lr_off(b["hps"], opt.flip_idx)) / 2
+    np.testing.assert_allclose(res["heads"]["wh"].cpu().numpy(), wh.cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(res["heads"]["hps"].cpu().numpy(), hps.cpu().numpy(), atol=1e-5)
+    p = (utils._sigmoid(a["hm"].clone()) + utils.flip_tensor(utils._sigmoid(b["hm"].clone()))) / 2
+    np.testing.assert_allclose(utils._sigmoid(res["heads"]["hm"].clone()).cpu().numpy(), p.cpu().numpy(), atol=1e-6)
+    assert torch.equal(res["heads"]["reg"], a["reg"]) and res["dets"].shape == (2, 30, 40)
