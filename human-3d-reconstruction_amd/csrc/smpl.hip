@@ -439,6 +439,11 @@ constexpr int S3_KP = 224, S3_NST = S3_KP / 16, S3_VT = 64, S3_NW = 8, S3_PB = 3
 constexpr int S3_PPAD = 128;                                  // the hosts pad the person count to this
 constexpr int S3_SPR = 7;                                     // 16-byte slots per row and stage: 6 data + 1 pad
 constexpr int S3_ROWB = S3_SPR * 16;                          // 112
+#ifdef H3D_SMPL_6
+constexpr int S3_DSLOTS = 6;                                  // slots of a row the DMA fetches: h, m, l
+#else
+constexpr int S3_DSLOTS = 4;                                  // h and m only: the lanes of the l slots carry an out-of-range offset (zeros, no traffic)
+#endif
 constexpr int S3_GROW = S3_NST * 96;                          // bytes of a row in global memory: 1344
 constexpr int S3_APIECES = 3 * S3_VT * S3_SPR / 64;           // 21 KiB pieces of direction rows
 constexpr int S3_BPIECES = S3_PB * S3_SPR / 64;               // 28 of coefficient rows
@@ -501,13 +506,13 @@ __global__ __launch_bounds__(64 * S3_NW) void smpl_verts3_kernel(const bf16_t *_
         const int q = (wv + S3_NW * j) * 64 + l;
         const int row = q / S3_SPR, sub = q - S3_SPR * row;           // row = c * 64 + v
         const int c = row >> 6, v = row & 63;
-        aoff[j] = (sub < S3_SPR - 1 && row < 3 * S3_VT) ? (c * Vpad + v0 + v) * S3_GROW + sub * 16 : 0x7ffffff0;
+        aoff[j] = (sub < S3_DSLOTS && row < 3 * S3_VT) ? (c * Vpad + v0 + v) * S3_GROW + sub * 16 : 0x7ffffff0;
     }
 #pragma unroll
     for (int j = 0; j < (S3_BPIECES + S3_NW - 1) / S3_NW; ++j) {
         const int q = (wv + S3_NW * j) * 64 + l;
         const int row = q / S3_SPR, sub = q - S3_SPR * row;           // row = person inside the workgroup
-        boff[j] = (sub < S3_SPR - 1 && row < S3_PB) ? (p0 + row) * S3_GROW + sub * 16 : 0x7ffffff0;
+        boff[j] = (sub < S3_DSLOTS && row < S3_PB) ? (p0 + row) * S3_GROW + sub * 16 : 0x7ffffff0;
     }
     const int dbytes = 3 * Vpad * S3_GROW, cbytes = Ppad * S3_GROW;
 
@@ -558,25 +563,36 @@ __global__ __launch_bounds__(64 * S3_NW) void smpl_verts3_kernel(const bf16_t *_
             if (st + 1 < S3_NST && MODE != 3)
                 s3_issue((const char *)dirsK3, dbytes, (const char *)coefK3, cbytes, smem + ((st + 1) & 1) * S3_SLOT, aoff, boff, wv, st + 1);
             const char *sl = smem + (st & 1) * S3_SLOT;
-            const E::frag bh = E::lds_frag(sl + fb_off), bm = E::lds_frag(sl + fb_off + 32), bl = E::lds_frag(sl + fb_off + 64);
+#ifdef H3D_SMPL_6
+            constexpr bool SIX = true;      // all six products down to 2^-24 relative (round 1)
+#else
+            constexpr bool SIX = false;     // hh + hm + mh: the three dropped products (mm, hl, lh) are 2^-16 relative each --
+#endif                                      // 2.2e-6 abs on the blend-shape displacement (fp64 emulation, |d| <= 0.34), 45x inside the
+                                            // 1e-4 tolerance -- for half the MFMAs and two thirds of the fragment reads
+            const E::frag bh = E::lds_frag(sl + fb_off), bm = E::lds_frag(sl + fb_off + 32);
+            E::frag bl = bh;
+            if constexpr (SIX) bl = E::lds_frag(sl + fb_off + 64);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 // the two vertex tiles of a coordinate alternate, so consecutive MFMAs do not share an accumulator
                 const char *ap0 = sl + fa_off + (c * 64) * S3_ROWB, *ap1 = ap0 + 32 * S3_ROWB;
                 E::frag ah0 = bh, am0 = bm, al0 = bl, ah1 = bh, am1 = bm, al1 = bl;
                 if constexpr (MODE != 2) {
-                    ah0 = E::lds_frag(ap0); am0 = E::lds_frag(ap0 + 32); al0 = E::lds_frag(ap0 + 64);
-                    ah1 = E::lds_frag(ap1); am1 = E::lds_frag(ap1 + 32); al1 = E::lds_frag(ap1 + 64);
+                    ah0 = E::lds_frag(ap0); am0 = E::lds_frag(ap0 + 32);
+                    ah1 = E::lds_frag(ap1); am1 = E::lds_frag(ap1 + 32);
+                    if constexpr (SIX) { al0 = E::lds_frag(ap0 + 64); al1 = E::lds_frag(ap1 + 64); }
                 }
                 if constexpr (MODE == 1) {
                     asm volatile("" ::"v"(ah0.v), "v"(am0.v), "v"(al0.v), "v"(ah1.v), "v"(am1.v), "v"(al1.v), "v"(bh.v), "v"(bm.v), "v"(bl.v));
                 } else {
-                    E::mma(acc[c][0], al0, bh);          // smallest terms first
-                    E::mma(acc[c][1], al1, bh);
-                    E::mma(acc[c][0], ah0, bl);
-                    E::mma(acc[c][1], ah1, bl);
-                    E::mma(acc[c][0], am0, bm);
-                    E::mma(acc[c][1], am1, bm);
+                    if constexpr (SIX) {
+                        E::mma(acc[c][0], al0, bh);      // smallest terms first
+                        E::mma(acc[c][1], al1, bh);
+                        E::mma(acc[c][0], ah0, bl);
+                        E::mma(acc[c][1], ah1, bl);
+                        E::mma(acc[c][0], am0, bm);
+                        E::mma(acc[c][1], am1, bm);
+                    }
                     E::mma(acc[c][0], am0, bh);
                     E::mma(acc[c][1], am1, bh);
                     E::mma(acc[c][0], ah0, bm);

@@ -46,7 +46,7 @@ def test_full_batch_size_properties(model):
     assert v.shape == (P, 6890, 3) and bool(torch.isfinite(v).all())
     v2 = smpl.lbs(model, betas[100:108].contiguous(), thetas[100:108].contiguous())
     # person-tile position invariance (different tile instantiation: same math, fma contraction may differ)
-    assert float((v[100:108] - v2).abs().max()) < 5e-6   # gen 3 (MFMA) vs gen 1: other summation order
+    assert float((v[100:108] - v2).abs().max()) < 1.5e-5   # gen 3 (MFMA, three split products: 2^-16 relative) vs gen 1 (fp32 FMA)
     v3 = smpl.lbs(model, betas[64:192].contiguous(), thetas[64:192].contiguous())
     assert torch.equal(v[64:192], v3)                    # same instantiation, other tile position: bitwise
     v_ref, _ = osmpl.lbs(betas[:2].cpu().numpy(), thetas[:2].cpu().numpy(), model.numpy_dict())
@@ -54,10 +54,11 @@ def test_full_batch_size_properties(model):
 
 
 def test_matrix_core_kernel_agrees_with_vector_kernel(model):
-    # gen 3 (fp32 MFMA blend shapes) vs gen 2 (vector FMA): same fp32 products, different summation order
+    # gen 3 (blend shapes on the bf16 matrix cores: hh + hm + mh of the three-term split, 2^-16 relative per product:
+    # 2.2e-6 abs on the displacement in an fp64 emulation) vs gen 2 (fp32 vector FMA)
     P = 640
     betas = torch.from_numpy(synth.normalish("b", (P, 10), 0, 1, 5)).to(DEV)
     thetas = torch.from_numpy(synth.normalish("t", (P, 72), 0, 0.3, 5)).to(DEV)
     v3 = smpl.lbs(model, betas, thetas, kernel="gen3")
     v2 = smpl.lbs(model, betas, thetas, kernel="gen2")
-    assert float((v3 - v2).abs().max()) < 2e-6
+    assert float((v3 - v2).abs().max()) < 1.5e-5
