@@ -1,6 +1,6 @@
-"""CPU aid: per-DeformConv-layer offset statistics of the synthetic weights (oracle network, fp32):
+"""TEST INFRASTRUCTURE (imports oracle/, hence it lives under tests/).  CPU aid: per-DeformConv-layer offset statistics of the synthetic weights (oracle network, fp32):
 mean |offset|, tail probabilities, and the share of samples that leave a margin-M apron of a 16x16 tile.
-    python tools/offset_stats.py [gain] [offset_scale] [hw]"""
+    python tests/offset_stats.py [gain] [offset_scale] [hw]"""
 import sys
 import numpy as np
 import torch
