@@ -63,6 +63,27 @@ def op_flops(op):
     return 0.0
 
 
+def op_bytes(op):
+    """Algorithmic HBM bytes of one plan op: every operand read once, every result written once (weights excluded: they
+    stay in L2 / the Infinity Cache across the batch)."""
+    es = 2 if op.dtype == _lib.H3D_BF16 else 4
+    pin, pout = op.B * op.H * op.W, op.B * op.Ho * op.Wo
+    if op.kind in (_lib.OP_STEM, _lib.OP_STEM3, _lib.OP_IM2COL):
+        return 4.0 * pin * op.Cin + es * pout * op.Cout
+    if op.kind == _lib.OP_HEADS:
+        d = ctypes.cast(op.in2, ctypes.POINTER(_lib.H3dHeadsDesc)).contents
+        return es * pin * op.Cin + 4.0 * pout * sum(d.head[i].C for i in range(d.nheads))
+    if op.kind == _lib.OP_UPADD:
+        return es * (pin * op.Cin + 2.0 * pout * op.Cout)
+    if op.kind == _lib.OP_UPDCN_F16:
+        return es * (pin * op.Cin + pout * op.Cin + pout * op.Cout)
+    out_es = 4 if op.out_mode in (_lib.OUT_NCHW_F32, _lib.OUT_NHWC_F32) else es
+    b = es * pin * op.Cin + out_es * pout * op.Cout
+    if op.kind in (_lib.OP_CONV, _lib.OP_CONV_STREAM) and op.in2:
+        b += es * pout * op.Cout                   # residual
+    return float(b)
+
+
 def kernel_name(op):
     buf = ctypes.create_string_buffer(200)
     _lib.check(_lib.lib().h3d_op_kernel_name(ctypes.byref(op), buf, 200), "op_kernel_name")
@@ -81,9 +102,10 @@ def per_kernel_profile(plan, iters):
     groups = {}
     for i, op in enumerate(plan.ops):
         real_cout = op.Cout
-        g = groups.setdefault(kernel_name(op), {"ms": 0.0, "flops": 0.0, "launches": 0})
+        g = groups.setdefault(kernel_name(op), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
         g["ms"] += float(tot[i])
         g["flops"] += op_flops(op)
+        g["bytes"] += op_bytes(op)
         g["launches"] += 1
     return groups
 
@@ -302,6 +324,7 @@ def main():
                          "16 images per GPU); resdcn_101 = configs[4] (ctdet, 768x768, 32 images per GPU): per-GPU shard of the "
                          "8-GPU batch, network + decode, no SMPL stage, no CPU baseline")
     ap.add_argument("--size", type=int, default=0, help="input height = width (default 512; 768 for resdcn_101)")
+    ap.add_argument("--engine-flag", action="append", default=[], help="engine lowering flag NAME=INT (engine.Plan.FLAGS), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="launcher + collective plumbing only, gloo on CPU (tests)")
@@ -346,6 +369,9 @@ def main():
         sd = synth.synth_state_dict(shapes, seed=0, offset_scale=args.offset_scale, gain=gain)
         det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
     det.model.engine(dev).streams = args.streams
+    for kv in args.engine_flag:
+        name, val = kv.split("=")
+        setattr(det.model.engine(dev), name, int(val))
     images = torch.from_numpy(synth.synth_images(1, size, size, seed=317 + rank)).to(dev)
     images = images.expand(args.batch, 3, size, size).contiguous()
     images += 0.01 * torch.arange(args.batch, device=dev, dtype=torch.float32).view(-1, 1, 1, 1)   # distinct images
@@ -455,7 +481,8 @@ def main():
                                 "step_frac": round(line["model_tflops"] / peak, 4)}
             print("[bench] roofline %s" % json.dumps(line["roofline"]), file=sys.stderr, flush=True)
             line["kernels"] = {k: {"ms": round(v["ms"], 3), "n": v["launches"],
-                                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
+                                   "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                                   "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)}      # algorithmic HBM bytes / time
                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             print("[bench] kernels %s" % json.dumps(line["kernels"]), file=sys.stderr, flush=True)
             if dla:

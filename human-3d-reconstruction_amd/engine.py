@@ -310,6 +310,7 @@ class Plan:
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
+        conv1x1_th16_min_cin=0,   # > 0: 1x1 convs with at least this many input channels (and > 32 outputs) use 16-row tiles
     )
 
     def __init__(self, pw, B, H, W, **flags):
@@ -376,10 +377,14 @@ class Plan:
             optr, ocs = out.ptr, out.cs
         else:
             optr, ocs = out_tensor.data_ptr(), cout
+        tune = 0
+        if (k == 1 and stride == 1 and self.conv1x1_th16_min_cin and cin >= self.conv1x1_th16_min_cin and cin % 64 == 0
+                and cout > 32 and self.pw.dtype == "bf16"):
+            tune = 0x1000 | ((4 if cout > 64 else 2) << 4) | 2       # csrc/conv.hip tuning override: MT, TH = 16
         self._op(_lib.OP_CONV, in_=x.ptr, in2=res.ptr if res is not None else None, w=wp.data_ptr(),
                  bias=bp.data_ptr(), out=optr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs,
                  in2_cs=res.cs if res is not None else 0, Ho=Ho, Wo=Wo, Cout=cout, out_cs=ocs, ksize=k,
-                 stride=stride, relu=int(relu), out_mode=out_mode, wrows=rows)
+                 stride=stride, relu=int(relu), out_mode=out_mode, wrows=rows, reserved=tune)
         return out
 
     def _conv_stream(self, x, wkey, out, bkey, bn, relu, res, stride=1):
