@@ -7,7 +7,10 @@ python -m pytest tests -x -q -m gpu > gpurun_out/t_full.log 2>&1 || { tail -30 g
 tail -2 gpurun_out/t_full.log
 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
 tail -1 gpurun_out/bench.json | cut -c1-400
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_stats.log 2>&1
+# kernel stats twice: with ONE step in flight (per-kernel durations comparable with bench.py's live HIP-event numbers, which are
+# taken launch by launch) and with the default two (durations inflated wherever the two streams' kernels share the GPU)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --pipeline 1 > gpurun_out/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_p2 -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_stats_p2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_w.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_sq1 -o q -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_q1.log 2>&1
