@@ -477,6 +477,8 @@ def main():
                                 "network_ms_per_step": round(total_ms, 3),
                                 # the north_star's target is quoted on the whole DLA-34+DCNv2 forward: all conv FLOP of
                                 # the network / its device time, and the same FLOP / the whole step (decode, SMPL, gather)
+                                "timing": "HIP events around every launch of the plan on one stream, 3 passes (independent of "
+                                          "steps_in_flight: kernels of two steps sharing the GPU stretch individual launches)",
                                 "network_tflops": round(net_tflops, 1), "network_frac": round(net_tflops / peak, 4),
                                 "step_frac": round(line["model_tflops"] / peak, 4)}
             print("[bench] roofline %s" % json.dumps(line["roofline"]), file=sys.stderr, flush=True)
