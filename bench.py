@@ -388,7 +388,15 @@ def main():
             return gather_detections(res["dets"], n_images=world * args.batch) if world > 1 else res["dets"]
         with torch.cuda.stream(slot_streams[k]):
             res = det.run(images, slot=k)
-            return gather_detections(res["dets"], n_images=world * args.batch) if world > 1 else res["dets"]
+            if world == 1:
+                return res["dets"]
+            done = torch.cuda.Event()
+            done.record()
+        # the collective is always issued from the default stream, in step order (one communicator, one stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        res["dets"].record_stream(cur)
+        return gather_detections(res["dets"], n_images=world * args.batch)
 
     # one-time setup outside both warm-up and the timed region: weight packing + plan lowering (host work and uploads,
     # no network launches) and the SMPL model upload.  The first launch of every kernel still pays its code-object
