@@ -177,6 +177,19 @@ __device__ __forceinline__ void stage_vectors(int tid, LD ld, ST st)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Workgroup barrier that leaves vmcnt alone.  __syncthreads() is release fence + s_barrier + acquire fence, and the release
+// waits for EVERY outstanding LDS-DMA of the wave (hipcc emits s_waitcnt vmcnt(0) in front of the s_barrier: a DMA is an
+// LDS write), which collapses a DMA ring of three or more slots to one stage of distance whatever the counted s_waitcnt
+// vmcnt(N) in front of it says.  Here the caller states its own vector-memory wait; lgkmcnt(0) retires this wave's LDS
+// reads and writes, and the empty asm statements keep the compiler from moving memory operations across the barrier.
+__device__ __forceinline__ void h3d_barrier_keep_vmcnt()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // XCD-aware tile order.  Workgroup ids are dealt round robin to the 8 XCDs (id % 8), each with its own 4 MiB L2, so
 // with the plain order the four neighbours of a tile -- which share its halo / apron -- sit on four other dies and the
 // shared pixels are fetched into several L2s.  With mode 1 die x works on the contiguous id range [x * nb/8, (x+1) * nb/8).

@@ -286,6 +286,9 @@ template <> int launch_conv_t<float>(const h3d_op &op, const ConvArgs &a, hipStr
              op.ksize, op.stride);
 }
 
+bool h3d_gemm1_takes(const h3d_op &op);
+int h3d_launch_gemm1(const h3d_op &op, hipStream_t st);
+
 int h3d_launch_conv(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "conv: null pointer");
@@ -308,6 +311,7 @@ int h3d_launch_conv(const h3d_op &op, hipStream_t st)
     a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
     a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.out_cs = op.out_cs; a.res_cs = op.in2_cs;
     a.relu = op.relu; a.out_mode = op.out_mode; a.tiles_x = a.tiles_y = 0;
+    if (h3d_gemm1_takes(op)) return h3d_launch_gemm1(op, st);      // 1x1 stride 1, bf16: the GEMM kernel (csrc/gemm1.hip)
     if (op.dtype == H3D_BF16) return launch_conv_t<bf16_t>(op, a, st);
     if (op.dtype == H3D_F32) return launch_conv_t<float>(op, a, st);
     H3D_FAIL(H3D_ERR_DTYPE, "conv: dtype %d", op.dtype);

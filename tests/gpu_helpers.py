@@ -55,7 +55,7 @@ def mk(kind, dtype, **kw):
 
 
 def conv(x, w, b, dtype, stride=1, relu=False, res=None, out_mode=_lib.OUT_NHWC, in_pad=0, out_pad=0,
-         pad_cout_to=None, name_only=False):
+         pad_cout_to=None, name_only=False, reserved=0):
     """x NCHW fp32 cpu; returns NCHW fp32 cpu result of the HIP conv (input/output living inside wider
     channel-strided buffers when in_pad/out_pad > 0)."""
     B, Ci, H, W = x.shape
@@ -83,7 +83,7 @@ def conv(x, w, b, dtype, stride=1, relu=False, res=None, out_mode=_lib.OUT_NHWC,
         optr = out.data_ptr()
     op = mk(_lib.OP_CONV, dtype, in_=xptr, in2=rptr, w=wp.data_ptr(), bias=bp.data_ptr(), out=optr, B=B, H=H, W=W,
             Cin=Ci, in_cs=Ci + in_pad, in2_cs=rcs, Ho=Ho, Wo=Wo, Cout=cout, out_cs=ocs, ksize=k, stride=stride,
-            relu=int(relu), out_mode=out_mode, wrows=rows)
+            relu=int(relu), out_mode=out_mode, wrows=rows, reserved=reserved)
     if name_only:
         return kernel_name(op)
     run(op)

@@ -77,6 +77,74 @@ def test_conv_matches_torch(case, dtype):
     _check(got, ref.float(), dtype, str(case))
 
 
+# 1x1 stride-1 bf16 convolutions as a GEMM (csrc/gemm1.hip).  reserved: 0x4000 = take the GEMM kernel whatever the grid,
+# 0x100 / 0x200 / 0x300 = the 256x256 / 128x256 (three ring slots) / 128x128 (4 waves, two workgroups per CU) tile;
+# 0x2000 = the halo-tile kernel instead.
+GEMM1_CASES = [
+    # (B, Cin, Cout, H, W, relu, residual, reserved, in_pad, out_pad)
+    (2, 128, 64, 24, 24, True, False, 0x4300, 0, 0),       # DLA level2 root class (auto leaves <= 64 channels to conv.hip); 1152 px = 9 tiles
+    (1, 448, 128, 16, 16, True, False, 0x4200, 0, 0),      # root over a concat, 7 stages through the 3-slot ring
+    (1, 1280, 512, 8, 8, True, False, 0x4100, 0, 0),       # level5 root, 20 stages, 256x256 tile, 64 px: mostly empty tile
+    (2, 256, 1024, 12, 12, False, True, 0x4100, 0, 0),     # ResNet bottleneck expand + residual, 288 px (partial tile)
+    (2, 1024, 256, 12, 12, True, False, 0x4200, 0, 0),     # ResNet bottleneck reduce
+    (1, 128, 72, 16, 16, False, False, 0x4200, 0, 0),      # Cout not a multiple of 32 (channel guard of the epilogue)
+    (1, 192, 384, 16, 24, True, True, 0x4200, 0, 0),       # 384 = three channel blocks of 128
+    (1, 192, 200, 16, 24, True, True, 0x4100, 0, 0),       # 200 of 256 packed rows: the rest of the 256-channel tile is zero filters
+    (2, 128, 128, 16, 16, True, True, 0x4200, 64, 128),    # input / output inside wider concat buffers
+    (1, 256, 64, 40, 40, True, False, 0x4300, 0, 64),      # 1600 px = 12.5 tiles of 128
+    (4, 512, 256, 96, 96, True, False, 0, 0, 0),           # auto dispatch (grid large enough): 256x256
+    (4, 512, 128, 96, 96, True, True, 0, 0, 0),            # auto: 128x128
+    (8, 1024, 256, 48, 48, True, False, 0, 0, 0),          # auto: 72 tiles of 256x256 would leave most CUs idle: 128x128
+]
+
+
+def _gemm1_tensors(case):
+    B, Ci, Co, H, W, relu, use_res, reserved, in_pad, out_pad = case
+    x = bf16_round(rnd("x", (B, Ci, H, W)))
+    w = bf16_round(rnd("w", (Co, Ci, 1, 1)) * (1.5 / np.sqrt(Ci)))
+    b = rnd("b", (Co,))
+    res = bf16_round(rnd("r", (B, Co, H, W))) if use_res else None
+    return x, w, b, res
+
+
+def gemm1_case_kernel_names():
+    return {conv(*_gemm1_tensors(c)[:3], "bf16", relu=c[5], res=_gemm1_tensors(c)[3], in_pad=c[8], out_pad=c[9], reserved=c[7],
+                 name_only=True) for c in GEMM1_CASES}
+
+
+@pytest.mark.parametrize("case", GEMM1_CASES)
+def test_gemm1_matches_torch_and_halo_kernel(case):
+    B, Ci, Co, H, W, relu, use_res, reserved, in_pad, out_pad = case
+    x, w, b, res = _gemm1_tensors(case)
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    kw = dict(relu=relu, res=res, in_pad=in_pad, out_pad=out_pad)
+    assert conv(x, w, b, "bf16", reserved=reserved, name_only=True, **kw).startswith("gemm1_kernel<")
+    got, untouched = conv(x, w, b, "bf16", reserved=reserved, **kw)
+    _check(got, ref.float(), "bf16", str(case))
+    assert untouched is None or untouched
+    # the halo-tile kernel of csrc/conv.hip on the same operands: same MFMA instruction over K in the same order
+    assert conv(x, w, b, "bf16", reserved=0x2000, name_only=True, **kw).startswith("conv_kernel<")
+    old, _ = conv(x, w, b, "bf16", reserved=0x2000, **kw)
+    assert float((got - old).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+def test_gemm1_declines_what_it_cannot_take():
+    x, w, b = bf16_round(rnd("x", (1, 128, 9, 9))), bf16_round(rnd("w", (64, 128, 1, 1)) * 0.1), rnd("b", (64,))
+    assert conv(x, w, b, "bf16", reserved=0x4000, name_only=True).startswith("conv_kernel<")      # 81 pixels: not a multiple of 16
+    x = bf16_round(rnd("x", (1, 96, 16, 16)))
+    w = bf16_round(rnd("w", (64, 96, 1, 1)) * 0.1)
+    assert conv(x, w, b, "bf16", reserved=0x4000, name_only=True).startswith("conv_kernel<")      # Cin % 64 != 0
+    x, w = rnd("x", (1, 128, 16, 16)), rnd("w", (64, 128, 1, 1)) * 0.1
+    assert conv(x, w, b, "f32", reserved=0x4000, name_only=True).startswith("conv_kernel<")       # fp32 plans
+    assert conv(bf16_round(x), bf16_round(w), b, "bf16", name_only=True).startswith("conv_kernel<")   # <= 64 output channels
+    w, b = bf16_round(rnd("w", (128, 128, 1, 1)) * 0.1), rnd("b", (128,))
+    assert conv(bf16_round(x), w, b, "bf16", name_only=True).startswith("conv_kernel<")                  # 2 x 1 tiles: grid too small
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_conv_channel_strided_views(dtype):
     # input read from / output written into slices of wider concat buffers; neighbours untouched

@@ -203,7 +203,7 @@ def test_bench_plan_kernels_are_all_covered():
     import test_gpu_conv
     from gpu_helpers import conv as _  # noqa: F401
     tested = {_conv2_built(c)[4].name for c in CONV2_CASES} | {_dcn_built(c)[5].name for c in DCN_CASES}
-    tested |= test_gpu_conv.conv_case_kernel_names("bf16")
+    tested |= test_gpu_conv.conv_case_kernel_names("bf16") | test_gpu_conv.gemm1_case_kernel_names()
     single = ("stem3_kernel", "heads_kernel<", "maxpool_kernel<", "upadd_kernel<", "copy_kernel<")
     for batch in (64, 32):
         names = _plan_kernel_names(batch)
