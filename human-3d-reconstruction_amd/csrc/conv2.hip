@@ -151,7 +151,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
         // my pieces of stage s have landed once only stage s+1's may be outstanding (vmcnt retires in order)
         if (AHEAD == 2 && s + 1 < nst) __builtin_amdgcn_s_waitcnt(WAIT_PMIN);
         else __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();                          // ... everyone's have; the slot of stage s-1 is no longer being read
+        h3d_barrier_keep_vmcnt();                 // ... everyone's have; the slot of stage s-1 is no longer being read (not
+                                                  // __syncthreads: its release fence waits for the younger stage's DMA too)
         if (SLOTS > 1 && s + AHEAD < nst && !(H3D_DBG(a) & 1))
             conv2_issue<MT, WAVES, S, NT>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + pslot * C::SLOT, hoff, woff, wv, s + AHEAD, ((s + AHEAD) * a.G + g0) * C::WGRP, H3D_DBG(a));
         const char *sl = smem + cslot * C::SLOT;
