@@ -191,6 +191,10 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     //      (outside the image: zeros, no branch), so every wave issues exactly NV of them per stage and the wait for the
     //      filter DMA of stage s can be counted: only the NV loads of stage s+1 were issued after it.
     constexpr bool D2 = WDMA && NP > 0 && sizeof(T) == 2;
+#ifndef DCN3_TAPAHEAD
+#define DCN3_TAPAHEAD 1
+#endif
+    constexpr bool TAPAHEAD = DCN3_TAPAHEAD && D2 && MT >= 4 && CK == 16;   // phase B: gathers one tap ahead (see computeB)
     [[maybe_unused]] int avoff[NV], adst[NV];
     [[maybe_unused]] u32x4 stg2[D2 ? 2 : 1][NV];
     if constexpr (D2) {
@@ -443,6 +447,36 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     auto computeB = [&](int s) {
         const char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
+        if constexpr (TAPAHEAD) {
+            // one workgroup per CU = two waves per SIMD: they cannot cover the gather -> blend -> MFMA chain of a tap by
+            // themselves, so tap t+1's four corner fragments
+            // are requested before tap t is blended and multiplied (16 more live registers: only the 128-channel variant has
+            // them)
+            static_assert(CK == 16, "one 16-channel fragment per tap");
+            typename X::frag v[2][4];
+            auto gather = [&](int tap, int q) {
+                const char *p00 = s_h + boff[tap];
+                v[q][0] = X::lds(p00);
+                v[q][1] = X::lds(p00 + C::SBH);
+                v[q][2] = X::lds(p00 + C::RBH);
+                v[q][3] = X::lds(p00 + C::RBH + C::SBH);
+            };
+            gather(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // LDS returns in order: tap t's filter fragments first (they arrive while tap t is blended), then the
+                // corners of tap t+1 (they arrive while tap t is multiplied)
+                typename X::frag fa[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + tap * CK * SS);
+                if (tap + 1 < 9) gather(tap + 1, (tap + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);            // (hipcc sinks the reads back in front of their first use otherwise)
+                const typename X::frag fb = X::blend(v[tap & 1], geo[tap]);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb);
+            }
+            return;
+        }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             typename X::frag fb[CK / 16];
