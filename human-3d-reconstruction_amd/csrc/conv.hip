@@ -500,11 +500,19 @@ __global__ __launch_bounds__(256) void upadd_kernel(const T *__restrict__ in, co
                                                     int C, int in_cs, int skip_cs, int Ho, int Wo, int out_cs, int f)
 {
     constexpr int N = Vec16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float s_w[];     // [k*k][C]
+    extern __shared__ __attribute__((aligned(16))) float s_w[];     // [k*k][C + 4]
     const int vpc = C / N, k = 2 * f, p = f / 2;
+    // rows of C + 4 floats: neighbouring pixels of a wave read neighbouring taps (kj = (ox + p) % f + ...), and with rows
+    // of C floats (a multiple of 256 B) the same channel vector of two taps sits on the same banks -- the SQ counters
+    // showed 75 % of this kernel's LDS cycles as bank conflicts and the waves LDS-issue-stalled 41 % of the time; the 16-byte
+    // skew puts tap t + 1 on the slots tap t leaves free
+    const int wrow = WLDS ? C + 4 : C;
     if constexpr (WLDS) {   // a compile-time choice: a run-time pointer select would turn the ds_reads into flat loads
-        for (int i = threadIdx.x; i < k * k * C / 4; i += 256)
-            *reinterpret_cast<f32x4 *>(s_w + 4 * i) = *reinterpret_cast<const f32x4 *>(w + 4 * i);
+        const int c4 = C / 4;
+        for (int i = threadIdx.x; i < k * k * c4; i += 256) {
+            const int t = i / c4, j = i - t * c4;
+            *reinterpret_cast<f32x4 *>(s_w + t * wrow + 4 * j) = *reinterpret_cast<const f32x4 *>(w + 4 * i);
+        }
         __syncthreads();
     }
     const int ppb = 256 / vpc;                                       // pixels per workgroup row segment
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(256) void upadd_kernel(const T *__restrict__ in, co
             if (!ok[q]) continue;                // same association order as before: taps (a, c2) ascending
             unpack16<T>(xv[q], x);
             const float *wp;
-            if constexpr (WLDS) wp = s_w + tap[q] * C + v * N;
+            if constexpr (WLDS) wp = s_w + tap[q] * wrow + v * N;
             else wp = w + tap[q] * C + v * N;
 #pragma unroll
             for (int n = 0; n < N; ++n) acc[n] = fmaf(wp[n], x[n], acc[n]);
@@ -595,10 +603,12 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
     dim3 grid(ew_grid(total)), blk(256);
     const bool f16out = op.kind == H3D_OP_UPADD && op.out_mode == H3D_OUT_NHWC_F16;
     if (f16out && es != 2) H3D_FAIL(H3D_ERR_DTYPE, "upadd: fp16 output needs a bf16 plan");
-    // tap table in LDS only while staging it is cheap next to the workgroup's 8 rows (measured: 4 KiB wins by 33 %,
-    // 8 KiB and more lose); tuning override: reserved 1 = never, 2 = whenever it fits 64 KiB
+    // tap table in LDS only while staging it is cheap next to the workgroup's 8 rows x (256 / vectors per pixel) pixels.
+    // With the skewed rows (no bank conflicts, see upadd_kernel), same box, batch 64: 4 KiB (64 ch, f = 2) 0.070 -> 0.063 ms;
+    // 8 KiB (128 ch) 0.057 -> 0.043; 16 KiB with 64 channels (f = 4) 0.102 -> 0.075; 16 KiB with 256 channels (8-pixel
+    // segments) 0.029 -> 0.041: stays in global memory.  Tuning override: reserved 1 = never, 2 = whenever it fits 64 KiB
     const size_t up_wbytes = (size_t)op.ksize * op.ksize * op.Cin * sizeof(float);
-    const bool up_wlds = op.reserved == 1 ? false : op.reserved == 2 ? up_wbytes <= 64 * 1024 : up_wbytes <= 4096;
+    const bool up_wlds = op.reserved == 1 ? false : op.reserved == 2 ? up_wbytes <= 64 * 1024 : (up_wbytes <= 8192 || (up_wbytes <= 16384 && op.Cin <= 64));
     if (h3d_note_kernel("%s<%s%s%s>", op.kind == H3D_OP_MAXPOOL ? "maxpool_kernel" : op.kind == H3D_OP_UPADD ? "upadd_kernel" : "copy_kernel",
                         es == 2 ? "unsigned short" : "float", op.kind == H3D_OP_UPADD ? (f16out ? ", true" : ", false") : "",
                         op.kind == H3D_OP_UPADD ? (up_wlds ? ", true" : ", false") : ""))
@@ -622,7 +632,7 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
         const size_t wfl = (size_t)op.ksize * op.ksize * op.Cin;
         // tap table in LDS when it fits the default 64 KiB (tuning override: reserved 1 = never, 2 = always)
         const bool wlds = up_wlds;
-        const size_t lds = wlds ? wfl * sizeof(float) : 0;
+        const size_t lds = wlds ? (wfl + 4 * (size_t)op.ksize * op.ksize) * sizeof(float) : 0;     // rows of C + 4 floats
         const dim3 ugrid(cdiv(op.Wo, 256 / vpc), op.B * cdiv(op.Ho, UP_ROWS));
 #define H3D_UPADD_LAUNCH(K, TT)                                                                                              \
     do {                                                                                                                      \
