@@ -41,6 +41,16 @@ struct Dcn3Args {
     unsigned long long *stamps;   // profiling builds: in-kernel phase stamps (common.h H3D_STAMP)
 };
 
+// profiling builds with -DDCN3_STAMP_B: the six phase stamps are replaced by sub-step stamps of phase B's second stage
+// (wave 0 of every workgroup; tools/stamp_dcn.py --stage-b)
+#if defined(H3D_ABLATE) && defined(DCN3_STAMP_B)
+#undef H3D_STAMP
+#define H3D_STAMP(wg, k) do { if ((k) == 6 && threadIdx.x == 0 && (wg) < 65536 && a.stamps) a.stamps[(wg) * H3D_NSTAMP + 6] = __builtin_readcyclecounter(); } while (0)
+#define H3D_STAMP_B(s, k) do { if ((s) == nchunks + 1 && threadIdx.x == 0 && blockIdx.x < 65536 && a.stamps) a.stamps[blockIdx.x * H3D_NSTAMP + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define H3D_STAMP_B(s, k) do { } while (0)
+#endif
+
 template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0>
 struct Dcn3Cfg {
     static constexpr int ES = sizeof(T);
@@ -509,17 +519,23 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     if constexpr (D2) {
         // one stage of distance from here on (the accumulators are live now); stage nchunks+1 is already in flight
         auto stepB = [&](int s, auto P, auto Q) {
+            H3D_STAMP_B(s, 0);
             patch_issue(s);
             __syncthreads();
+            H3D_STAMP_B(s, 1);
             store2(P);
             patch_commit(smem + C::PB);
             __builtin_amdgcn_s_waitcnt(0x0f70);  // (the patch loads were the youngest: nothing older is pending either)
+            H3D_STAMP_B(s, 2);
             __syncthreads();
+            H3D_STAMP_B(s, 3);
             if (s + 1 < 2 * nchunks) {
                 issue_w(s + 1);
                 if (s != nchunks) load2(s + 1, Q);
             }
+            H3D_STAMP_B(s, 4);
             computeB(s);
+            H3D_STAMP_B(s, 5);
         };
         for (int s = nchunks; s < 2 * nchunks; s += 2) { stepB(s, I0, I1); stepB(s + 1, I1, I0); }
     } else {
