@@ -94,11 +94,11 @@ def per_kernel_profile(plan, iters):
     """HIP-event time of every op of the plan, grouped by kernel instantiation."""
     n = len(plan.ops)
     ms = (ctypes.c_float * n)()
-    tot = np.zeros(n)
+    passes = []
     for _ in range(iters):
         _lib.check(_lib.lib().h3d_run_ops_timed(plan.op_array, n, _lib.stream_ptr(), ms), "run_ops_timed")
-        tot += np.frombuffer(ms, dtype=np.float32, count=n)
-    tot /= iters
+        passes.append(np.frombuffer(ms, dtype=np.float32, count=n).copy())
+    tot = np.median(np.stack(passes), axis=0)      # per launch: the median pass (one stalled pass moved a family by 37 % once)
     groups = {}
     for i, op in enumerate(plan.ops):
         real_cout = op.Cout
@@ -462,7 +462,7 @@ def main():
         line["model_tflops"] = round(gflop_img * line["value"] / 1e3 / world, 1)      # per GPU
         if not args.no_roofline:
             plan = det.model.engine(dev).plan(args.batch, size, size)
-            groups = per_kernel_profile(plan, iters=3)
+            groups = per_kernel_profile(plan, iters=5)
             total_ms = sum(g["ms"] for g in groups.values())
             name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
@@ -485,7 +485,7 @@ def main():
                                 "network_ms_per_step": round(total_ms, 3),
                                 # the north_star's target is quoted on the whole DLA-34+DCNv2 forward: all conv FLOP of
                                 # the network / its device time, and the same FLOP / the whole step (decode, SMPL, gather)
-                                "timing": "HIP events around every launch of the plan on one stream, 3 passes (independent of "
+                                "timing": "HIP events around every launch of the plan on one stream, median of 5 passes per launch (independent of "
                                           "steps_in_flight: kernels of two steps sharing the GPU stretch individual launches)",
                                 "network_tflops": round(net_tflops, 1), "network_frac": round(net_tflops / peak, 4),
                                 "step_frac": round(line["model_tflops"] / peak, 4)}
