@@ -1,4 +1,4 @@
-// 1x1 stride-1 convolution as a plain GEMM (bf16, fp32 accumulate), fed entirely by LDS-DMA.
+// 1x1 convolution (stride 1, or 2: a strided row gather) as a plain GEMM (bf16, fp32 accumulate), fed entirely by LDS-DMA.
 // (reference: the Root / project convs of DLA-34, model.py:148-166, 200-207; the bottleneck 1x1 convs of the published
 //  ResNet-101-DCN and the 1x1 convs of Hourglass-104's residual blocks; same math and the same epilogue as csrc/conv.hip,
 //  which keeps fp32, other kernel sizes / strides and the shapes this kernel does not take.)
@@ -27,7 +27,8 @@ struct Gemm1Args {
     const float *bias;
     const char *res;     // bf16 NHWC or null
     char *out;           // bf16 NHWC
-    long long N;         // B * H * W
+    long long N;         // B * Ho * Wo output pixels
+    int H, W, Ho, Wo, stride;   // stride 2 (the 1x1 down-sampling convs of ResNet / Hourglass): input pixel (2 oy, 2 ox)
     int Cin, in_cs, Cout, out_cs, res_cs, relu, wrows;
     int tiles_n, blocks_m;
     int xcd;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm1_kernel(Gemm1Args a)
     // ---- DMA sources, rebased to this workgroup's first pixel / filter row (per-lane offsets stay small) --------------
     const long long in_left = (a.N - p0) * a.in_cs * 2;
     const char *in0 = a.in + (size_t)p0 * a.in_cs * 2;
-    const int in_bytes = (int)(in_left < 0x7ffffff0ll ? in_left : 0x7ffffff0ll);
+    int in_bytes = (int)(in_left < 0x7ffffff0ll ? in_left : 0x7ffffff0ll);
     const char *w0 = a.w + (size_t)cout0 * a.Cin * 2;
     const int w_bytes = (a.wrows - cout0) * a.Cin * 2;
     // lane l of a piece: row 8 * piece + (l >> 3), LDS slot l & 7 <- source slot (l & 7) ^ ((row >> 1) & 7)
@@ -104,6 +105,25 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm1_kernel(Gemm1Args a)
     for (int j = 0; j < C::PB; ++j) {
         const int row = (wv + j * C::WAVES) * 8 + (l >> 3);
         offb[j] = row * a.in_cs * 2 + (((l & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    if (a.stride != 1) {
+        // strided input: the pixel rows of the tile are output pixels (b, oy, ox) reading input pixel (s oy, s ox); offsets
+        // are absolute (the launcher has checked that the whole input lies below 2 GiB), rows past the last pixel out of range
+        in0 = a.in;
+        in_bytes = (int)((long long)a.N / (a.Ho * a.Wo) * a.H * a.W * a.in_cs * 2);
+        const int hw = a.Ho * a.Wo;
+#pragma unroll
+        for (int j = 0; j < C::PB; ++j) {
+            const int row = (wv + j * C::WAVES) * 8 + (l >> 3);
+            const long long pp = p0 + row;
+            int off = 0x7ffffff0;
+            if (pp < a.N) {
+                const int b = (int)(pp / hw), rr = (int)(pp - (long long)b * hw);
+                const int oy = rr / a.Wo, ox = rr - oy * a.Wo;
+                off = ((b * a.H + oy * a.stride) * a.W + ox * a.stride) * a.in_cs * 2 + (((l & 7) ^ ((row >> 1) & 7)) << 4);
+            }
+            offb[j] = off;
+        }
     }
     auto issue = [&](int s, char *slot) { gemm1_issue<C::PA, C::PB, C::WAVES, C::BM>(w0, w_bytes, in0, in_bytes, slot, offa, offb, wv, s); };
 
@@ -181,7 +201,8 @@ static int launch_gemm1_cfg(const Gemm1Args &a0, hipStream_t st)
 // the lean NHWC epilogue, a pixel count the width-16 view covers exactly, a grid worth the tiles)
 bool h3d_gemm1_takes(const h3d_op &op)
 {
-    if (op.dtype != H3D_BF16 || op.ksize != 1 || op.stride != 1 || op.out_mode != H3D_OUT_NHWC) return false;
+    if (op.dtype != H3D_BF16 || op.ksize != 1 || (op.stride != 1 && op.stride != 2) || op.out_mode != H3D_OUT_NHWC) return false;
+    if (op.stride == 2 && (long long)op.B * op.H * op.W * op.in_cs * 2 >= 0x7ffffff0ll) return false;   // absolute 32-bit offsets
     if (op.reserved & 0x3000) return false;                  // tuning overrides 0x1000 (tile shape), 0x2000: the halo-tile kernel of csrc/conv.hip
     const long long N = (long long)op.B * op.Ho * op.Wo;
     if (op.Cin % 64 || op.Cin < 128 || op.in_cs % 8 || op.Cout % 8 || op.out_cs % 8 || (N & 15)) return false;
@@ -202,6 +223,7 @@ int h3d_launch_gemm1(const h3d_op &op, hipStream_t st)
     a.in = (const char *)op.in; a.w = (const char *)op.w; a.bias = op.bias; a.res = (const char *)op.in2; a.out = (char *)op.out;
     a.N = (long long)op.B * op.Ho * op.Wo; a.Cin = op.Cin; a.in_cs = op.in_cs; a.Cout = op.Cout; a.out_cs = op.out_cs;
     a.res_cs = op.in2_cs; a.relu = op.relu; a.wrows = op.wrows; a.tiles_n = a.blocks_m = 0; a.xcd = 0;
+    a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo; a.stride = op.stride;
     // a tile's epilogue reads the bias of ALL its channel rows unguarded, and its filter rows must exist or lie past the end
     // of the bank: a channel block of BM rows needs cdiv(Cout, BM) * BM packed rows (128 is guaranteed, see above)
     const bool ok256 = cdiv(op.Cout, 256) * 256 <= op.wrows;

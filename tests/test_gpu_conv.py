@@ -81,7 +81,7 @@ def test_conv_matches_torch(case, dtype):
 # 0x100 / 0x200 / 0x300 = the 256x256 / 128x256 (three ring slots) / 128x128 (4 waves, two workgroups per CU) tile;
 # 0x2000 = the halo-tile kernel instead.
 GEMM1_CASES = [
-    # (B, Cin, Cout, H, W, relu, residual, reserved, in_pad, out_pad)
+    # (B, Cin, Cout, H, W, relu, residual, reserved, in_pad, out_pad[, stride])
     (2, 128, 64, 24, 24, True, False, 0x4300, 0, 0),       # DLA level2 root class (auto leaves <= 64 channels to conv.hip); 1152 px = 9 tiles
     (1, 448, 128, 16, 16, True, False, 0x4200, 0, 0),      # root over a concat, 7 stages through the 3-slot ring
     (1, 1280, 512, 8, 8, True, False, 0x4100, 0, 0),       # level5 root, 20 stages, 256x256 tile, 64 px: mostly empty tile
@@ -95,33 +95,38 @@ GEMM1_CASES = [
     (4, 512, 256, 96, 96, True, False, 0, 0, 0),           # auto dispatch (grid large enough): 256x256
     (4, 512, 128, 96, 96, True, True, 0, 0, 0),            # auto: 128x128
     (8, 1024, 256, 48, 48, True, False, 0, 0, 0),          # auto: 72 tiles of 256x256 would leave most CUs idle: 128x128
+    (2, 256, 512, 24, 40, False, False, 0x4100, 0, 0, 2),  # stride 2 (ResNet / Hourglass down-sampling 1x1): strided row gather
+    (1, 128, 128, 17, 31, True, False, 0x4300, 64, 0, 2),  # stride 2, odd input size (9 x 16 outputs), input inside a wider buffer
+    (8, 256, 512, 96, 96, False, False, 0, 0, 0, 2),       # stride 2, auto dispatch
 ]
 
 
 def _gemm1_tensors(case):
-    B, Ci, Co, H, W, relu, use_res, reserved, in_pad, out_pad = case
+    B, Ci, Co, H, W, relu, use_res, reserved, in_pad, out_pad = case[:10]
+    st = case[10] if len(case) > 10 else 1
     x = bf16_round(rnd("x", (B, Ci, H, W)))
     w = bf16_round(rnd("w", (Co, Ci, 1, 1)) * (1.5 / np.sqrt(Ci)))
     b = rnd("b", (Co,))
-    res = bf16_round(rnd("r", (B, Co, H, W))) if use_res else None
+    res = bf16_round(rnd("r", (B, Co, (H - 1) // st + 1, (W - 1) // st + 1))) if use_res else None
     return x, w, b, res
 
 
 def gemm1_case_kernel_names():
     return {conv(*_gemm1_tensors(c)[:3], "bf16", relu=c[5], res=_gemm1_tensors(c)[3], in_pad=c[8], out_pad=c[9], reserved=c[7],
-                 name_only=True) for c in GEMM1_CASES}
+                 stride=c[10] if len(c) > 10 else 1, name_only=True) for c in GEMM1_CASES}
 
 
 @pytest.mark.parametrize("case", GEMM1_CASES)
 def test_gemm1_matches_torch_and_halo_kernel(case):
-    B, Ci, Co, H, W, relu, use_res, reserved, in_pad, out_pad = case
+    B, Ci, Co, H, W, relu, use_res, reserved, in_pad, out_pad = case[:10]
+    st = case[10] if len(case) > 10 else 1
     x, w, b, res = _gemm1_tensors(case)
-    ref = F.conv2d(x.double(), w.double(), b.double())
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=st)
     if use_res:
         ref = ref + res.double()
     if relu:
         ref = F.relu(ref)
-    kw = dict(relu=relu, res=res, in_pad=in_pad, out_pad=out_pad)
+    kw = dict(relu=relu, res=res, in_pad=in_pad, out_pad=out_pad, stride=st)
     assert conv(x, w, b, "bf16", reserved=reserved, name_only=True, **kw).startswith("gemm1_kernel<")
     got, untouched = conv(x, w, b, "bf16", reserved=reserved, **kw)
     _check(got, ref.float(), "bf16", str(case))

@@ -29,6 +29,8 @@ n = len(plan.ops)
 ms = (ctypes.c_float * n)()
 idx = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_CONV and op.ksize == 1 and op.stride == 1 and op.Cin % 64 == 0 and op.Cin >= 128]
 cfgs = [0x2000, 0, 0x4100, 0x4200, 0x4300]
+idx_s2 = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_CONV and op.ksize == 1 and op.stride == 2 and op.Cin % 64 == 0 and op.Cin >= 128]
+idx = idx + idx_s2
 res = {}
 for rep in range(2):
     for cfg in cfgs:
