@@ -423,9 +423,12 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float *__restrict_
     }
 }
 
+int h3d_launch_stem_s2(const h3d_op &op, hipStream_t st);      // csrc/extra.hip: the 7x7 stride-2 stems of ResNet / Hourglass
+
 int h3d_launch_stem(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "stem: null pointer");
+    if (op.stride == 2) return h3d_launch_stem_s2(op, st);
     if (op.Cin != 3 || op.Cout != 16 || op.ksize != 7 || op.Ho != op.H || op.Wo != op.W || op.out_cs % 4)
         H3D_FAIL(H3D_ERR_SHAPE, "stem: expects 7x7 3->16 stride 1 (got k=%d %d->%d)", op.ksize, op.Cin, op.Cout);
     const int tx = cdiv(op.W, 16), ty = cdiv(op.H, 16);

@@ -5,6 +5,7 @@
 //   H3D_OP_IM2COL       the 7x7 stride-2 stem conv (3 -> 64 / 128 channels) as im2col + the MFMA 1x1 conv: NCHW fp32
 //                       images -> NHWC patches [B,Ho,Wo,Kpad], channel k = c*49 + ky*7 + kx (the order of
 //                       weight.reshape(Cout, -1)), zero from 147 up to Kpad = 160
+//                       (fp32 plans; bf16 plans run the convolution itself: stem_s2_kernel below, H3D_OP_STEM with stride 2)
 //   H3D_OP_MAXPOOL3     nn.MaxPool2d(3, stride 2, padding 1) (ResNet stem)
 //   H3D_OP_DEPTH2SPACE  [B,H,W,4C] -> [B,2H,2W,C]: group g = 2*py + px of the channels is the output pixel
 //                       (2y+py, 2x+px); with it ConvTranspose2d(C, C, 4, stride 2, padding 1) of the ResNet-DCN up
@@ -93,6 +94,91 @@ __global__ void depth2space_kernel(const T *__restrict__ in, T *__restrict__ out
 }
 
 static inline int ex_grid(size_t total) { size_t g = (total + 255) / 256; return (int)(g > 2048 * 8 ? 2048 * 8 : (g ? g : 1)); }
+
+// The 7x7 stride-2 stem convolution itself (bf16 plans): Conv2d(3, Cout, 7, stride 2, padding 3) + BN + ReLU from NCHW fp32
+// images to NHWC bf16 on v_mfma_f32_16x16x32_bf16, csrc/conv.hip's stem_mfma_kernel with stride 2 and more channel tiles.
+// im2col + 1x1 conv wrote and re-read a [B,Ho,Wo,160] patch tensor (1.5 GB at 32 x 768 x 768: 1.19 + 0.56 ms per step of
+// ResNet-101-DCN); here the image patch of a 8 x 32 output tile (21 x 69 pixels) is staged in LDS as interleaved pixels of
+// 4 bf16 (c0, c1, c2, 0), so the 7 taps of a filter row of output pixel ox are ONE contiguous K = 28 (+4 zero-weight) run
+// starting at input pixel 2 ox: lane (p, q) reads its 8 K elements with a single aligned ds_read_b128 (pixels 2 ox + 2q,
+// + 2q + 1).  Wave w owns 16 output channels (blockIdx.y * 64 + 16 w), keeps their 7 filter-row fragments in registers and
+// walks the tile's 16 groups of 16 pixels.  w: bf16 [Cout][7][32] (k = dx*4 + c, engine.PackedWeights.stem_s2), bias fp32.
+typedef __attribute__((ext_vector_type(4))) float f32x4_st;
+__global__ __launch_bounds__(256) void stem_s2_kernel(const float *__restrict__ img, const bf16_t *__restrict__ w,
+                                                      const float *__restrict__ bias, bf16_t *__restrict__ out, int B, int H,
+                                                      int W, int Ho, int Wo, int Cout, int out_cs, int tiles_x, int tiles_y)
+{
+    constexpr int TH = 8, TW = 32, IH = (TH - 1) * 2 + 7, IW = 72;      // 21 rows x (62 + 7 + 2 -> 72) pixels
+    __shared__ __attribute__((aligned(16))) uint2 s[IH][IW];
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, p = l & 15, q = l >> 4;
+    const int tiles = tiles_x * tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int c0 = blockIdx.y * 64 + wv * 16;
+    u32x4 fa[7];
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy) fa[dy] = u32x4{0u, 0u, 0u, 0u};
+    if (c0 < Cout) {
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy) fa[dy] = *reinterpret_cast<const u32x4 *>(w + ((size_t)(c0 + p) * 7 + dy) * 32 + 8 * q);
+    }
+    const size_t plane = (size_t)H * W;
+    const float *im = img + (size_t)b * 3 * plane;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int iy = i / IW, ix = i - iy * IW;
+        const int gy = 2 * oy0 - 3 + iy, gx = 2 * ox0 - 3 + ix;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t o = (size_t)gy * W + gx;
+            v0 = im[o]; v1 = im[plane + o]; v2 = im[2 * plane + o];
+        }
+        s[iy][ix] = uint2{pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f)};
+    }
+    __syncthreads();
+    if (c0 >= Cout) return;
+    float bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bs[i] = bias[c0 + 4 * q + i];
+    // two groups per iteration: two independent MFMA chains
+#pragma unroll 1
+    for (int g = 0; g < TH * TW / 16; g += 2) {
+        f32x4_st acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const int py = g >> 1;
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32x4 fb = *reinterpret_cast<const u32x4 *>(&s[2 * py + dy][2 * (16 * u + p) + 2 * q]);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[dy]), __builtin_bit_cast(bf16x8_t, fb),
+                                                                 acc[u], 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int oy = oy0 + py, ox = ox0 + 16 * u + p;
+            if (oy < Ho && ox < Wo)
+                store4<bf16_t>(out + ((size_t)(b * Ho + oy) * Wo + ox) * out_cs + c0 + 4 * q, fmaxf(acc[u][0] + bs[0], 0.f),
+                               fmaxf(acc[u][1] + bs[1], 0.f), fmaxf(acc[u][2] + bs[2], 0.f), fmaxf(acc[u][3] + bs[3], 0.f));
+        }
+    }
+}
+
+int h3d_launch_stem_s2(const h3d_op &op, hipStream_t st)
+{
+    if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "stem (stride 2): bf16 plans only (dtype %d)", op.dtype);
+    if (op.Cin != 3 || op.ksize != 7 || op.stride != 2 || op.Cout % 16 || op.out_cs % 4 || op.out_cs < op.Cout ||
+        op.Ho != (op.H - 1) / 2 + 1 || op.Wo != (op.W - 1) / 2 + 1)
+        H3D_FAIL(H3D_ERR_SHAPE, "stem (stride 2): expects 7x7 3->16n, output floor((H-1)/2)+1 (got k=%d %d->%d, %dx%d -> %dx%d)", op.ksize,
+                 op.Cin, op.Cout, op.H, op.W, op.Ho, op.Wo);
+    if (((uintptr_t)op.w & 15) || ((uintptr_t)op.out & 7)) H3D_FAIL(H3D_ERR_ARG, "stem (stride 2): weights must be 16-byte aligned");
+    const int tx = cdiv(op.Wo, 32), ty = cdiv(op.Ho, 8);
+    if (h3d_note_kernel("stem_s2_kernel")) return H3D_OK;
+    hipLaunchKernelGGL(stem_s2_kernel, dim3(op.B * tx * ty, cdiv(op.Cout, 64)), dim3(256), 0, st, (const float *)op.in, (const bf16_t *)op.w,
+                       op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.Ho, op.Wo, op.Cout, op.out_cs, tx, ty);
+    H3D_CHECK_LAUNCH("stem_s2_kernel");
+    return H3D_OK;
+}
 
 int h3d_launch_extra(const h3d_op &op, hipStream_t st)
 {

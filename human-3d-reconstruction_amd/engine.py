@@ -169,6 +169,18 @@ class PackedWeights:
             self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
         return self.t[key]
 
+    def stem_s2(self, wkey, bkey, bn):
+        """7x7 stride-2 stem filters [Cout,3,7,7] (+ BatchNorm `bn` folded) for csrc/extra.hip stem_s2_kernel:
+        bf16 [Cout][7 dy][32] with k = dx*4 + c (zero for dx = 7 and c = 3), bias fp32 [Cout]."""
+        key = ("stem_s2", wkey, bn)
+        if key not in self.t:
+            w, b = self._fold(self.sd[wkey], self.sd[bkey] if bkey else None, bn)
+            co = w.shape[0]
+            wp = torch.zeros(co, 7, 8, 4)
+            wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)          # [o][dy][dx][c]
+            self.t[key] = (wp.reshape(co, 7, 32).to(torch.bfloat16).contiguous().to(self.device), b.float().contiguous().to(self.device))
+        return self.t[key]
+
     def stem3(self):
         """base_layer + level0 + level1 packed for csrc/stem3.hip: bf16 [16][7][32] | [5][16][32] | [32][9][16] and
         fp32 biases [16 | 16 | 32] (BatchNorm folded)."""
@@ -310,6 +322,7 @@ class Plan:
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
+        stem_s2_direct=True,      # bf16 plans of the other backbones: the 7x7 stride-2 stem conv itself instead of im2col + 1x1 conv
         conv1x1_th16_min_cin=0,   # > 0: 1x1 convs with at least this many input channels (and > 32 outputs) use 16-row tiles
     )
 
@@ -616,14 +629,25 @@ class Plan:
                 self.conv(feat, head + ".weight", bkey=head + ".bias", relu=False,
                           out_mode=_lib.OUT_NCHW_F32, out_tensor=o)
 
+    def _stem_s2(self, wkey, bkey, bn, cout):
+        """Conv2d(3, cout, 7, stride 2, padding 3) + BN + ReLU from the NCHW fp32 images."""
+        H, W = self.H, self.W
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        if self.dtype == "bf16" and self.stem_s2_direct:
+            w, b = self.pw.stem_s2(wkey, bkey, bn)
+            x = self._alloc(Ho, Wo, cout)
+            self._op(_lib.OP_STEM, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=x.ptr, H=H, W=W, Cin=3, in_cs=3,
+                     Ho=Ho, Wo=Wo, Cout=cout, out_cs=x.cs, ksize=7, stride=2, relu=1)
+            return x
+        patches = self._alloc(Ho, Wo, 160)                   # fp32 plans: im2col + 1x1 conv (csrc/extra.hip)
+        self._op(_lib.OP_IM2COL, in_=self.images.data_ptr(), out=patches.ptr, H=H, W=W, Cin=3, in_cs=3, Ho=Ho, Wo=Wo, Cout=160,
+                 out_cs=patches.cs, ksize=7, stride=2)
+        return self.conv(patches, self.pw.im2col_key(wkey), bkey=bkey, bn=bn)
+
     # -- ResNet-101-DCN (arch_res.py; published CenterNet `resnet_dcn.py`) ---------------------------------------------------
     def _lower_resdcn(self):
         B, H, W = self.B, self.H, self.W
-        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        patches = self._alloc(Ho, Wo, 160)                   # conv1 7x7/2 as im2col + 1x1 conv (csrc/extra.hip)
-        self._op(_lib.OP_IM2COL, in_=self.images.data_ptr(), out=patches.ptr, H=H, W=W, Cin=3, in_cs=3, Ho=Ho, Wo=Wo, Cout=160,
-                 out_cs=patches.cs, ksize=7, stride=2)
-        x = self.conv(patches, self.pw.im2col_key("conv1.weight"), bn="bn1")
+        x = self._stem_s2("conv1.weight", None, "bn1", 64)   # conv1 7x7/2 + bn1 + ReLU
         y = self._alloc((x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1, x.C)
         self._op(_lib.OP_MAXPOOL3, in_=x.ptr, out=y.ptr, H=x.H, W=x.W, Cin=x.C, in_cs=x.cs, Ho=y.H, Wo=y.W, Cout=x.C, out_cs=y.cs,
                  ksize=3, stride=2)
@@ -670,12 +694,8 @@ class Plan:
     def _lower_hourglass(self):
         B, H, W = self.B, self.H, self.W
         nstack = 2
-        # pre.0: Conv2d(3, 128, 7, stride 2, pad 3) + BN + ReLU as im2col (csrc/extra.hip) + the MFMA 1x1 conv
-        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        patches = self._alloc(Ho, Wo, 160)
-        self._op(_lib.OP_IM2COL, in_=self.images.data_ptr(), out=patches.ptr, H=H, W=W, Cin=3, in_cs=3, Ho=Ho, Wo=Wo, Cout=160,
-                 out_cs=patches.cs, ksize=7, stride=2)
-        inter = self.conv(patches, self.pw.im2col_key("pre.0.conv.weight"), bn="pre.0.bn")
+        # pre.0: Conv2d(3, 128, 7, stride 2, pad 3) + BN + ReLU
+        inter = self._stem_s2("pre.0.conv.weight", None, "pre.0.bn", arch_hg.PRE_DIM)
         inter = self._hg_residual(inter, "pre.1", arch_hg.PRE_DIM, arch_hg.DIMS[0], 2)
         self.all_outputs = []
         for i in range(nstack):

@@ -80,7 +80,9 @@ int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *
  *    One descriptor per launch; h3d_run_ops walks an array of them (the forward "plan").
  * ===================================================================================== */
 enum {
-    H3D_OP_STEM = 1,    /* base_layer 7x7 3->C0 conv+BN+ReLU from NCHW fp32 images (model.py:231-235) */
+    H3D_OP_STEM = 1,    /* base_layer 7x7 3->C0 conv+BN+ReLU from NCHW fp32 images (model.py:231-235): stride 1, C0 = 16;
+                           bf16 plans also stride 2 with C0 a multiple of 16 (the stems of ResNet-101-DCN / Hourglass-104):
+                           w = bf16 [C0][7][32], k = dx*4 + c, zero for dx = 7 and c = 3 */
     H3D_OP_CONV = 2,    /* kxk (k=1|3, stride 1|2, pad k/2) conv + bias [+residual] [+ReLU]            */
     H3D_OP_DCN = 3,     /* modulated deformable 3x3 s1 p1 d1 dg1 conv + bias [+ReLU] (model.py:346-362);
                            weights [rows][9][Cin] are fp16 when dtype = bf16 (csrc/dcn2.hip), fp32 otherwise */

@@ -205,6 +205,33 @@ def test_stem(dtype):
     _check(from_nhwc(out, 16), ref, dtype)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 48, 80, 0), (1, 128, 37, 51, 0), (2, 64, 64, 64, 32), (1, 80, 23, 20, 0)])
+def test_stem_stride2_matches_torch(shape):
+    """csrc/extra.hip stem_s2_kernel (H3D_OP_STEM with stride 2, bf16 plans: the 7x7 stems of ResNet-101-DCN / Hourglass-104)
+    against F.conv2d on the bf16-rounded operands; odd sizes, partial tiles, channel counts of 1.25 and 2 blocks of 64,
+    output inside a wider buffer."""
+    B, Co, H, W, out_pad = shape
+    x = rnd("img", (B, 3, H, W))
+    w = rnd("w", (Co, 3, 7, 7)) * 0.1
+    b = rnd("b", (Co,))
+    ref = F.relu(F.conv2d(bf16_round(x).double(), bf16_round(w).double(), b.double(), 2, 3)).float()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    wp = torch.zeros(Co, 7, 8, 4)
+    wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wd = wp.reshape(Co, 7, 32).to(torch.bfloat16).contiguous().to(DEV)
+    xi, bd = x.contiguous().to(DEV), b.to(DEV)
+    cs = Co + out_pad
+    out = torch.full((B, Ho, Wo, cs), 7.0, dtype=torch.bfloat16, device=DEV)
+    op = mk(_lib.OP_STEM, "bf16", in_=xi.data_ptr(), w=wd.data_ptr(), bias=bd.data_ptr(), out=out.data_ptr(), B=B, H=H, W=W, Cin=3,
+            in_cs=3, Ho=Ho, Wo=Wo, Cout=Co, out_cs=cs, ksize=7, stride=2, relu=1)
+    from gpu_helpers import kernel_name
+    assert kernel_name(op) == "stem_s2_kernel"
+    run(op)
+    _check(from_nhwc(out, Co), ref, "bf16", str(shape))
+    if out_pad:
+        assert bool((out[..., Co:].float() == 7.0).all().item())
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_maxpool_and_upadd_and_copy(dtype):
     x = rnd("x", (2, 32, 18, 22))
