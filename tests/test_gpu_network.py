@@ -433,3 +433,28 @@ def test_flip_test_on_a_mirror_symmetric_input_keeps_symmetry_and_runs_both_pass
     p = (utils._sigmoid(a["hm"].clone()) + utils.flip_tensor(utils._sigmoid(b["hm"].clone()))) / 2
     np.testing.assert_allclose(utils._sigmoid(res["heads"]["hm"].clone()).cpu().numpy(), p.cpu().numpy(), atol=1e-6)
     assert torch.equal(res["heads"]["reg"], a["reg"]) and res["dets"].shape == (2, 30, 40)
+
+
+@pytest.mark.parametrize("arch_args", [[], ["--arch", "resdcn_101"], ["--arch", "hourglass"]])
+def test_bench_cli_prints_one_contract_line(arch_args):
+    """bench.py end to end as the driver starts it (a child process; small batch and image): ONE JSON line with the contract's
+    keys, `roofline` with a live per-launch figure, and a value that is a rate of the K timed steps."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4", "--size", "128",
+           "--no-cpu-baseline"] + arch_args
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "images/s" and d["higher_is_better"] is True
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and d["vs_baseline"] is None
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
+        assert k in rf, k
+    assert rf["avg_launch_ms"] > 0 and 0 < rf["frac"] < 1
