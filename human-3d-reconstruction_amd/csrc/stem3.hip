@@ -38,14 +38,28 @@ constexpr int S3K_SH = 19, S3K_SW = 35, S3K_LH = 17, S3K_LW = 33;
 constexpr int S3K_LDS_I = S3K_IH * S3K_IW * 8, S3K_LDS_S = S3K_SH * S3K_ROWB, S3K_LDS_L = S3K_LH * S3K_ROWB;
 constexpr int S3K_LDS = S3K_LDS_I + S3K_LDS_S + S3K_LDS_L + 4096;     // + slack: masked lanes of the last groups read past a row
 
-__global__ __launch_bounds__(512) void stem3_kernel(Stem3Args a)
+// bias + ReLU + bf16 rounding of one accumulator quad, zero outside the image -- branch free: the ReLU runs on the packed
+// pairs (v_pk_max_i16 against 0: a negative bf16 is a negative int16, rounding never changes the sign, so
+// round(relu(x)) == relu(round(x)) bit for bit) and the image test is a select.  (-2 % on the kernel: its waves are parked
+// on the four barriers of a tile 55 % of the time, not short of vector issue slots.)
+__device__ __forceinline__ u32x2 stem3_epi(const f32x4_s3 &acc, const float (&b)[4], bool in)
+{
+    typedef short s16x2_s3 __attribute__((ext_vector_type(2)));
+    uint32_t lo = pack_bf16x2(acc[0] + b[0], acc[1] + b[1]), hi = pack_bf16x2(acc[2] + b[2], acc[3] + b[3]);
+    lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_s3, lo), s16x2_s3{0, 0}));
+    hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_s3, hi), s16x2_s3{0, 0}));
+    return u32x2{in ? lo : 0u, in ? hi : 0u};
+}
+
+__global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
 {
     __shared__ __attribute__((aligned(16))) char smem[S3K_LDS];
     uint2 *s_i = reinterpret_cast<uint2 *>(smem);
     char *s_s = smem + S3K_LDS_I;
     char *s_l = s_s + S3K_LDS_S;
 
-    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, p = l & 15, q = l >> 4;
+    const int tid = threadIdx.x, l = tid & 63, p = l & 15, q = l >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform for the compiler too: the group index arithmetic of P1 / P2 runs on the scalar unit
     const int tiles = a.tiles_x * a.tiles_y;
     const int ntile = a.B * tiles;
     const int t_first = blockIdx.x * S3K_TPB;
@@ -123,10 +137,7 @@ __global__ __launch_bounds__(512) void stem3_kernel(Stem3Args a)
         if (sx < S3K_SW) {
             const int gy = sy0 + sy, gx = sx0 + sx;
             const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            u32x2 v = {0u, 0u};
-            if (in) v = u32x2{pack_bf16x2(fmaxf(acc[0] + b0[0], 0.f), fmaxf(acc[1] + b0[1], 0.f)),
-                              pack_bf16x2(fmaxf(acc[2] + b0[2], 0.f), fmaxf(acc[3] + b0[3], 0.f))};
-            *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = v;
+            *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = stem3_epi(acc, b0, in);
         }
     }
     __syncthreads();
@@ -166,10 +177,7 @@ __global__ __launch_bounds__(512) void stem3_kernel(Stem3Args a)
             if (lx < S3K_LW) {
                 const int gy = ly0 + ly, gx = lx0 + lx;
                 const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                u32x2 v = {0u, 0u};
-                if (in) v = u32x2{pack_bf16x2(fmaxf(acc[u][0] + b1[0], 0.f), fmaxf(acc[u][1] + b1[1], 0.f)),
-                                  pack_bf16x2(fmaxf(acc[u][2] + b1[2], 0.f), fmaxf(acc[u][3] + b1[3], 0.f))};
-                *reinterpret_cast<u32x2 *>(s_l + ly * S3K_ROWB + lx * S3K_PXB + q * 8) = v;
+                *reinterpret_cast<u32x2 *>(s_l + ly * S3K_ROWB + lx * S3K_PXB + q * 8) = stem3_epi(acc[u], b1, in);
             }
         }
     }
