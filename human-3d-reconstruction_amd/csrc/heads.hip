@@ -42,6 +42,7 @@ struct HeadsArgs {
     int tiles_x, tiles_y;
     int dbg;   // profiling ablation (h3d_op.reserved): 1 = skip the weight loads after the prologue
     int xcd;   // h3d_tile_id mode
+    unsigned long long *stamps;   // profiling builds: per workgroup {kernel start, end, cycles wave 0 spent in the stage barriers, in gemm2, waiting for its own DMA pieces}
 };
 
 template <typename T, int TH>
@@ -265,6 +266,10 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 #pragma unroll
     for (int n = 0; n < NT; ++n) boff[n] = (wv * NT + n) * C::RB + r * C::SB + 8 * h * ES;
 
+#ifdef H3D_ABLATE
+    unsigned long long t_bar = 0, t_g2 = 0, t_dma = 0;
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
     int s = 0;
     for (int head = 0; head < a.nheads; ++head) {
         const char *s_b = s_bias + (head & 1) * C::LDS_BIAS;
@@ -380,10 +385,26 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                 const char *slot = s_ring + (s & 1) * C::SLOT;
                 if (BIASC && tr == 0) stage(std::true_type{}, slot, tr);
                 else stage(std::false_type{}, slot, tr);
+#ifdef H3D_ABLATE
+                const unsigned long long tb0 = __builtin_readcyclecounter();
+                __builtin_amdgcn_s_waitcnt(0x0f70);          // my own DMA pieces of the next stage
+                const unsigned long long tb1 = __builtin_readcyclecounter();
+                t_dma += tb1 - tb0;
+#endif
+                if (!(H3D_DBG(a) & 2))   // (profiling: 2 = no stage barrier -- wrong results, timing only)
                 __syncthreads();   // vmcnt(0) + barrier: next stage's weights (and the 1x1 slice) have landed
+#ifdef H3D_ABLATE
+                t_bar += __builtin_readcyclecounter() - tb1;
+#endif
             }
             // ---- slab done: X = ReLU(acc [+ b1]) -> B operand; acc2 += W2[:, slab] . X ----------------------
+#ifdef H3D_ABLATE
+            const unsigned long long tg0 = __builtin_readcyclecounter();
+#endif
             gemm2<T, TH, NT, M2, BIASC>(acc, acc2, s_b + slab * HC_SLAB * 4, s_w2, r, h, sw);
+#ifdef H3D_ABLATE
+            t_g2 += __builtin_readcyclecounter() - tg0;
+#endif
             if (C::TRS == 1) __syncthreads();   // (f32 path) s_w2 is rewritten in the very next stage
         }
         // ---- head done: z = acc2 + b2 -> NCHW fp32 (lane = pixel: coalesced rows) ------------------------
@@ -411,6 +432,19 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
             }
         }
     }
+#ifdef H3D_ABLATE
+    if (a.stamps && blockIdx.x < 65536) {
+        if (a.dbg & 64) {                       // per-wave barrier time instead (tools/stamp_heads.py --waves)
+            if (l == 0) a.stamps[blockIdx.x * H3D_NSTAMP + wv] = t_bar;
+        } else if (tid == 0) {
+            a.stamps[blockIdx.x * H3D_NSTAMP + 0] = t_start;
+            a.stamps[blockIdx.x * H3D_NSTAMP + 1] = __builtin_readcyclecounter();
+            a.stamps[blockIdx.x * H3D_NSTAMP + 2] = t_bar;
+            a.stamps[blockIdx.x * H3D_NSTAMP + 3] = t_g2;
+            a.stamps[blockIdx.x * H3D_NSTAMP + 4] = t_dma;
+        }
+    }
+#endif
 }
 
 static_assert(HEADS_MAX == H3D_HEADS_MAX, "header/kernel mismatch");
@@ -429,6 +463,11 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
     a.in = (const char *)op.in; a.w1 = (const char *)op.w; a.b1 = op.bias;
     a.dbg = op.reserved & 0xff;
     a.xcd = h3d_xcd_mode();
+#ifdef H3D_ABLATE
+    a.stamps = h3d_stamp_buffer();
+#else
+    a.stamps = nullptr;
+#endif
     a.nheads = d->nheads; a.head_conv = op.Cout; a.B = op.B; a.H = op.H; a.W = op.W; a.in_cs = op.in_cs;
     for (int i = 0; i < d->nheads; ++i) {
         if (!d->head[i].w2 || !d->head[i].b2 || !d->head[i].out) H3D_FAIL(H3D_ERR_ARG, "heads: head %d null pointer", i);
