@@ -12,7 +12,7 @@
 // accumulator row order, which the host bakes into the packed 1x1 weights).
 //
 // Weight pipeline: the 3x3 filters stream through a 2-slot LDS ring one tap ROW (3 taps, 24 KB) per
-// stage by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), issued one
+// stage by LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass), issued one
 // stage (48 MFMAs per wave) ahead; one barrier per stage.  The ring rows are unpadded (an LDS-DMA
 // wave-instruction writes 1 KB contiguously) and XOR-swizzled through the per-lane SOURCE address
 // so the A-fragment ds_read_b128 stay conflict-free.  The 1x1 slice of a slab arrives the same way.
@@ -78,12 +78,6 @@ template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
-__device__ __forceinline__ void glds16(const char *gsrc, char *lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
-}
 
 // Biases of one head -> LDS by LDS-DMA (wave 0: b1[head_conv] <= 1 KiB, wave 1: b2[96]); lanes past the end of either
 // array carry offsets outside the buffer and write zeros.  Reading them from global memory where they are used put
@@ -170,6 +164,47 @@ __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][N
     }
 }
 
+// LDS-DMA of one weight stage / one 1x1 slice in the BUFFER form: per-lane 32-bit offsets that do not depend on the stage
+// (row, tap and swizzled chunk of the lane's 16 bytes) + a scalar stage offset, instead of a 64-bit per-lane address rebuilt
+// for every piece (global_load_lds): an LDS-DMA instruction costs its wave 100-185 issue cycles as it is, and the address
+// arithmetic in front of each of the 3 + 2 pieces per wave and stage came on top (the weight stream was 10 % of the kernel:
+// ablation in DESIGN.md 2.3).  Plain functions of plain arguments: a lambda capturing a buffer descriptor drops the host stub.
+template <typename T, int TH>
+__device__ __forceinline__ void heads_dma_w1(const char *w1, int w1_bytes, char *slot, int wv, int l, int soff)
+{
+    using C = HeadsCfg<T, TH>;
+    constexpr int ES = sizeof(T);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)w1, 0, w1_bytes, 0x00020000);
+    constexpr int NI = C::TAPS * HC_SLAB / C::RPI;          // wave-instructions per stage (24 / 16)
+#pragma unroll
+    for (int j = 0; j < NI / 8; ++j) {
+        const int g = j * 8 + wv;                            // 1 KB run index
+        const int row_all = g * C::RPI + l / C::CPR;         // = tap_in_stage * 64 + row
+        const int tp = row_all / HC_SLAB, row = row_all - tp * HC_SLAB;
+        const int c = (l % C::CPR) ^ ((row >> C::SWZ_SHIFT) & (C::CPR - 1));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(slot + g * 1024), 16,
+                                                 ((row * 9 + tp) * HC_IN) * ES + c * 16, soff, 0, 0);
+    }
+}
+template <typename T, int TH>
+__device__ __forceinline__ void heads_dma_w2(const char *w2, int head_conv, char *s_w2, int wv, int l, int soff)
+{
+    using C = HeadsCfg<T, TH>;
+    constexpr int ES = sizeof(T);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)w2, 0, 32 * HC_MT2 * head_conv * ES, 0x00020000);
+    constexpr int NI = 32 * HC_MT2 / C::RPI;                 // 12 / 24 wave-instructions
+#pragma unroll
+    for (int j = 0; j < (NI + 7) / 8; ++j) {
+        const int g = j * 8 + wv;
+        if (g < NI) {
+            const int row = g * C::RPI + l / C::CPR;
+            const int c = (l % C::CPR) ^ ((row >> C::SWZ_SHIFT) & (C::CPR - 1));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(s_w2 + g * 1024), 16,
+                                                     row * head_conv * ES + c * 16, soff, 0, 0);
+        }
+    }
+}
+
 template <typename T, int TH, int M2, bool BIASC>
 __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 {
@@ -198,35 +233,17 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     // ---- LDS-DMA of stage s: TAPS taps x 64 rows of W1 for (head, slab) -> ring slot s & 1 -----------
     // lane i of a wave-instruction lands at byte i*16 of a 1 KB run = RPI rows; it fetches source
     // chunk (i % CPR) ^ swz(row) so that LDS position p of a row holds chunk p ^ swz(row).
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const int w1_bytes = a.nheads * a.head_conv * 9 * HC_IN * ES;
     auto issue_w1 = [&](int s) {
         if ((H3D_DBG(a) & 1) && s > 0) return;
         const int hs = s / C::TRS, tr = s - hs * C::TRS;        // hs = head * slabs + slab
-        const int head = hs / slabs, slab = hs - head * slabs;
-        char *slot = s_ring + (s & 1) * C::SLOT;
-        constexpr int NI = C::TAPS * HC_SLAB / C::RPI;          // wave-instructions per stage (24 / 16)
-#pragma unroll
-        for (int j = 0; j < NI / 8; ++j) {
-            const int g = j * 8 + wv;                            // 1 KB run index
-            const int row_all = g * C::RPI + l / C::CPR;         // = tap_in_stage * 64 + row
-            const int tp = row_all / HC_SLAB, row = row_all - tp * HC_SLAB;
-            const int c = (l % C::CPR) ^ ((row >> C::SWZ_SHIFT) & (C::CPR - 1));
-            const size_t chan = (size_t)head * a.head_conv + slab * HC_SLAB + row;
-            glds16(a.w1 + ((chan * 9 + tr * C::TAPS + tp) * HC_IN) * ES + c * 16, slot + g * 1024);
-        }
+        heads_dma_w1<T, TH>(a.w1, w1_bytes, s_ring + (s & 1) * C::SLOT, wvs, l, ((hs * HC_SLAB * 9 + tr * C::TAPS) * HC_IN) * ES);
     };
     // ---- LDS-DMA of the 1x1 slice [96 rows][64 K of this slab] -> s_w2 --------------------------------
     auto issue_w2 = [&](int head, int slab) {
         if (H3D_DBG(a) & 1) return;
-        constexpr int NI = 32 * HC_MT2 / C::RPI;                 // 12 / 24 wave-instructions
-#pragma unroll
-        for (int j = 0; j < (NI + 7) / 8; ++j) {
-            const int g = j * 8 + wv;
-            if (g < NI) {
-                const int row = g * C::RPI + l / C::CPR;
-                const int c = (l % C::CPR) ^ ((row >> C::SWZ_SHIFT) & (C::CPR - 1));
-                glds16(a.w2[head] + ((size_t)row * a.head_conv + slab * HC_SLAB) * ES + c * 16, s_w2 + g * 1024);
-            }
-        }
+        heads_dma_w2<T, TH>(a.w2[head], a.head_conv, s_w2, wvs, l, slab * HC_SLAB * ES);
     };
 
     // ---- prologue: stage 0 weights in flight, halo tile (all 64 channels, zero outside the image) -----
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     for (int n = 0; n < NT; ++n) boff[n] = (wv * NT + n) * C::RB + r * C::SB + 8 * h * ES;
 
 #ifdef H3D_ABLATE
-    unsigned long long t_bar = 0, t_g2 = 0, t_dma = 0;
+    unsigned long long t_bar = 0, t_g2 = 0, t_dma = 0, t_stage = 0;
     const unsigned long long t_start = __builtin_readcyclecounter();
 #endif
     int s = 0;
@@ -304,8 +321,8 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                 }
                 constexpr int NSTEP = C::TAPS * (HC_IN / 16);
                 if constexpr (ES == 2 && M2 == 1 && HEADS_PF > 0) {
-                    // bf16, narrow heads (registers to spare; a spilled fragment register would be saved before its data
-                    // arrived, so the wider variants -- which spill -- keep the compiler's schedule): explicit software pipeline.  The fragments of step i+1 (a step = one tap x 16 channels: 2 filter
+                    // bf16, narrow heads (the 3-tile instantiation spills with it, in the 2-tile one it measures the same as the
+                    // compiler's schedule: 0.279 / 0.287 vs 0.280 ms at depth 2 / 1): explicit software pipeline.  The fragments of step i+1 (a step = one tap x 16 channels: 2 filter
                     // + NT pixel fragments feeding 2*NT MFMAs) are requested BEFORE the MFMAs of step i and waited for with a
                     // counted s_waitcnt.  Left to itself hipcc issues every ds_read right in front of its MFMA behind
                     // lgkmcnt(0) -- and does so even when the loads are hoisted in the source -- so the reads are inline asm
@@ -383,8 +400,16 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                     heads_issue_bias(a.b1 + (head + 1) * a.head_conv, a.head_conv, a.b2[head + 1],   // previous head's epilogue, at least one barrier ago
                                      s_bias + ((head + 1) & 1) * C::LDS_BIAS, __builtin_amdgcn_readfirstlane(wv), l);
                 const char *slot = s_ring + (s & 1) * C::SLOT;
-                if (BIASC && tr == 0) stage(std::true_type{}, slot, tr);
+#ifdef H3D_ABLATE
+                const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+                if ((H3D_DBG(a) & 4) && wv >= 4) { /* profiling: only the older wave of each SIMD computes (timing only) */ }
+                else if ((H3D_DBG(a) & 8) && wv < 4) { /* profiling: only the younger wave computes */ }
+                else if (BIASC && tr == 0) stage(std::true_type{}, slot, tr);
                 else stage(std::false_type{}, slot, tr);
+#ifdef H3D_ABLATE
+                t_stage += __builtin_readcyclecounter() - ts0;
+#endif
 #ifdef H3D_ABLATE
                 const unsigned long long tb0 = __builtin_readcyclecounter();
                 __builtin_amdgcn_s_waitcnt(0x0f70);          // my own DMA pieces of the next stage
@@ -442,6 +467,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
             a.stamps[blockIdx.x * H3D_NSTAMP + 2] = t_bar;
             a.stamps[blockIdx.x * H3D_NSTAMP + 3] = t_g2;
             a.stamps[blockIdx.x * H3D_NSTAMP + 4] = t_dma;
+            a.stamps[blockIdx.x * H3D_NSTAMP + 5] = t_stage;
         }
     }
 #endif

@@ -17,9 +17,11 @@ det.run(x); torch.cuda.synchronize()
 plan = det.model.engine(dev).plan(B, 512, 512)
 L = _lib.lib()
 L.h3d_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+DBG = int([a for a in sys.argv if a.startswith("dbg=")][0][4:]) if any(a.startswith("dbg=") for a in sys.argv) else 0
 for i in [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_HEADS]:
     op = plan.ops[i]
     arr = (_lib.H3dOp * 1)(op)
+    arr[0].reserved = DBG          # ablation bits: 1 no weight stream, 2 no stage barrier, 4 / 8 only the older / younger wave of a SIMD computes
     for _ in range(2):
         _lib.check(L.h3d_run_ops(arr, 1, _lib.stream_ptr()), "run")
     torch.cuda.synchronize()
@@ -35,5 +37,5 @@ for i in [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_HEADS]:
         assert L.h3d_debug_stamps(buf.ctypes.data, n * 8) == 0
         tw = buf.reshape(n, 8).astype(np.float64)
         print("   barrier share per wave 0..7: " + " ".join("%.1f%%" % (100 * (tw[:, w] / tot).mean()) for w in range(8)))
-    print("op %d %s: %d workgroups, mean %.0f ticks; own DMA pieces (vmcnt) %.1f %%, barrier %.1f %%, gemm2 %.1f %%" % (
-        i, kernel_name(op).replace("unsigned short", "bf"), n, tot.mean(), 100 * (t[:, 4] / tot).mean(), 100 * (t[:, 2] / tot).mean(), 100 * (t[:, 3] / tot).mean()))
+    print("op %d %s: %d workgroups, mean %.0f ticks; tap-row stages (fragment reads + MFMA) %.1f %%, own DMA pieces (vmcnt) %.1f %%, barrier %.1f %%, gemm2 %.1f %%" % (
+        i, kernel_name(op).replace("unsigned short", "bf"), n, tot.mean(), 100 * (t[:, 5] / tot).mean(), 100 * (t[:, 4] / tot).mean(), 100 * (t[:, 2] / tot).mean(), 100 * (t[:, 3] / tot).mean()))
