@@ -29,6 +29,7 @@ struct Conv2Args {
     int G, tiles_x, tiles_y;
     int dbg;   // ABLATE builds only (op.reserved >> 16): 1 = no DMA after stage 0, 2 = no fragment reads / MFMA
     int xcd;   // h3d_tile_id mode
+    unsigned long long *stamps;   // profiling builds: per workgroup and wave (0-7) the cycles spent at the stage barrier; slot 7: wave 0's {DMA issue} (tools/stamp_conv2.py)
 };
 
 template <int MT, int WAVES, int S = 1, int SLOTS = 2, int NT = 1>
@@ -139,6 +140,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
         if (j < nst && (SLOTS > 1 || j == 0))
             conv2_issue<MT, WAVES, S, NT>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + j * C::SLOT, hoff, woff, wv, j, (j * a.G + g0) * C::WGRP, H3D_DBG(a));
     int cslot = 0, pslot = AHEAD % SLOTS;          // slot consumed by stage s / filled with stage s + AHEAD
+#ifdef H3D_ABLATE
+    unsigned long long t_bar = 0, t_iss = 0;
+    const unsigned long long t_start = __builtin_readcyclecounter();
+#endif
     for (int s = 0; s < nst; ++s) {
         if constexpr (SLOTS == 1) {
             // one slot, several stages: the stage is fetched once nobody reads its predecessor any more; the wait is
@@ -151,10 +156,20 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
         // my pieces of stage s have landed once only stage s+1's may be outstanding (vmcnt retires in order)
         if (AHEAD == 2 && s + 1 < nst) __builtin_amdgcn_s_waitcnt(WAIT_PMIN);
         else __builtin_amdgcn_s_waitcnt(0x0f70);
+#ifdef H3D_ABLATE
+        const unsigned long long tb0 = __builtin_readcyclecounter();
+#endif
         h3d_barrier_keep_vmcnt();                 // ... everyone's have; the slot of stage s-1 is no longer being read (not
                                                   // __syncthreads: its release fence waits for the younger stage's DMA too)
+#ifdef H3D_ABLATE
+        const unsigned long long tb1 = __builtin_readcyclecounter();
+        t_bar += tb1 - tb0;
+#endif
         if (SLOTS > 1 && s + AHEAD < nst && !(H3D_DBG(a) & 1))
             conv2_issue<MT, WAVES, S, NT>(in_b, (int)img_bytes, a.wimg, w_bytes, smem + pslot * C::SLOT, hoff, woff, wv, s + AHEAD, ((s + AHEAD) * a.G + g0) * C::WGRP, H3D_DBG(a));
+#ifdef H3D_ABLATE
+        t_iss += __builtin_readcyclecounter() - tb1;
+#endif
         const char *sl = smem + cslot * C::SLOT;
         cslot = cslot + 1 == SLOTS ? 0 : cslot + 1;
         pslot = pslot + 1 == SLOTS ? 0 : pslot + 1;
@@ -201,6 +216,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
         }
     }
 
+#ifdef H3D_ABLATE
+    if (a.stamps && blockIdx.x < 65536 && blockIdx.y == 0 && l == 0) {
+        const unsigned long long t_loop = __builtin_readcyclecounter() - t_start;
+        if (wv < 4) a.stamps[blockIdx.x * H3D_NSTAMP + wv] = t_bar;                 // waves 0-3: the oldest wave of each SIMD
+        if (wv >= WAVES - 3) a.stamps[blockIdx.x * H3D_NSTAMP + 4 + (wv - (WAVES - 3))] = t_bar;   // the three youngest
+        if (wv == 0) a.stamps[blockIdx.x * H3D_NSTAMP + 7] = (t_iss << 32) | (t_loop & 0xffffffffull);
+    }
+#endif
     EpiArgs e;
     e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
@@ -221,6 +244,11 @@ static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
     a.tiles_x = cdiv(a.Wo, 16);
     a.tiles_y = cdiv(a.Ho, C::TH);
     a.xcd = h3d_xcd_mode();
+#ifdef H3D_ABLATE
+    a.stamps = h3d_stamp_buffer();
+#else
+    a.stamps = nullptr;
+#endif
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4)) ? 2 : lean ? 1 : 0;
