@@ -38,10 +38,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import h3d_amd  # noqa: E402,F401
 from h3d_amd import _lib, arch, synth  # noqa: E402
-from h3d_amd.detector import MultiPoseDetector, Opt, gather_detections  # noqa: E402
+from h3d_amd.detector import MultiPoseDetector, Opt, gather_detections, shard_batch  # noqa: E402
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_MFMA_TFLOPS = {"bf16": PEAK_BF16_MFMA_TFLOPS, "f16": PEAK_BF16_MFMA_TFLOPS, "f32": 157.3}
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # this round's counter passes; a kernel that is not in it reports traffic: null
 
 
 def op_flops(op):
@@ -98,12 +100,15 @@ def per_kernel_profile(plan, iters):
     for _ in range(iters):
         _lib.check(_lib.lib().h3d_run_ops_timed(plan.op_array, n, _lib.stream_ptr(), ms), "run_ops_timed")
         passes.append(np.frombuffer(ms, dtype=np.float32, count=n).copy())
-    tot = np.median(np.stack(passes), axis=0)      # per launch: the median pass (one stalled pass moved a family by 37 % once)
+    st = np.stack(passes)
+    tot = np.median(st, axis=0)      # per launch: the median pass; the min / max passes are reported beside it
+    lo, hi = st.min(axis=0), st.max(axis=0)
     groups = {}
     for i, op in enumerate(plan.ops):
-        real_cout = op.Cout
-        g = groups.setdefault(kernel_name(op), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        g = groups.setdefault(kernel_name(op), {"ms": 0.0, "ms_min": 0.0, "ms_max": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
         g["ms"] += float(tot[i])
+        g["ms_min"] += float(lo[i])
+        g["ms_max"] += float(hi[i])
         g["flops"] += op_flops(op)
         g["bytes"] += op_bytes(op)
         g["launches"] += 1
@@ -154,51 +159,67 @@ def cpu_baseline(opt, sd, seconds_budget=20.0, keep=None):
                       "4 fp64 SMPL meshes/image)" % (iters, B, cores)}
 
 
-def dcn_pass2_fraction(det, images2, dev):
-    """Share of DeformConv samples (pixel x tap) whose bilinear corners leave the LDS apron of their 16x16 tile and go
-    through the kernels' global-gather pass 2, for the weights this run uses (synthetic offsets are small; trained
-    networks have larger ones -- `--offset-scale`).  The fused kernels never write their offsets, so an UNFUSED twin of
-    the plan (conv_offset_mask as its own launch) is run on 2 images and the test of csrc/dcn3.hip / dcn4.hip
-    (`ry >= 0 && ry + 1 < HH && ...`) is evaluated on its offset maps with each layer's own apron margin."""
+def dcn_apron_stats(det, images2, dev):
+    """How far the DeformConv samples of THIS run's weights reach (synthetic offsets are small; trained networks have
+    larger ones -- `--offset-scale`).  Per (pixel, tap) sample: does a bilinear corner leave the LDS apron of its 16x16
+    tile (`apron_miss_frac`: such samples take one of the tile's NP patch slots, csrc/dcn3.hip), and per tile: are there
+    more such samples than slots (`tiles_over_slots_frac`: only those tiles run the slow global-gather pass 2).  The
+    fused kernels never write their offsets, so an UNFUSED twin of the plan (conv_offset_mask as its own launch) is run
+    on 2 images and the kernels' test (`ry >= 0 && ry + 1 < HH && ...`) is evaluated on its offset maps with each
+    layer's own apron margin and slot count."""
     import re
     from h3d_amd.engine import Plan
     eng = det.model.engine(dev)
     B, _, H, W = images2.shape
     fused = Plan(eng.pw, B, H, W, **eng._flags())
-    margins = []
+    cfgs = []                      # (margin, patch slots) per DeformConv launch
     for op in fused.ops:
-        if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_STREAM):
-            margins.append(int(re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+),", kernel_name(op)).group(1)))
+        name = kernel_name(op)
+        if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_STREAM, _lib.OP_UPDCN_STREAM):
+            m = re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+), \d+, \w+, (\d+)", name) or re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+)", name)
+            if m is None:
+                return {"error": "unrecognised DeformConv kernel name %r" % name}
+            cfgs.append((int(m.group(1)), int(m.group(2)) if m.lastindex >= 2 else 0))
         elif op.kind in (_lib.OP_DCN_FUSED_F16, _lib.OP_UPDCN_F16):
-            margins.append(1 if re.match(r"dcn4_kernel<\d+, \d+, 1,", kernel_name(op)) else 2)
-    twin = Plan(eng.pw, B, H, W, **dict(eng._flags(), fuse_offsets=False))
+            cfgs.append((1 if re.match(r"dcn4_kernel<\d+, \d+, 1,", name) else 2, 0))
+    twin = Plan(eng.pw, B, H, W, **dict(eng._flags(), fuse_offsets=False, fuse_updcn3=False))
     twin.op_array[0].in_ = images2.data_ptr()
     twin.run()
     torch.cuda.synchronize()
     dcn_ops = [op for op in twin.ops if op.kind == _lib.OP_DCN]
-    assert len(dcn_ops) == len(margins), (len(dcn_ops), len(margins))
-    slow_all = tot_all = 0.0
-    worst, mean_abs = 0.0, []
-    for op, M in zip(dcn_ops, margins):
+    if len(dcn_ops) != len(cfgs):
+        return {"error": "twin plan has %d DeformConvs, fused plan %d" % (len(dcn_ops), len(cfgs))}
+    miss_all = tot_all = 0.0
+    tiles_over = tiles_all = 0
+    worst, worst_tiles, mean_abs = 0.0, 0.0, []
+    for op, (M, NP) in zip(dcn_ops, cfgs):
         om = [t for t in twin.keep if torch.is_tensor(t) and t.data_ptr() == op.in2][0]      # [B,h,w,32] fp32
         h, w = om.shape[1], om.shape[2]
         ys = torch.arange(h, device=dev, dtype=torch.float32).view(1, h, 1)
         xs = torch.arange(w, device=dev, dtype=torch.float32).view(1, 1, w)
         y0, x0 = ys - ys % 16 - 1 - M, xs - xs % 16 - 1 - M              # apron origin of the pixel's tile
         HH = 18 + 2 * M
-        slow = tot = 0.0
+        miss = torch.zeros(om.shape[:3], device=dev)
         for t in range(9):
             ti, tj = divmod(t, 3)
             h_im, w_im = ys - 1 + ti + om[..., 2 * t], xs - 1 + tj + om[..., 2 * t + 1]
             inside = (h_im > -1) & (w_im > -1) & (h_im < h) & (w_im < w)
             ry, rx = torch.floor(h_im) - y0, torch.floor(w_im) - x0
             ok = (ry >= 0) & (ry + 1 < HH) & (rx >= 0) & (rx + 1 < HH)
-            slow += float((inside & ~ok).sum())
-            tot += float(inside.numel())
+            miss += (inside & ~ok).float()
+        th, tw = -(-h // 16), -(-w // 16)
+        pad = torch.zeros(om.shape[0], th * 16, tw * 16, device=dev)
+        pad[:, :h, :w] = miss
+        per_tile = pad.view(-1, th, 16, tw, 16).sum(dim=(2, 4))           # samples of a tile that want a slot
+        over = float((per_tile > NP).sum())
+        tiles_over, tiles_all = tiles_over + over, tiles_all + per_tile.numel()
+        worst_tiles = max(worst_tiles, over / per_tile.numel())
         mean_abs.append(float(om[..., :18].abs().mean()))
-        slow_all, tot_all = slow_all + slow, tot_all + tot
-        worst = max(worst, slow / tot)
-    return {"layers": len(margins), "samples_pass2_frac": round(slow_all / tot_all, 5), "worst_layer_frac": round(worst, 5),
+        m_l, t_l = float(miss.sum()), 9.0 * miss.numel()
+        miss_all, tot_all = miss_all + m_l, tot_all + t_l
+        worst = max(worst, m_l / t_l)
+    return {"layers": len(cfgs), "apron_miss_frac": round(miss_all / tot_all, 5), "worst_layer_apron_miss_frac": round(worst, 5),
+            "tiles_over_slots_frac": round(tiles_over / max(tiles_all, 1), 5), "worst_layer_tiles_over_slots_frac": round(worst_tiles, 5),
             "mean_abs_offset_px": round(float(np.mean(mean_abs)), 3)}
 
 
@@ -264,10 +285,16 @@ def dry_run(args, world, rank):
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("gloo")
-    dets = torch.full((args.batch, 100, 40), float(rank))
+    strong = args.global_batch > 0
+    if strong:
+        lo, hi = shard_batch(args.global_batch, rank, world)
+        n_global = args.global_batch
+    else:
+        lo, hi, n_global = rank * args.batch, (rank + 1) * args.batch, world * args.batch
+    dets = torch.full((hi - lo, 100, 40), float(rank))
 
     def step():
-        return gather_detections(dets, n_images=world * args.batch) if world > 1 else dets
+        return gather_detections(dets, n_images=n_global) if world > 1 else dets
 
     for _ in range(args.warmup):
         step()
@@ -283,17 +310,156 @@ def dry_run(args, world, rank):
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert out.shape == (world * args.batch, 100, 40)
-    assert all(float(out[r * args.batch, 0, 0]) == r for r in range(world))
+    assert out.shape == (n_global, 100, 40)
+    assert all(float(out[shard_batch(n_global, r, world)[0], 0, 0]) == r for r in range(world))
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "value": round(world * args.batch * args.steps / dt, 2), "unit": "images/s",
+        print(json.dumps({"metric": METRIC, "value": round(n_global * args.steps / dt, 2), "unit": "images/s",
                           "n_gpus": world, "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "dry_run": True,
-                          "config": {"workload": "DRY RUN: all-gather of dets only (gloo, CPU)", "batch_per_gpu": args.batch,
-                                     "global_batch": world * args.batch}}))
+                          "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "dry_run": True,
+                          "config": {"workload": "DRY RUN: all-gather of dets only (gloo, CPU)", "batch_per_gpu": hi - lo,
+                                     "global_batch": n_global}}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def build_detector(arch_name, dtype, size, args, dev, people=None):
+    """-> (detector, opt, synthetic state_dict, conv GFLOP per image) for one of the three backbones."""
+    if arch_name == "dla_34":
+        opt = Opt(input_h=size, input_w=size, smpl=True, smpl_people=args.people if people is None else people, dtype=dtype, K=100)
+        sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, offset_scale=args.offset_scale, gain=args.weight_gain)
+        det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
+        return det, opt, sd, arch.conv_flops(opt.heads, True, size, size) / 1e9
+    from h3d_amd import arch_hg, arch_res
+    from h3d_amd.detector import make_detector
+    if arch_name == "hourglass":
+        opt = Opt(arch="hourglass", input_h=size, input_w=size, dtype=dtype, K=100)
+        shapes, gain = arch_hg.state_dict_shapes(opt.heads), 0.8
+        gflop_img = arch_hg.conv_flops(opt.heads, size, size) / 1e9
+    else:
+        opt = Opt(arch="resdcn_101", task="ctdet", input_h=size, input_w=size, dtype=dtype, K=100)
+        shapes, gain = arch_res.state_dict_shapes(opt.heads, 64), 0.9
+        gflop_img = arch_res.conv_flops(opt.heads, size, size) / 1e9
+    sd = synth.synth_state_dict(shapes, seed=0, offset_scale=args.offset_scale, gain=gain)
+    det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
+    return det, opt, sd, gflop_img
+
+
+def workload_name(arch_name, size, batch, strong, n_global):
+    split = ("one batch of %d split over the ranks (this rank: %d)" % (n_global, batch)) if strong else ("batch %d per GPU" % batch)
+    if arch_name == "dla_34":
+        return ("DLA-34+DCNv2 multi_pose + pose/shape heads -> sigmoid/NMS/top-100 decode -> SMPL 6890-vert LBS; "
+                "%dx%d, %s (BASELINE configs[2])" % (size, size, split))
+    if arch_name == "hourglass":
+        return "Hourglass-104 multi_pose -> decode; %dx%d, %s (BASELINE configs[3]: 128 over 8 GPUs = 16)" % (size, size, split)
+    return "ResNet-101-DCN ctdet -> decode; %dx%d, %s (BASELINE configs[4]: 256 over 8 GPUs = 32)" % (size, size, split)
+
+
+def make_step(det, images, nslot, world, n_global, dev):
+    """-> (step(), per-image dets shape).  step() issues one batch: consecutive calls alternate between `nslot` HIP streams, each
+    with its own copy of the plan's buffers; for world > 1 the single collective (all-gather of dets) follows on the
+    default stream, in step order."""
+    slot_streams = [torch.cuda.Stream(device=dev) for _ in range(nslot)] if nslot > 1 else [None]
+    counter = [0]
+    dets_shape = (det.opt.K, 6 if det.opt.task == "ctdet" else 40)
+
+    def step():
+        k = counter[0] % nslot
+        counter[0] += 1
+        if slot_streams[k] is None:
+            res = det.run(images, slot=0)
+            return gather_detections(res["dets"], n_images=n_global) if world > 1 else res["dets"]
+        with torch.cuda.stream(slot_streams[k]):
+            res = det.run(images, slot=k)
+            if world == 1:
+                return res["dets"]
+            done = torch.cuda.Event()
+            done.record()
+        # the collective is always issued from the default stream, in step order (one communicator, one stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        res["dets"].record_stream(cur)
+        return gather_detections(res["dets"], n_images=n_global)
+
+    return step, dets_shape
+
+
+def time_steps(step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def shard_sweep(det, images, nslot, dev, batches, steps=10):
+    """images/s of the SAME detector on the first B images of the batch, for the shard sizes a strong-scaling run of the
+    headline batch would hand one GPU (64 over 8 / 4 / 2 GPUs).  Same step as the timed region (network + decode + SMPL,
+    `nslot` steps in flight); measured after it, on one GPU."""
+    out = {}
+    for b in batches:
+        if b >= images.shape[0]:
+            continue
+        sub = images[:b].contiguous()
+        step, _ = make_step(det, sub, nslot, 1, b, dev)
+        dt = time_steps(step, steps, 3)
+        out[str(b)] = {"images_per_s": round(b * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3)}
+    return out
+
+
+def annotate_index_match(m, dtype):
+    """`robust_prefix_equal` is vacuous when no rank is provably stable under the measured score error: say so."""
+    m = dict(m)
+    m["dtype"] = dtype
+    if m["robust_prefix"] == 0:
+        m["bit_match_evidence"] = ("none: no rank's order is provably stable under this plan's score error (robust_prefix 0), so "
+                                   "robust_prefix_equal holds vacuously -- read agreement / set_overlap")
+    else:
+        m["bit_match_evidence"] = ("the first %d ranks cannot change order under the measured score error and are %s on the GPU"
+                                   % (m["robust_prefix"], "bit-identical" if m["robust_prefix_equal"] else "NOT identical"))
+    return m
+
+
+def parity_mode(args, size, images, keep, dev, steps=3):
+    """The metric's second clause on the SAME workload: the f32 plan (exact fmaf chains on v_mfma_f32_32x32x2_f32) timed on the
+    same 64 images, and its top-k peak indices on the cpu_baseline's 2 images against the fp32 oracle."""
+    from oracle import index_match as oim
+    det32, opt32, _, gflop = build_detector("dla_34", "f32", size, args, dev)
+    step, _ = make_step(det32, images, 1, 1, images.shape[0], dev)
+    dt = time_steps(step, steps, 1)
+    res = det32.run(keep["images"].to(dev))
+    m = annotate_index_match(oim.index_match({k: v.cpu().numpy() for k, v in res["heads"].items()}, res["inds"].cpu().numpy(),
+                                             keep["heads"], K=opt32.K), "f32")
+    out = {"dtype": "f32", "images_per_s": round(images.shape[0] * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "batch": int(images.shape[0]), "step_frac_of_f32_mfma_peak": round(gflop * images.shape[0] * steps / dt / 1e3 / PEAK_MFMA_TFLOPS["f32"], 4),
+           "index_match": m}
+    del det32
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_archs(args, dev, steps=5):
+    """The per-GPU shards of BASELINE configs[3] / [4] (what `--arch hourglass` / `--arch resdcn_101` time), a few steps each
+    after the headline measurement, so that the driver's one command observes them too: network + decode, no SMPL stage."""
+    out = {}
+    for name, batch, size, dtype, nslot in (("hourglass", 16, 512, "bf16", 3), ("resdcn_101", 32, 768, "f16", 2)):
+        try:
+            det, opt, _, gflop = build_detector(name, dtype, size, args, dev)
+            images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317)).to(dev)
+            step, _ = make_step(det, images, nslot, 1, batch, dev)
+            dt = time_steps(step, steps, 2)
+            out[name] = {"images_per_s": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "batch_per_gpu": batch,
+                         "size": size, "dtype": dtype, "steps": steps, "steps_in_flight": nslot,
+                         "model_tflops": round(gflop * batch * steps / dt / 1e3, 1)}
+            del det, images
+            torch.cuda.empty_cache()
+        except Exception as e:          # a record measured AFTER the headline number must not take the line down with it
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 METRIC = "images/sec whole-node, DLA-34+SMPL batch-64 512x512; top-k index bit-match"
@@ -304,8 +470,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (weak scaling: the default)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="> 0: STRONG scaling -- one batch of this many images per step for the whole job, rank r takes the "
+                         "contiguous slice detector.shard_batch(G, r, world) (the reference's DataParallel scatter of ONE batch, "
+                         "trains/trainer.py:176; SURVEY 8e: batch 64 -> 8 per GPU on 8 GPUs); the line then says \"scaling\": \"strong\"")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the records measured after the timed region (shard_sweep, parity_mode, other_archs)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--people", type=int, default=100, help="SMPL meshes per image (<= K)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batches run concurrently on their own HIP streams")
     ap.add_argument("--pipeline", type=int, default=None,
@@ -351,62 +523,35 @@ def main():
 
     dla = args.arch == "dla_34"
     size = args.size or (768 if args.arch == "resdcn_101" else 512)
-    if dla:
-        opt = Opt(input_h=size, input_w=size, smpl=True, smpl_people=args.people, dtype=args.dtype, K=100)
-        sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, offset_scale=args.offset_scale, gain=args.weight_gain)
-        det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
-        gflop_img = arch.conv_flops(opt.heads, True, size, size) / 1e9
+    strong = args.global_batch > 0
+    if strong:
+        lo, hi = shard_batch(args.global_batch, rank, world)
+        batch, n_global = hi - lo, args.global_batch
+        if batch == 0:
+            raise SystemExit("--global-batch %d leaves rank %d of %d without images" % (args.global_batch, rank, world))
     else:
-        from h3d_amd import arch_hg, arch_res
-        from h3d_amd.detector import make_detector
-        if args.arch == "hourglass":
-            opt = Opt(arch="hourglass", input_h=size, input_w=size, dtype=args.dtype, K=100)
-            shapes, gain = arch_hg.state_dict_shapes(opt.heads), 0.8
-            gflop_img = arch_hg.conv_flops(opt.heads, size, size) / 1e9
-        else:
-            opt = Opt(arch="resdcn_101", task="ctdet", input_h=size, input_w=size, dtype=args.dtype, K=100)
-            shapes, gain = arch_res.state_dict_shapes(opt.heads, 64), 0.9
-            gflop_img = arch_res.conv_flops(opt.heads, size, size) / 1e9
-        sd = synth.synth_state_dict(shapes, seed=0, offset_scale=args.offset_scale, gain=gain)
-        det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
-    det.model.engine(dev).streams = args.streams
+        lo, batch, n_global = rank * args.batch, args.batch, world * args.batch
+    det, opt, sd, gflop_img = build_detector(args.arch, args.dtype, size, args, dev)
+    eng = det.model.engine(dev)
+    eng.streams = args.streams
     for kv in args.engine_flag:
         name, val = kv.split("=")
-        setattr(det.model.engine(dev), name, int(val))
-    images = torch.from_numpy(synth.synth_images(1, size, size, seed=317 + rank)).to(dev)
-    images = images.expand(args.batch, 3, size, size).contiguous()
-    images += 0.01 * torch.arange(args.batch, device=dev, dtype=torch.float32).view(-1, 1, 1, 1)   # distinct images
+        setattr(eng, name, int(val))
+    # every image of the job is a different synthetic image (image i of the global batch is a pure function of i)
+    images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317, first=lo)).to(dev)
 
     nslot = max(1, args.pipeline if args.pipeline is not None else (3 if args.arch == "hourglass" else 2))
-    slot_streams = [torch.cuda.Stream(device=dev) for _ in range(nslot)] if nslot > 1 else [None]
-    counter = [0]
-
-    def step():
-        k = counter[0] % nslot
-        counter[0] += 1
-        if slot_streams[k] is None:
-            res = det.run(images, slot=0)
-            return gather_detections(res["dets"], n_images=world * args.batch) if world > 1 else res["dets"]
-        with torch.cuda.stream(slot_streams[k]):
-            res = det.run(images, slot=k)
-            if world == 1:
-                return res["dets"]
-            done = torch.cuda.Event()
-            done.record()
-        # the collective is always issued from the default stream, in step order (one communicator, one stream)
-        cur = torch.cuda.current_stream()
-        cur.wait_event(done)
-        res["dets"].record_stream(cur)
-        return gather_detections(res["dets"], n_images=world * args.batch)
+    if args.streams > 1:
+        nslot = 1              # sub-batch streams and plan slots are two uses of the same idea; not combined in the bench
+    step, dets_shape = make_step(det, images, nslot, world, n_global, dev)
 
     # one-time setup outside both warm-up and the timed region: weight packing + plan lowering (host work and uploads,
     # no network launches) and the SMPL model upload.  The first launch of every kernel still pays its code-object
     # load, so keep --warmup >= 1
     t_setup = time.perf_counter()
-    eng = det.model.engine(dev)
     if args.streams <= 1:                       # (the sub-batch plans of --streams N are built by the first step)
         for k in range(nslot):
-            eng.plan(args.batch, size, size, k)
+            eng.plan(batch, size, size, k)
     from h3d_amd import smpl as _smpl
     if dla and det.smpl_model._dev is None:
         det.smpl_model._dev = _smpl._device_pack(det.smpl_model, dev)
@@ -434,82 +579,95 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert out.shape == (world * args.batch, 100, 6 if args.arch == "resdcn_101" else 40)
+    assert out.shape == (n_global,) + dets_shape, (out.shape, n_global, dets_shape)
     if rank == 0:
-        print("[bench] %d GPU(s): %.1f images/s, %.3f ms/step" % (world, world * args.batch * args.steps / dt,
+        print("[bench] %d GPU(s): %.1f images/s, %.3f ms/step" % (world, n_global * args.steps / dt,
                                                                  1e3 * dt / args.steps), file=sys.stderr, flush=True)
 
     if rank == 0:
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else 157.3
+        peak = PEAK_MFMA_TFLOPS[args.dtype]
         line = {
             "metric": METRIC,
-            "value": round(world * args.batch * args.steps / dt, 2), "unit": "images/s",
+            "value": round(n_global * args.steps / dt, 2), "unit": "images/s",
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": ("DLA-34+DCNv2 multi_pose + pose/shape heads -> sigmoid/NMS/top-100 decode -> "
-                                    "SMPL 6890-vert LBS; 512x512, batch %d per GPU (BASELINE configs[2])" % args.batch) if dla else
-                                   ("Hourglass-104 multi_pose -> decode; %dx%d, batch %d per GPU (BASELINE configs[3]: 128 over 8 GPUs = 16)"
-                                    % (size, size, args.batch)) if args.arch == "hourglass" else
-                                   ("ResNet-101-DCN ctdet -> decode; %dx%d, batch %d per GPU (BASELINE configs[4]: 256 over 8 GPUs = 32; "
-                                    "bf16 where the config says fp16)" % (size, size, args.batch)),
-                       "batch_per_gpu": args.batch, "global_batch": world * args.batch, "K": 100,
-                       "smpl_people_per_image": args.people, "conv_gflop_per_image": round(gflop_img, 2),
+            "config": {"workload": workload_name(args.arch, size, batch, strong, n_global),
+                       "batch_per_gpu": batch, "global_batch": n_global, "K": 100,
+                       "smpl_people_per_image": args.people if dla else 0, "conv_gflop_per_image": round(gflop_img, 2),
                        "parallelism": "dp%d (image shards, one all-gather of dets)" % world,
                        "steps_in_flight": nslot,
-                       "weights": "synthetic (h3d_amd.synth, seed 0, gain %g, offset_scale %g)" % (args.weight_gain, args.offset_scale)},
+                       "images": "%d distinct synthetic images (h3d_amd.synth.synth_image_batch, seed 317)" % n_global,
+                       "weights": "synthetic (h3d_amd.synth, seed 0, gain %s, offset_scale %g)"
+                                  % ("%g" % args.weight_gain if dla else "per arch", args.offset_scale)},
+            # what the metric's second clause ("top-k index bit-match") can mean per arithmetic: see index_match / parity_mode
+            "metric_note": "value = throughput of the %s plan; top-k index bit-match against the fp32 oracle is attainable in the f32 "
+                           "plan only (parity_mode), the %s plan is reported with set overlap / agreement (index_match)" % (args.dtype, args.dtype),
         }
         line["model_tflops"] = round(gflop_img * line["value"] / 1e3 / world, 1)      # per GPU
         if not args.no_roofline:
-            plan = det.model.engine(dev).plan(args.batch, size, size)
+            plan = eng.plan(batch, size, size)
             groups = per_kernel_profile(plan, iters=5)
             total_ms = sum(g["ms"] for g in groups.values())
             name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            traffic, traffic_src = None, None   # HBM bytes per launch from the committed rocprofv3 --pmc passes
-            for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-                try:
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", f)))["kernels"]
-                    traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
-                except (OSError, ValueError, KeyError):
-                    traffic = None
-                if traffic:
-                    traffic_src = "profiles/%s (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 unit corrections)" % f
-                    break
-            net_tflops = args.batch * gflop_img / total_ms                         # GFLOP / ms = TFLOP/s
+            traffic, traffic_src = None, None   # HBM bytes per launch from THIS round's committed rocprofv3 --pmc passes, or null
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))["kernels"]
+                traffic = pmc.get(name, {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError, KeyError):
+                traffic = None
+            if traffic:
+                traffic_src = ("profiles/%s (FETCH_SIZE + WRITE_SIZE, separate --pmc passes, gfx950 unit corrections)" % PMC_TRAFFIC_FILE)
+            net_tflops = batch * gflop_img / total_ms                         # GFLOP / ms = TFLOP/s
             line["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1),
                                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                 "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": g["launches"],
                                 "avg_launch_ms": round(g["ms"] / g["launches"], 4),
+                                "avg_launch_ms_min_max": [round(g["ms_min"] / g["launches"], 4), round(g["ms_max"] / g["launches"], 4)],
                                 "share_of_network_time": round(g["ms"] / total_ms, 3),
                                 "network_ms_per_step": round(total_ms, 3),
                                 # the north_star's target is quoted on the whole DLA-34+DCNv2 forward: all conv FLOP of
                                 # the network / its device time, and the same FLOP / the whole step (decode, SMPL, gather)
-                                "timing": "HIP events around every launch of the plan on one stream, median of 5 passes per launch (independent of "
-                                          "steps_in_flight: kernels of two steps sharing the GPU stretch individual launches)",
+                                "timing": "HIP events around every launch of the plan on one stream, median of 5 passes per launch, min / max pass beside it "
+                                          "(independent of steps_in_flight: kernels of two steps sharing the GPU stretch individual launches)",
                                 "network_tflops": round(net_tflops, 1), "network_frac": round(net_tflops / peak, 4),
                                 "step_frac": round(line["model_tflops"] / peak, 4)}
             print("[bench] roofline %s" % json.dumps(line["roofline"]), file=sys.stderr, flush=True)
-            line["kernels"] = {k: {"ms": round(v["ms"], 3), "n": v["launches"],
+            line["kernels"] = {k: {"ms": round(v["ms"], 3), "ms_min": round(v["ms_min"], 3), "ms_max": round(v["ms_max"], 3), "n": v["launches"],
                                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
                                    "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)}      # algorithmic HBM bytes / time
                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             print("[bench] kernels %s" % json.dumps(line["kernels"]), file=sys.stderr, flush=True)
-            if dla:
-                line["dcn_pass2"] = dcn_pass2_fraction(det, images[:2].contiguous(), dev)
+            if dla and args.dtype != "f32":
+                line["dcn_apron"] = dcn_apron_stats(det, images[:2].contiguous(), dev)
             if world == 1 and dla:
-                line["boundary_op"] = boundary_op_times(min(args.batch, 16), dev)
+                line["boundary_op"] = boundary_op_times(min(batch, 16), dev)
                 print("[bench] boundary_op %s" % json.dumps(line["boundary_op"]), file=sys.stderr, flush=True)
+        extras = world == 1 and dla and not args.no_extras and not strong and args.dtype == "bf16"
+        if extras:
+            # the per-GPU shards a STRONG-scaling run of the headline batch would see (64 over 8 GPUs = 8 per GPU)
+            line["shard_sweep"] = shard_sweep(det, images, nslot, dev, (8, 16, 32))
+            print("[bench] shard_sweep %s" % json.dumps(line["shard_sweep"]), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1 and dla:
             keep = {}
             line["cpu_baseline"] = cpu_baseline(opt, sd, keep=keep)
             # the checker's second use: the same 2 images through the GPU path, indices compared with the oracle's
             from oracle import index_match as oim
             res = det.run(keep["images"].to(dev))
-            line["index_match"] = oim.index_match({k: v.cpu().numpy() for k, v in res["heads"].items()},
-                                                  res["inds"].cpu().numpy(), keep["heads"], K=opt.K)
+            line["index_match"] = annotate_index_match(oim.index_match({k: v.cpu().numpy() for k, v in res["heads"].items()},
+                                                                       res["inds"].cpu().numpy(), keep["heads"], K=opt.K), args.dtype)
             print("[bench] index_match %s" % json.dumps(line["index_match"]), file=sys.stderr, flush=True)
+            if extras:
+                line["parity_mode"] = parity_mode(args, size, images, keep, dev)
+                print("[bench] parity_mode %s" % json.dumps(line["parity_mode"]), file=sys.stderr, flush=True)
+        if extras:
+            del det, eng, images
+            torch.cuda.empty_cache()
+            line["other_archs"] = other_archs(args, dev)
+            print("[bench] other_archs %s" % json.dumps(line["other_archs"]), file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

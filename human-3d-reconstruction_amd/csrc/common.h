@@ -8,8 +8,16 @@
 
 #include "../../include/h3d.h"
 
+#include <type_traits>
 typedef uint16_t bf16_t;  // raw bf16 bits
+struct f16_t { uint16_t bits; };   // raw IEEE fp16 bits: a distinct type, so that templates can tell the two 2-byte element types apart
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+// element-type name as it appears in the kernel symbols rocprofv3 prints
+template <typename T> constexpr const char *h3d_tname() { return std::is_same_v<T, float> ? "float" : std::is_same_v<T, f16_t> ? "f16_t" : "unsigned short"; }
+// host side: element size of an h3d_op dtype (0 = unknown)
+static inline int h3d_dtype_bytes(int dtype) { return dtype == H3D_F32 ? 4 : (dtype == H3D_BF16 || dtype == H3D_F16) ? 2 : 0; }
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -121,6 +129,58 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
     typedef __attribute__((ext_vector_type(2))) __bf16 b2;
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{lo, hi}, b2));   // one v_cvt_pk_bf16_f32 (RNE)
 }
+// two floats -> packed fp16 pair, round-to-nearest-even; callers clamp to +-65504 first (ET<f16_t>::clamp_lo)
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi)
+{
+    return __builtin_bit_cast(uint32_t, f16x2_t{(_Float16)lo, (_Float16)hi});
+}
+
+// fp16 plans (H3D_F16: BASELINE configs[4] runs ResNet-101-DCN in fp16, experiments/ctdet_coco_resdcn101.sh:3): same
+// kernels, v_mfma_f32_32x32x16_f16 (the bf16 rate), 3 more mantissa bits per stored activation; results saturate at
+// +-65504 instead of overflowing to infinity.
+template <> struct ET<f16_t> {
+    static constexpr int BYTES = 2;
+    struct frag { u32x4 v; };
+    static __device__ __forceinline__ frag lds_frag(const char *p)
+    {
+        frag f;
+        f.v = *reinterpret_cast<const u32x4 *>(p);
+        return f;
+    }
+    static __device__ __forceinline__ frag lds_frag2(const char *lo, const char *) { return lds_frag(lo); }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
+    {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.v), __builtin_bit_cast(f16x8_t, b.v), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(f16_t v) { return (float)__builtin_bit_cast(_Float16, v.bits); }
+    static __device__ __forceinline__ f16_t from_f32(float f)
+    {
+        f16_t o;
+        o.bits = __builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
+        return o;
+    }
+};
+
+// Per-type pieces of the epilogues: two packed elements <-> floats, and the store clamp.  clamp(v, lo): lo = 0 (ReLU) or
+// -inf; fp16 also bounds the value by +-65504 in the same v_med3_f32 (no extra instruction).
+template <typename T> struct EP;
+template <> struct EP<bf16_t> {
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
+    static __device__ __forceinline__ void unpack2(uint32_t u, float &a, float &b) { a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u); }
+    static __device__ __forceinline__ float clamp(float v, float lo) { return fmaxf(v, lo); }
+};
+template <> struct EP<f16_t> {
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_f16x2(a, b); }
+    static __device__ __forceinline__ void unpack2(uint32_t u, float &a, float &b)
+    {
+        const f16x2_t h = __builtin_bit_cast(f16x2_t, u);
+        a = (float)h[0]; b = (float)h[1];
+    }
+    static __device__ __forceinline__ float clamp(float v, float lo) { return __builtin_amdgcn_fmed3f(v, fmaxf(lo, -65504.f), 65504.f); }
+};
+template <> struct EP<float> {
+    static __device__ __forceinline__ float clamp(float v, float lo) { return fmaxf(v, lo); }
+};
 
 // store 4 consecutive channels held as floats
 template <typename T> __device__ __forceinline__ void store4(T *p, float a, float b, float c, float d);
@@ -132,6 +192,12 @@ template <> __device__ __forceinline__ void store4<float>(float *p, float a, flo
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float a, float b, float c, float d)
 {
     u32x2 v = {pack_bf16x2(a, b), pack_bf16x2(c, d)};
+    *reinterpret_cast<u32x2 *>(p) = v;
+}
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t *p, float a, float b, float c, float d)
+{
+    u32x2 v = {pack_f16x2(__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)),
+               pack_f16x2(__builtin_amdgcn_fmed3f(c, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(d, -65504.f, 65504.f))};
     *reinterpret_cast<u32x2 *>(p) = v;
 }
 template <typename T> __device__ __forceinline__ void load4(const T *p, float *o);
@@ -147,6 +213,13 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t *p, float
     o[1] = __uint_as_float(v[0] & 0xffff0000u);
     o[2] = __uint_as_float(v[1] << 16);
     o[3] = __uint_as_float(v[1] & 0xffff0000u);
+}
+
+template <> __device__ __forceinline__ void load4<f16_t>(const f16_t *p, float *o)
+{
+    u32x2 v = *reinterpret_cast<const u32x2 *>(p);
+    EP<f16_t>::unpack2(v[0], o[0], o[1]);
+    EP<f16_t>::unpack2(v[1], o[2], o[3]);
 }
 
 // Cooperative global -> LDS staging of TOTAL 16-byte vectors by NTHREADS threads: ALL loads are
@@ -210,10 +283,7 @@ __device__ __forceinline__ void unpack16(const u32x4 &v, float *o)
         for (int i = 0; i < 4; ++i) o[i] = __uint_as_float(v[i]);
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[2 * i] = __uint_as_float(v[i] << 16);
-            o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
-        }
+        for (int i = 0; i < 4; ++i) EP<T>::unpack2(v[i], o[2 * i], o[2 * i + 1]);
     }
 }
 template <typename T>
@@ -223,6 +293,10 @@ __device__ __forceinline__ u32x4 pack16(const float *o)
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(o[i]);
+    } else if constexpr (std::is_same_v<T, f16_t>) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = pack_f16x2(__builtin_amdgcn_fmed3f(o[2 * i], -65504.f, 65504.f), __builtin_amdgcn_fmed3f(o[2 * i + 1], -65504.f, 65504.f));
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2 && C::EPI_LDS_OK) {
         __syncthreads();                          // halo and filters are no longer read
-        tile_epilogue_lds<MT, C::NT>(acc, e, b, oy0, ox0, cout0, __builtin_amdgcn_readfirstlane(wv), l, smem + wv * epi_lds_stride<MT, C::NT>());
+        tile_epilogue_lds<T, MT, C::NT>(acc, e, b, oy0, ox0, cout0, __builtin_amdgcn_readfirstlane(wv), l, smem + wv * epi_lds_stride<MT, C::NT>());
     } else {
         tile_epilogue<T, MT, C::NT, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }
@@ -187,7 +187,7 @@ static int launch_conv_cfg(const ConvArgs &a0, hipStream_t st)
     const int epi = (C::EPI_LDS_OK && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 &&
                      (!a.res || (a.res_cs % 8 == 0 && ((uintptr_t)a.res & 15) == 0)))
                         ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", KS, STRIDE, MT,
+    if (h3d_note_kernel("conv_kernel<%s, %d, %d, %d, %d, %d, %d, %d>", h3d_tname<T>(), KS, STRIDE, MT,
                         CK, TH, WAVES, epi))
         return H3D_OK;
     if constexpr (C::EPI_LDS_OK) {
@@ -205,10 +205,10 @@ static int launch_conv_cfg(const ConvArgs &a0, hipStream_t st)
     return H3D_OK;
 }
 
-template <typename T> static int launch_conv_t(const h3d_op &op, const ConvArgs &a, hipStream_t st);
-
-template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipStream_t st)
+// 2-byte element types (bf16_t, f16_t): one tiling table
+template <typename T> static int launch_conv_t(const h3d_op &op, const ConvArgs &a, hipStream_t st)
 {
+    static_assert(sizeof(T) == 2, "float has its own table below");
     const int cin = op.Cin, co = op.Cout;
     // workgroups a (TH rows x 16 px) x (bn channels) tiling produces; small-resolution layers
     // (level3..5, B*H*W <= 256k px) are re-tiled finer so every CU gets >= 4 workgroups
@@ -216,48 +216,48 @@ template <> int launch_conv_t<bf16_t>(const h3d_op &op, const ConvArgs &a, hipSt
     constexpr long WANT = 1024;
     if (op.ksize == 3 && op.stride == 1) {
         if (cin % 32 == 0) {
-            if (co <= 32) return launch_conv_cfg<bf16_t, 3, 1, 1, 32, 16>(a, st);
+            if (co <= 32) return launch_conv_cfg<T, 3, 1, 1, 32, 16>(a, st);
             if (co <= 64) {
-                if (nblk(16, 64) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 16, 8>(a, st);   // 8 waves x (32 px x 64 ch)
-                return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 8>(a, st);
+                if (nblk(16, 64) >= WANT) return launch_conv_cfg<T, 3, 1, 2, 32, 16, 8>(a, st);   // 8 waves x (32 px x 64 ch)
+                return launch_conv_cfg<T, 3, 1, 2, 32, 8>(a, st);
             }
             // 8 waves x (32 px x 128 ch), CK = 32: a chunk's MFMA time now exceeds the prefetch latency
-            if (nblk(16, 128) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 4, 32, 16, 8>(a, st);
-            if (nblk(8, 128) >= WANT) return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 8>(a, st);
-            return launch_conv_cfg<bf16_t, 3, 1, 2, 32, 8>(a, st);
+            if (nblk(16, 128) >= WANT) return launch_conv_cfg<T, 3, 1, 4, 32, 16, 8>(a, st);
+            if (nblk(8, 128) >= WANT) return launch_conv_cfg<T, 3, 1, 4, 16, 8>(a, st);
+            return launch_conv_cfg<T, 3, 1, 2, 32, 8>(a, st);
         }
-        if (co <= 32) return launch_conv_cfg<bf16_t, 3, 1, 1, 16, 16>(a, st);
-        if (co <= 64) return launch_conv_cfg<bf16_t, 3, 1, 2, 16, 16>(a, st);
-        return launch_conv_cfg<bf16_t, 3, 1, 4, 16, 16>(a, st);
+        if (co <= 32) return launch_conv_cfg<T, 3, 1, 1, 16, 16>(a, st);
+        if (co <= 64) return launch_conv_cfg<T, 3, 1, 2, 16, 16>(a, st);
+        return launch_conv_cfg<T, 3, 1, 4, 16, 16>(a, st);
     }
     if (op.ksize == 3 && op.stride == 2) {
-        if (co <= 32) return launch_conv_cfg<bf16_t, 3, 2, 1, 16, 8>(a, st);
-        if (co <= 64 || nblk(8, 128) < WANT) return launch_conv_cfg<bf16_t, 3, 2, 2, 16, 8>(a, st);
-        return launch_conv_cfg<bf16_t, 3, 2, 4, 16, 8>(a, st);
+        if (co <= 32) return launch_conv_cfg<T, 3, 2, 1, 16, 8>(a, st);
+        if (co <= 64 || nblk(8, 128) < WANT) return launch_conv_cfg<T, 3, 2, 2, 16, 8>(a, st);
+        return launch_conv_cfg<T, 3, 2, 4, 16, 8>(a, st);
     }
     if (op.ksize == 1 && op.stride == 1) {
         if (cin % 64 == 0) {
             if (co > 32 && (op.reserved & 0x1000)) {           // tuning override (tools/ab_conv1x1.py): 0x1000 | MT << 4 | TH >> 3
                 const int mt = (op.reserved >> 4) & 15, th = (op.reserved & 15) * 8;
-                if (mt == 4 && th == 16) return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 16>(a, st);
-                if (mt == 4 && th == 8) return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 8>(a, st);
-                if (mt == 2 && th == 16) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 16>(a, st);
-                if (mt == 2 && th == 8) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 8>(a, st);
+                if (mt == 4 && th == 16) return launch_conv_cfg<T, 1, 1, 4, 64, 16>(a, st);
+                if (mt == 4 && th == 8) return launch_conv_cfg<T, 1, 1, 4, 64, 8>(a, st);
+                if (mt == 2 && th == 16) return launch_conv_cfg<T, 1, 1, 2, 64, 16>(a, st);
+                if (mt == 2 && th == 8) return launch_conv_cfg<T, 1, 1, 2, 64, 8>(a, st);
             }
-            if (co <= 32) return launch_conv_cfg<bf16_t, 1, 1, 1, 64, 16>(a, st);
+            if (co <= 32) return launch_conv_cfg<T, 1, 1, 1, 64, 16>(a, st);
             // 8-row tiles throughout: these layers are HBM / latency bound and twice the workgroups hide more of it
             // (tools/ab_conv1x1.py, batch 64: 448->128 @64x64 0.085 -> 0.073 ms, 1280->512 @16x16 0.042 -> 0.036, ...)
-            if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 64, 8>(a, st);
-            return launch_conv_cfg<bf16_t, 1, 1, 4, 64, 8>(a, st);
+            if (co <= 64) return launch_conv_cfg<T, 1, 1, 2, 64, 8>(a, st);
+            return launch_conv_cfg<T, 1, 1, 4, 64, 8>(a, st);
         }
-        if (co <= 32) return launch_conv_cfg<bf16_t, 1, 1, 1, 16, 16>(a, st);
-        if (co <= 64) return launch_conv_cfg<bf16_t, 1, 1, 2, 16, 16>(a, st);
-        return launch_conv_cfg<bf16_t, 1, 1, 4, 16, 16>(a, st);
+        if (co <= 32) return launch_conv_cfg<T, 1, 1, 1, 16, 16>(a, st);
+        if (co <= 64) return launch_conv_cfg<T, 1, 1, 2, 16, 16>(a, st);
+        return launch_conv_cfg<T, 1, 1, 4, 16, 16>(a, st);
     }
     if (op.ksize == 1 && op.stride == 2) {        // the 1x1 stride-2 skip convs of the Hourglass / ResNet residual blocks
-        if (co <= 32) return launch_conv_cfg<bf16_t, 1, 2, 1, 16, 8>(a, st);
-        if (co <= 64) return launch_conv_cfg<bf16_t, 1, 2, 2, 16, 8>(a, st);
-        return launch_conv_cfg<bf16_t, 1, 2, 4, 16, 8>(a, st);
+        if (co <= 32) return launch_conv_cfg<T, 1, 2, 1, 16, 8>(a, st);
+        if (co <= 64) return launch_conv_cfg<T, 1, 2, 2, 16, 8>(a, st);
+        return launch_conv_cfg<T, 1, 2, 4, 16, 8>(a, st);
     }
     H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv: ksize=%d stride=%d not covered (k in {1,3}, stride in {1,2})",
              op.ksize, op.stride);
@@ -292,7 +292,8 @@ int h3d_launch_gemm1(const h3d_op &op, hipStream_t st);
 int h3d_launch_conv(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "conv: null pointer");
-    const int es = op.dtype == H3D_BF16 ? 2 : 4;
+    const int es = h3d_dtype_bytes(op.dtype);
+    if (!es) H3D_FAIL(H3D_ERR_DTYPE, "conv: dtype %d", op.dtype);
     if (op.Cin % 16 || op.in_cs % (16 / es) || op.Cin > op.in_cs)
         H3D_FAIL(H3D_ERR_SHAPE, "conv: Cin=%d (stride %d) must be a multiple of 16", op.Cin, op.in_cs);
     const int pad = op.ksize / 2;
@@ -313,6 +314,7 @@ int h3d_launch_conv(const h3d_op &op, hipStream_t st)
     a.relu = op.relu; a.out_mode = op.out_mode; a.tiles_x = a.tiles_y = 0;
     if (h3d_gemm1_takes(op)) return h3d_launch_gemm1(op, st);      // 1x1 stride 1, bf16: the GEMM kernel (csrc/gemm1.hip)
     if (op.dtype == H3D_BF16) return launch_conv_t<bf16_t>(op, a, st);
+    if (op.dtype == H3D_F16) return launch_conv_t<f16_t>(op, a, st);
     if (op.dtype == H3D_F32) return launch_conv_t<float>(op, a, st);
     H3D_FAIL(H3D_ERR_DTYPE, "conv: dtype %d", op.dtype);
 }
@@ -371,8 +373,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ img
 // (output channel) -> each lane owns 4 consecutive channels of one pixel: 8-byte NHWC stores,
 // 512 contiguous bytes per wave.  w: [16][7][32] bf16 (k = dx*4 + c), prepared by the host.
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const float *__restrict__ img, const bf16_t *__restrict__ w,
-                                                        const float *__restrict__ bias, bf16_t *__restrict__ out, int B,
+template <typename T>      // bf16_t | f16_t
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float *__restrict__ img, const T *__restrict__ w,
+                                                        const float *__restrict__ bias, T *__restrict__ out, int B,
                                                         int H, int W, int out_cs, int tiles_x, int tiles_y)
 {
     constexpr int TH = 16, TW = 64, IH = TH + 6, IW = TW + 6 + 2;   // +2: the K=32 run of the last pixel reads 8 px
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float *__restrict_
             const size_t o = (size_t)gy * W + gx;
             c0 = im[o]; c1 = im[plane + o]; c2 = im[2 * plane + o];
         }
-        s[iy][ix] = uint2{pack_bf16x2(c0, c1), pack_bf16x2(c2, 0.f)};
+        s[iy][ix] = uint2{EP<T>::pack2(c0, c1), EP<T>::pack2(c2, 0.f)};
     }
     __syncthreads();
     float bs[4];
@@ -413,12 +416,14 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float *__restrict_
             // K elements 8q..8q+7 of the run starting at pixel (py+dy, px0+p): pixels +2q, +2q+1
             const uint2 lo = s[py + dy][px0 + p + 2 * q], hi = s[py + dy][px0 + p + 2 * q + 1];
             const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[dy]), __builtin_bit_cast(bf16x8_t, fb),
-                                                          acc, 0, 0, 0);
+            if constexpr (std::is_same_v<T, f16_t>)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[dy]), __builtin_bit_cast(f16x8_t, fb), acc, 0, 0, 0);
+            else
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[dy]), __builtin_bit_cast(bf16x8_t, fb), acc, 0, 0, 0);
         }
         const int oy = oy0 + py, ox = ox0 + px0 + p;
         if (oy < H && ox < W)
-            store4<bf16_t>(out + ((size_t)(b * H + oy) * W + ox) * out_cs + 4 * q, fmaxf(acc[0] + bs[0], 0.f),
+            store4<T>(out + ((size_t)(b * H + oy) * W + ox) * out_cs + 4 * q, fmaxf(acc[0] + bs[0], 0.f),
                            fmaxf(acc[1] + bs[1], 0.f), fmaxf(acc[2] + bs[2], 0.f), fmaxf(acc[3] + bs[3], 0.f));
     }
 }
@@ -433,12 +438,16 @@ int h3d_launch_stem(const h3d_op &op, hipStream_t st)
         H3D_FAIL(H3D_ERR_SHAPE, "stem: expects 7x7 3->16 stride 1 (got k=%d %d->%d)", op.ksize, op.Cin, op.Cout);
     const int tx = cdiv(op.W, 16), ty = cdiv(op.H, 16);
     dim3 grid(op.B * tx * ty);
-    if (op.dtype == H3D_BF16) {
-        // op.w: bf16 [16][7][32] (k = dx*4 + c, zero padded) -- see engine.PackedWeights.stem
+    if (op.dtype == H3D_BF16 || op.dtype == H3D_F16) {
+        // op.w: bf16 / fp16 [16][7][32] (k = dx*4 + c, zero padded) -- see engine.PackedWeights.stem
         const int mx = cdiv(op.W, 64), my = cdiv(op.H, 16);
-        if (h3d_note_kernel("stem_mfma_kernel")) return H3D_OK;
-        hipLaunchKernelGGL(stem_mfma_kernel, dim3(op.B * mx * my), dim3(256), 0, st, (const float *)op.in, (const bf16_t *)op.w,
-                           op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.out_cs, mx, my);
+        if (h3d_note_kernel("stem_mfma_kernel<%s>", op.dtype == H3D_F16 ? "f16_t" : "unsigned short")) return H3D_OK;
+        if (op.dtype == H3D_F16)
+            hipLaunchKernelGGL(stem_mfma_kernel<f16_t>, dim3(op.B * mx * my), dim3(256), 0, st, (const float *)op.in, (const f16_t *)op.w,
+                               op.bias, (f16_t *)op.out, op.B, op.H, op.W, op.out_cs, mx, my);
+        else
+            hipLaunchKernelGGL(stem_mfma_kernel<bf16_t>, dim3(op.B * mx * my), dim3(256), 0, st, (const float *)op.in, (const bf16_t *)op.w,
+                               op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.out_cs, mx, my);
         H3D_CHECK_LAUNCH("stem_mfma_kernel");
         return H3D_OK;
     }
@@ -596,8 +605,9 @@ static inline int ew_grid(size_t total) { size_t g = (total + 255) / 256; return
 int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.out) H3D_FAIL(H3D_ERR_ARG, "elementwise: null pointer");
-    const int es = op.dtype == H3D_BF16 ? 2 : (op.dtype == H3D_F32 ? 4 : 0);
+    const int es = h3d_dtype_bytes(op.dtype);
     if (!es) H3D_FAIL(H3D_ERR_DTYPE, "elementwise: dtype %d", op.dtype);
+    const bool f16 = op.dtype == H3D_F16;
     const int n = 16 / es;
     if (op.Cin % n || op.in_cs % n || op.out_cs % n || op.Cin != op.Cout)
         H3D_FAIL(H3D_ERR_SHAPE, "elementwise: channels %d/%d strides %d/%d must be multiples of %d", op.Cin, op.Cout,
@@ -605,7 +615,7 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
     const size_t total = (size_t)op.B * op.Ho * op.Wo * (op.Cin / n);
     dim3 grid(ew_grid(total)), blk(256);
     const bool f16out = op.kind == H3D_OP_UPADD && op.out_mode == H3D_OUT_NHWC_F16;
-    if (f16out && es != 2) H3D_FAIL(H3D_ERR_DTYPE, "upadd: fp16 output needs a bf16 plan");
+    if (f16out && op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "upadd: fp16 output is an option of bf16 plans (fp16 plans write fp16 anyway)");
     // tap table in LDS only while staging it is cheap next to the workgroup's 8 rows x (256 / vectors per pixel) pixels.
     // With the skewed rows (no bank conflicts, see upadd_kernel), same box, batch 64: 4 KiB (64 ch, f = 2) 0.070 -> 0.063 ms;
     // 8 KiB (128 ch) 0.057 -> 0.043; 16 KiB with 64 channels (f = 4) 0.102 -> 0.075; 16 KiB with 256 channels (8-pixel
@@ -613,12 +623,15 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
     const size_t up_wbytes = (size_t)op.ksize * op.ksize * op.Cin * sizeof(float);
     const bool up_wlds = op.reserved == 1 ? false : op.reserved == 2 ? up_wbytes <= 64 * 1024 : (up_wbytes <= 8192 || (up_wbytes <= 16384 && op.Cin <= 64));
     if (h3d_note_kernel("%s<%s%s%s>", op.kind == H3D_OP_MAXPOOL ? "maxpool_kernel" : op.kind == H3D_OP_UPADD ? "upadd_kernel" : "copy_kernel",
-                        es == 2 ? "unsigned short" : "float", op.kind == H3D_OP_UPADD ? (f16out ? ", true" : ", false") : "",
+                        f16 ? "f16_t" : es == 2 ? "unsigned short" : "float", op.kind == H3D_OP_UPADD ? (f16out ? ", true" : ", false") : "",
                         op.kind == H3D_OP_UPADD ? (up_wlds ? ", true" : ", false") : ""))
         return H3D_OK;
     if (op.kind == H3D_OP_MAXPOOL) {
         if (op.Ho != op.H / 2 || op.Wo != op.W / 2) H3D_FAIL(H3D_ERR_SHAPE, "maxpool: output must be floor(H/2) x floor(W/2)");
-        if (es == 2)
+        if (f16)
+            hipLaunchKernelGGL(maxpool_kernel<f16_t>, grid, blk, 0, st, (const f16_t *)op.in, (f16_t *)op.out, op.B, op.H,
+                               op.W, op.Cin, op.in_cs, op.Ho, op.Wo, op.out_cs);
+        else if (es == 2)
             hipLaunchKernelGGL(maxpool_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t *)op.in, (bf16_t *)op.out, op.B, op.H,
                                op.W, op.Cin, op.in_cs, op.Ho, op.Wo, op.out_cs);
         else
@@ -644,10 +657,12 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
     } while (0)
         if (wlds) {
             if (f16out) H3D_UPADD_LAUNCH((upadd_kernel<bf16_t, true, true>), bf16_t);
+            else if (f16) H3D_UPADD_LAUNCH((upadd_kernel<f16_t, false, true>), f16_t);
             else if (es == 2) H3D_UPADD_LAUNCH((upadd_kernel<bf16_t, false, true>), bf16_t);
             else H3D_UPADD_LAUNCH((upadd_kernel<float, false, true>), float);
         } else {
             if (f16out) H3D_UPADD_LAUNCH((upadd_kernel<bf16_t, true, false>), bf16_t);
+            else if (f16) H3D_UPADD_LAUNCH((upadd_kernel<f16_t, false, false>), f16_t);
             else if (es == 2) H3D_UPADD_LAUNCH((upadd_kernel<bf16_t, false, false>), bf16_t);
             else H3D_UPADD_LAUNCH((upadd_kernel<float, false, false>), float);
         }
@@ -712,6 +727,9 @@ extern "C" int h3d_nchw_f32_to_nhwc(const float *src, void *dst, int dtype, int 
     if (dtype == H3D_BF16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t *)dst, B, C,
                            H * W, dst_cs);
+    else if (dtype == H3D_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (f16_t *)dst, B, C,
+                           H * W, dst_cs);
     else if (dtype == H3D_F32)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float *)dst, B, C,
                            H * W, dst_cs);
@@ -729,6 +747,9 @@ extern "C" int h3d_nhwc_to_nchw_f32(const void *src, int dtype, float *dst, int 
     dim3 grid(cdiv(H * W, 32), cdiv(C, 32), B);
     if (dtype == H3D_BF16)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t *)src, dst,
+                           B, C, H * W, src_cs);
+    else if (dtype == H3D_F16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const f16_t *)src, dst,
                            B, C, H * W, src_cs);
     else if (dtype == H3D_F32)
         hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, dst, B,

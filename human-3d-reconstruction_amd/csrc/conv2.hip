@@ -29,6 +29,7 @@ struct Conv2Args {
     int G, tiles_x, tiles_y;
     int dbg;   // ABLATE builds only (op.reserved >> 16): 1 = no DMA after stage 0, 2 = no fragment reads / MFMA
     int xcd;   // h3d_tile_id mode
+    int f16;   // host side only: fp16 plan (the launcher picks the f16_t instantiation)
     unsigned long long *stamps;   // profiling builds: per workgroup and wave (0-7) the cycles spent at the stage barrier; slot 7: wave 0's {DMA issue} (tools/stamp_conv2.py)
 };
 
@@ -79,11 +80,12 @@ __device__ __forceinline__ void conv2_issue(const char *in_b, int in_bytes, cons
     }
 }
 
-template <int MT, int WAVES, int EPI, int S = 1, int SLOTS = 2, int NT = 1, bool PIPE = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
+template <typename T, int MT, int WAVES, int EPI, int S = 1, int SLOTS = 2, int NT = 1, bool PIPE = false>   // T: bf16_t | f16_t; EPI: 0 general, 1 lean NHWC, 2 LDS-transposed NHWC (epilogue.h); S: stride
 __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
 {
     using C = Conv2Cfg<MT, WAVES, S, SLOTS, NT>;
-    using E = ET<bf16_t>;
+    using E = ET<T>;
+    static_assert(sizeof(T) == 2, "2-byte element types");
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
 
     const int tid = threadIdx.x;
@@ -229,10 +231,33 @@ __global__ __launch_bounds__(64 * WAVES) void conv2_kernel(Conv2Args a)
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2) {
         __syncthreads();                          // nobody reads the ring any more
-        tile_epilogue_lds<MT, NT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT, NT>());
+        tile_epilogue_lds<T, MT, NT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT, NT>());
     } else {
-        tile_epilogue<bf16_t, MT, NT, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+        tile_epilogue<T, MT, NT, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }
+}
+
+template <typename T, int MT, int WAVES, int S, int SLOTS, int NT, bool PIPE>
+static int launch_conv2_t(const Conv2Args &a, dim3 grid, int epi, hipStream_t st)
+{
+    using C = Conv2Cfg<MT, WAVES, S, SLOTS, NT>;
+    if constexpr (PIPE) {
+        if (epi == 2) {
+            if (h3d_note_kernel("conv2_kernel<%s, %d, %d, %d, %d, %d, %d, true>", h3d_tname<T>(), MT, WAVES, epi, S, SLOTS, NT)) return H3D_OK;
+            hipLaunchKernelGGL((conv2_kernel<T, MT, WAVES, 2, S, SLOTS, NT, true>), grid, dim3(C::THREADS), 0, st, a);
+            H3D_CHECK_LAUNCH("conv2_kernel");
+            return H3D_OK;
+        }
+    }
+    if (h3d_note_kernel("conv2_kernel<%s, %d, %d, %d, %d, %d, %d>", h3d_tname<T>(), MT, WAVES, epi, S, SLOTS, NT)) return H3D_OK;
+    if (epi == 2)
+        hipLaunchKernelGGL((conv2_kernel<T, MT, WAVES, 2, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
+    else if (epi == 1)
+        hipLaunchKernelGGL((conv2_kernel<T, MT, WAVES, 1, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv2_kernel<T, MT, WAVES, 0, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
+    H3D_CHECK_LAUNCH("conv2_kernel");
+    return H3D_OK;
 }
 
 template <int MT, int WAVES, int S = 1, int SLOTS = 2, int NT = 1, bool PIPE = false>
@@ -252,29 +277,14 @@ static int launch_conv2_cfg(const Conv2Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(cdiv(a.Cout, 32), MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0 && !(a.dbg & 4)) ? 2 : lean ? 1 : 0;
-    if constexpr (PIPE) {
-        if (epi == 2) {
-            if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d, %d, %d, true>", MT, WAVES, epi, S, SLOTS, NT)) return H3D_OK;
-            hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S, SLOTS, NT, true>), grid, dim3(C::THREADS), 0, st, a);
-            H3D_CHECK_LAUNCH("conv2_kernel");
-            return H3D_OK;
-        }
-    }
-    if (h3d_note_kernel("conv2_kernel<%d, %d, %d, %d, %d, %d>", MT, WAVES, epi, S, SLOTS, NT)) return H3D_OK;
-    if (epi == 2)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 2, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
-    else if (epi == 1)
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 1, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv2_kernel<MT, WAVES, 0, S, SLOTS, NT>), grid, dim3(C::THREADS), 0, st, a);
-    H3D_CHECK_LAUNCH("conv2_kernel");
-    return H3D_OK;
+    if (a.f16) return launch_conv2_t<f16_t, MT, WAVES, S, SLOTS, NT, PIPE>(a, grid, epi, st);
+    return launch_conv2_t<bf16_t, MT, WAVES, S, SLOTS, NT, PIPE>(a, grid, epi, st);
 }
 
 int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "conv_stream: null pointer");
-    if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "conv_stream: bf16 only (dtype %d)", op.dtype);
+    if (op.dtype != H3D_BF16 && op.dtype != H3D_F16) H3D_FAIL(H3D_ERR_DTYPE, "conv_stream: bf16 / fp16 plans only (dtype %d)", op.dtype);
     if (op.ksize != 3 || (op.stride != 1 && op.stride != 2) || op.Ho != (op.H - 1) / op.stride + 1 || op.Wo != (op.W - 1) / op.stride + 1)
         H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv_stream: covers 3x3 p1 with stride 1 or 2 (k=%d s=%d, %dx%d -> %dx%d)", op.ksize, op.stride,
                  op.H, op.W, op.Ho, op.Wo);
@@ -291,6 +301,7 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
     a.out = (char *)op.out; a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
     a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.out_cs = op.out_cs; a.res_cs = op.in2_cs; a.relu = op.relu; a.out_mode = op.out_mode;
     a.G = op.wrows / 32; a.tiles_x = a.tiles_y = 0;
+    a.f16 = op.dtype == H3D_F16;
     a.dbg = op.reserved >> 16;
     // workgroups a (th rows x 16 px) x (32*mt channels) tiling produces
     const int gq = cdiv(op.Cout, 32);

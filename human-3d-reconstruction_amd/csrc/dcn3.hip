@@ -717,7 +717,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2) {
         __syncthreads();                          // the apron and the filters are no longer read
-        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
+        tile_epilogue_lds<T, MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
     } else {
         tile_epilogue<T, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }
@@ -751,7 +751,7 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (sizeof(T) == 2 && MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN, epi,
+    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", h3d_tname<T>(), MT, CK, MARGIN, epi,
                         WDMA ? "true" : "false", NP))
         return H3D_OK;
     if constexpr (sizeof(T) == 2 && MT >= 2) {
@@ -772,12 +772,52 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
 // channels per filter stage of H3D_OP_DCN_FUSED_STREAM: hosts pack the stage-major filter images with this CK
 extern "C" int h3d_dcn_fused_ck(int Cin, int Cout) { (void)Cin; (void)Cout; return 16; }
 
+// 2-byte plans (bf16_t: the apron is converted to fp16 while it is staged; f16_t: it is fp16 already)
+template <typename T>
+static int launch_dcn3_lowp(const h3d_op &op, const Dcn3Args &a, bool wdma, hipStream_t st)
+{
+    if (wdma) {
+        if ((op.reserved & 0x1000) || op.Cin % 32) {     // tuning override: round 1's configurations (no patches: every sample that
+                                                         // leaves the apron goes through pass 2); also Cin = 16 (mod 32): the
+                                                         // patch variants' pipeline is unrolled by two stages
+            if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 1, true>(a, st);
+            if (op.Cout <= 64) return launch_dcn3_cfg<T, 2, 16, 1, true>(a, st);
+            return launch_dcn3_cfg<T, 4, 16, 2, true>(a, st);
+        }
+        // <= 64 output channels: margin-2 apron, 16-channel stages, <= 128 VGPRs and 78 KB of LDS -> two workgroups
+        // (16 waves) per CU, one computing while the other waits at its stage barriers; 256 patch slots per tile.
+        // > 64: one workgroup per CU has the LDS for a margin-4 apron (26 x 26 pixels)
+        if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 2, true, 256>(a, st);
+        if (op.Cout <= 64) return launch_dcn3_cfg<T, 2, 16, 2, true, 256>(a, st);
+        // a layer whose 128-channel workgroups would leave CUs idle (16 x 16 maps at batch 64: 128 workgroups on 256 CUs)
+        // runs 64-channel workgroups instead: twice the gather / blend work, on CUs that had nothing to do
+        const long wgs4 = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
+        if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) return launch_dcn3_cfg<T, 2, 16, 2, true, 256>(a, st);
+        return launch_dcn3_cfg<T, 4, 16, 4, true, 256>(a, st);
+    }
+    if (op.Cin % 32 == 0 && op.Cout <= 64) {
+        if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 32, 2>(a, st);
+        return launch_dcn3_cfg<T, 2, 32, 2>(a, st);
+    }
+    if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 2>(a, st);
+    if (op.Cout <= 64) return launch_dcn3_cfg<T, 2, 16, 2>(a, st);
+    // a layer whose 128-channel workgroups would leave CUs idle (16x16 maps at batch 64: 128 workgroups) runs
+    // 64-channel workgroups instead: twice the gather / blend work, but on CUs that had nothing to do
+    const long wgs4 = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
+    if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) {
+        if (op.Cin % 32 == 0) return launch_dcn3_cfg<T, 2, 32, 2>(a, st);
+        return launch_dcn3_cfg<T, 2, 16, 2>(a, st);
+    }
+    return launch_dcn3_cfg<T, 4, 16, 2>(a, st);
+}
+
 int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
 {
     const bool wdma = op.kind == H3D_OP_DCN_FUSED_STREAM;
-    if (wdma && op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused_stream: bf16 plans only");
+    if (wdma && op.dtype != H3D_BF16 && op.dtype != H3D_F16) H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused_stream: bf16 / fp16 plans only");
     if (!op.in || !op.w || !op.bias || !op.out || !op.in2) H3D_FAIL(H3D_ERR_ARG, "dcn_fused: null pointer");
-    const int es = op.dtype == H3D_BF16 ? 2 : 4;
+    const int es = h3d_dtype_bytes(op.dtype);
+    if (!es) H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused: dtype %d", op.dtype);
     if (op.ksize != 3 || op.stride != 1 || op.Ho != op.H || op.Wo != op.W)
         H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused: covers 3x3 s1 p1 d1 dg1 only (k=%d s=%d)", op.ksize, op.stride);
     if (op.Cin % 16 || op.in_cs % (16 / es) || op.Cin > op.in_cs)
@@ -794,42 +834,9 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.tiles_x = a.tiles_y = 0;
     a.dbg = op.reserved;
     a.G = op.wrows / 32;
-    if (wdma) {
-        if ((size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
-        if ((op.reserved & 0x1000) || op.Cin % 32) {     // tuning override: round 1's configurations (no patches: every sample that
-                                                         // leaves the apron goes through pass 2); also Cin = 16 (mod 32): the
-                                                         // patch variants' pipeline is unrolled by two stages
-            if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 1, true>(a, st);
-            if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 1, true>(a, st);
-            return launch_dcn3_cfg<bf16_t, 4, 16, 2, true>(a, st);
-        }
-        // <= 64 output channels: margin-2 apron, 16-channel stages, <= 128 VGPRs and 78 KB of LDS -> two workgroups
-        // (16 waves) per CU, one computing while the other waits at its stage barriers; 256 patch slots per tile.
-        // > 64: one workgroup per CU has the LDS for a margin-4 apron (26 x 26 pixels)
-        if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 2, true, 256>(a, st);
-        if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 2, true, 256>(a, st);
-        // a layer whose 128-channel workgroups would leave CUs idle (16 x 16 maps at batch 64: 128 workgroups on 256 CUs)
-        // runs 64-channel workgroups instead: twice the gather / blend work, on CUs that had nothing to do
-        const long wgs4 = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
-        if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) return launch_dcn3_cfg<bf16_t, 2, 16, 2, true, 256>(a, st);
-        return launch_dcn3_cfg<bf16_t, 4, 16, 4, true, 256>(a, st);
-    }
-    if (op.dtype == H3D_BF16) {
-        if (op.Cin % 32 == 0 && op.Cout <= 64) {
-            if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 32, 2>(a, st);
-            return launch_dcn3_cfg<bf16_t, 2, 32, 2>(a, st);
-        }
-        if (op.Cout <= 32) return launch_dcn3_cfg<bf16_t, 1, 16, 2>(a, st);
-        if (op.Cout <= 64) return launch_dcn3_cfg<bf16_t, 2, 16, 2>(a, st);
-        // a layer whose 128-channel workgroups would leave CUs idle (16x16 maps at batch 64: 128 workgroups) runs
-        // 64-channel workgroups instead: twice the gather / blend work, but on CUs that had nothing to do
-        const long wgs4 = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
-        if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) {
-            if (op.Cin % 32 == 0) return launch_dcn3_cfg<bf16_t, 2, 32, 2>(a, st);
-            return launch_dcn3_cfg<bf16_t, 2, 16, 2>(a, st);
-        }
-        return launch_dcn3_cfg<bf16_t, 4, 16, 2>(a, st);
-    }
+    if (wdma && (size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
+    if (op.dtype == H3D_BF16) return launch_dcn3_lowp<bf16_t>(op, a, wdma, st);
+    if (op.dtype == H3D_F16) return launch_dcn3_lowp<f16_t>(op, a, wdma, st);
     if (op.dtype == H3D_F32) {
         if (op.Cout <= 32) return launch_dcn3_cfg<float, 1, 16, 2>(a, st);
         return launch_dcn3_cfg<float, 2, 16, 2>(a, st);

@@ -531,7 +531,7 @@ __global__ __launch_bounds__(512, DENSE ? 4 : 2) void dcn4_kernel(Dcn4Args a)
     e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
     if constexpr (EPI == 2) {
         __syncthreads();
-        tile_epilogue_lds<MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
+        tile_epilogue_lds<bf16_t, MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
     } else {
         tile_epilogue<bf16_t, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }

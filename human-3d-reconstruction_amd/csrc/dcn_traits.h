@@ -143,5 +143,11 @@ template <> struct SE<bf16_t> {
     }
 };
 
+// fp16 plans: the input already IS the sample type -- no conversion while staging, the blend and the MFMA operands as in
+// bf16 plans
+template <> struct SE<f16_t> : SE<bf16_t> {
+    static __device__ __forceinline__ u32x4 convert16(u32x4 raw) { return raw; }
+    static __device__ __forceinline__ frag global8(const char *p) { return lds(p); }
+};
 
 __device__ __forceinline__ float dcn2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }   // v_exp + v_rcp (1 ulp each)

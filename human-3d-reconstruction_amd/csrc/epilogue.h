@@ -50,7 +50,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[MT][NT], const EpiAr
                         load4<T>(rp + co, rv);
                         v0 += rv[0]; v1 += rv[1]; v2 += rv[2]; v3 += rv[3];
                     }
-                    store4<T>(op + co, fmaxf(v0, lo), fmaxf(v1, lo), fmaxf(v2, lo), fmaxf(v3, lo));
+                    store4<T>(op + co, fmaxf(v0, lo), fmaxf(v1, lo), fmaxf(v2, lo), fmaxf(v3, lo));   // (store4<f16_t> clamps to the fp16 range)
                 }
             }
         }
@@ -105,7 +105,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[MT][NT], const EpiAr
     }
 }
 
-// LDS-transposed epilogue (bf16 NHWC outputs, Cout % 8 == 0, out_cs % 8 == 0, 16-byte aligned bases).
+// LDS-transposed epilogue (bf16 / fp16 NHWC outputs, Cout % 8 == 0, out_cs % 8 == 0, 16-byte aligned bases).
 // The MFMA C layout gives each lane 4 consecutive channels of one pixel, so a direct store writes 8-byte
 // pieces 2*out_cs bytes apart: 16 partial writes per 128-byte line.  Here every wave first drops its
 // 32 pixels x 32*MT channels (bias, residual, ReLU applied in fp32, then rounded) into its own LDS region
@@ -115,7 +115,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 (&acc)[MT][NT], const EpiAr
 // no longer be read by anyone else).  Residual images must be smaller than 2 GiB (buffer offsets).
 template <int MT, int NT = 1> constexpr int epi_lds_stride() { return (NT * 32 * (64 * MT + 16) + 1023) / 1024 * 1024; }
 
-template <int MT, int NT, bool HASRES>
+template <typename T, int MT, int NT, bool HASRES>
 __device__ __forceinline__ void tile_epilogue_lds_impl(f32x16 (&acc)[MT][NT], const EpiArgs &a, int b, int oy0, int ox0,
                                                        int cout0, int wv, int l, char *lw)
 {
@@ -161,10 +161,12 @@ __device__ __forceinline__ void tile_epilogue_lds_impl(f32x16 (&acc)[MT][NT], co
                     char *slot = lw + (n * 32 + r) * ROWB + (co + 4 * h) * 2;      // this lane's 4 channels of its pixel
                     if constexpr (HASRES) {
                         const u32x2 rr = *reinterpret_cast<const u32x2 *>(slot);
-                        v0 += __uint_as_float(rr[0] << 16); v1 += __uint_as_float(rr[0] & 0xffff0000u);
-                        v2 += __uint_as_float(rr[1] << 16); v3 += __uint_as_float(rr[1] & 0xffff0000u);
+                        float r0, r1, r2, r3;
+                        EP<T>::unpack2(rr[0], r0, r1);
+                        EP<T>::unpack2(rr[1], r2, r3);
+                        v0 += r0; v1 += r1; v2 += r2; v3 += r3;
                     }
-                    const u32x2 pk = {pack_bf16x2(fmaxf(v0, lo), fmaxf(v1, lo)), pack_bf16x2(fmaxf(v2, lo), fmaxf(v3, lo))};
+                    const u32x2 pk = {EP<T>::pack2(EP<T>::clamp(v0, lo), EP<T>::clamp(v1, lo)), EP<T>::pack2(EP<T>::clamp(v2, lo), EP<T>::clamp(v3, lo))};
                     *reinterpret_cast<u32x2 *>(slot) = pk;
                 }
         }
@@ -184,10 +186,11 @@ __device__ __forceinline__ void tile_epilogue_lds_impl(f32x16 (&acc)[MT][NT], co
     }
 }
 
-template <int MT, int NT = 1>
+template <typename T, int MT, int NT = 1>       // T: bf16_t | f16_t (the rounding of the stored result and the residual's format)
 __device__ __forceinline__ void tile_epilogue_lds(f32x16 (&acc)[MT][NT], const EpiArgs &a, int b, int oy0, int ox0,
                                                   int cout0, int wv, int l, char *lw)
 {
-    if (a.res) tile_epilogue_lds_impl<MT, NT, true>(acc, a, b, oy0, ox0, cout0, wv, l, lw);     // wave-uniform
-    else tile_epilogue_lds_impl<MT, NT, false>(acc, a, b, oy0, ox0, cout0, wv, l, lw);
+    static_assert(sizeof(T) == 2, "2-byte NHWC outputs");
+    if (a.res) tile_epilogue_lds_impl<T, MT, NT, true>(acc, a, b, oy0, ox0, cout0, wv, l, lw);     // wave-uniform
+    else tile_epilogue_lds_impl<T, MT, NT, false>(acc, a, b, oy0, ox0, cout0, wv, l, lw);
 }

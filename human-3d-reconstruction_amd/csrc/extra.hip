@@ -104,8 +104,9 @@ static inline int ex_grid(size_t total) { size_t g = (total + 255) / 256; return
 // + 2q + 1).  Wave w owns 16 output channels (blockIdx.y * 64 + 16 w), keeps their 7 filter-row fragments in registers and
 // walks the tile's 16 groups of 16 pixels.  w: bf16 [Cout][7][32] (k = dx*4 + c, engine.PackedWeights.stem_s2), bias fp32.
 typedef __attribute__((ext_vector_type(4))) float f32x4_st;
-__global__ __launch_bounds__(256) void stem_s2_kernel(const float *__restrict__ img, const bf16_t *__restrict__ w,
-                                                      const float *__restrict__ bias, bf16_t *__restrict__ out, int B, int H,
+template <typename T>      // bf16_t | f16_t
+__global__ __launch_bounds__(256) void stem_s2_kernel(const float *__restrict__ img, const T *__restrict__ w,
+                                                      const float *__restrict__ bias, T *__restrict__ out, int B, int H,
                                                       int W, int Ho, int Wo, int Cout, int out_cs, int tiles_x, int tiles_y)
 {
     constexpr int TH = 8, TW = 32, IH = (TH - 1) * 2 + 7, IW = 72;      // 21 rows x (62 + 7 + 2 -> 72) pixels
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void stem_s2_kernel(const float *__restrict__ 
             const size_t o = (size_t)gy * W + gx;
             v0 = im[o]; v1 = im[plane + o]; v2 = im[2 * plane + o];
         }
-        s[iy][ix] = uint2{pack_bf16x2(v0, v1), pack_bf16x2(v2, 0.f)};
+        s[iy][ix] = uint2{EP<T>::pack2(v0, v1), EP<T>::pack2(v2, 0.f)};
     }
     __syncthreads();
     if (c0 >= Cout) return;
@@ -151,14 +152,16 @@ __global__ __launch_bounds__(256) void stem_s2_kernel(const float *__restrict__ 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const u32x4 fb = *reinterpret_cast<const u32x4 *>(&s[2 * py + dy][2 * (16 * u + p) + 2 * q]);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[dy]), __builtin_bit_cast(bf16x8_t, fb),
-                                                                 acc[u], 0, 0, 0);
+                if constexpr (std::is_same_v<T, f16_t>)
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa[dy]), __builtin_bit_cast(f16x8_t, fb), acc[u], 0, 0, 0);
+                else
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa[dy]), __builtin_bit_cast(bf16x8_t, fb), acc[u], 0, 0, 0);
             }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int oy = oy0 + py, ox = ox0 + 16 * u + p;
             if (oy < Ho && ox < Wo)
-                store4<bf16_t>(out + ((size_t)(b * Ho + oy) * Wo + ox) * out_cs + c0 + 4 * q, fmaxf(acc[u][0] + bs[0], 0.f),
+                store4<T>(out + ((size_t)(b * Ho + oy) * Wo + ox) * out_cs + c0 + 4 * q, fmaxf(acc[u][0] + bs[0], 0.f),
                                fmaxf(acc[u][1] + bs[1], 0.f), fmaxf(acc[u][2] + bs[2], 0.f), fmaxf(acc[u][3] + bs[3], 0.f));
         }
     }
@@ -166,16 +169,20 @@ __global__ __launch_bounds__(256) void stem_s2_kernel(const float *__restrict__ 
 
 int h3d_launch_stem_s2(const h3d_op &op, hipStream_t st)
 {
-    if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "stem (stride 2): bf16 plans only (dtype %d)", op.dtype);
+    if (op.dtype != H3D_BF16 && op.dtype != H3D_F16) H3D_FAIL(H3D_ERR_DTYPE, "stem (stride 2): bf16 / fp16 plans only (dtype %d)", op.dtype);
     if (op.Cin != 3 || op.ksize != 7 || op.stride != 2 || op.Cout % 16 || op.out_cs % 4 || op.out_cs < op.Cout ||
         op.Ho != (op.H - 1) / 2 + 1 || op.Wo != (op.W - 1) / 2 + 1)
         H3D_FAIL(H3D_ERR_SHAPE, "stem (stride 2): expects 7x7 3->16n, output floor((H-1)/2)+1 (got k=%d %d->%d, %dx%d -> %dx%d)", op.ksize,
                  op.Cin, op.Cout, op.H, op.W, op.Ho, op.Wo);
     if (((uintptr_t)op.w & 15) || ((uintptr_t)op.out & 7)) H3D_FAIL(H3D_ERR_ARG, "stem (stride 2): weights must be 16-byte aligned");
     const int tx = cdiv(op.Wo, 32), ty = cdiv(op.Ho, 8);
-    if (h3d_note_kernel("stem_s2_kernel")) return H3D_OK;
-    hipLaunchKernelGGL(stem_s2_kernel, dim3(op.B * tx * ty, cdiv(op.Cout, 64)), dim3(256), 0, st, (const float *)op.in, (const bf16_t *)op.w,
-                       op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.Ho, op.Wo, op.Cout, op.out_cs, tx, ty);
+    if (h3d_note_kernel("stem_s2_kernel<%s>", op.dtype == H3D_F16 ? "f16_t" : "unsigned short")) return H3D_OK;
+    if (op.dtype == H3D_F16)
+        hipLaunchKernelGGL(stem_s2_kernel<f16_t>, dim3(op.B * tx * ty, cdiv(op.Cout, 64)), dim3(256), 0, st, (const float *)op.in, (const f16_t *)op.w,
+                           op.bias, (f16_t *)op.out, op.B, op.H, op.W, op.Ho, op.Wo, op.Cout, op.out_cs, tx, ty);
+    else
+        hipLaunchKernelGGL(stem_s2_kernel<bf16_t>, dim3(op.B * tx * ty, cdiv(op.Cout, 64)), dim3(256), 0, st, (const float *)op.in, (const bf16_t *)op.w,
+                           op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.Ho, op.Wo, op.Cout, op.out_cs, tx, ty);
     H3D_CHECK_LAUNCH("stem_s2_kernel");
     return H3D_OK;
 }
@@ -183,8 +190,9 @@ int h3d_launch_stem_s2(const h3d_op &op, hipStream_t st)
 int h3d_launch_extra(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.out) H3D_FAIL(H3D_ERR_ARG, "extra op: null pointer");
-    const int es = op.dtype == H3D_BF16 ? 2 : (op.dtype == H3D_F32 ? 4 : 0);
+    const int es = h3d_dtype_bytes(op.dtype);
     if (!es) H3D_FAIL(H3D_ERR_DTYPE, "extra op: dtype %d", op.dtype);
+    const bool f16 = op.dtype == H3D_F16;
     const int n = 16 / es;
     const dim3 blk(256);
     if (op.kind == H3D_OP_IM2COL) {
@@ -193,9 +201,12 @@ int h3d_launch_extra(const h3d_op &op, hipStream_t st)
             H3D_FAIL(H3D_ERR_SHAPE, "im2col: K = %d, padded K (Cout) = %d, stride %d", K, op.Cout, op.out_cs);
         if (op.Ho != (op.H + 2 * pad - op.ksize) / op.stride + 1 || op.Wo != (op.W + 2 * pad - op.ksize) / op.stride + 1)
             H3D_FAIL(H3D_ERR_SHAPE, "im2col: output %dx%d does not match (H+2p-k)/s+1", op.Ho, op.Wo);
-        if (h3d_note_kernel("im2col_kernel<%s>", es == 2 ? "unsigned short" : "float")) return H3D_OK;
+        if (h3d_note_kernel("im2col_kernel<%s>", f16 ? "f16_t" : es == 2 ? "unsigned short" : "float")) return H3D_OK;
         const size_t total = (size_t)op.B * op.Ho * op.Wo * (op.Cout / n);
-        if (es == 2)
+        if (f16)
+            hipLaunchKernelGGL(im2col_kernel<f16_t>, dim3(ex_grid(total)), blk, 0, st, (const float *)op.in, (f16_t *)op.out, op.B, op.Cin,
+                               op.H, op.W, op.Ho, op.Wo, op.ksize, op.stride, pad, K, op.Cout, op.out_cs);
+        else if (es == 2)
             hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(ex_grid(total)), blk, 0, st, (const float *)op.in, (bf16_t *)op.out, op.B, op.Cin,
                                op.H, op.W, op.Ho, op.Wo, op.ksize, op.stride, pad, K, op.Cout, op.out_cs);
         else
@@ -208,9 +219,12 @@ int h3d_launch_extra(const h3d_op &op, hipStream_t st)
     if (op.kind == H3D_OP_MAXPOOL3) {
         if (op.Cin != op.Cout || op.Ho != (op.H - 1) / 2 + 1 || op.Wo != (op.W - 1) / 2 + 1)
             H3D_FAIL(H3D_ERR_SHAPE, "maxpool3: output must be floor((H-1)/2)+1 (k3 s2 p1)");
-        if (h3d_note_kernel("maxpool3_kernel<%s>", es == 2 ? "unsigned short" : "float")) return H3D_OK;
+        if (h3d_note_kernel("maxpool3_kernel<%s>", f16 ? "f16_t" : es == 2 ? "unsigned short" : "float")) return H3D_OK;
         const size_t total = (size_t)op.B * op.Ho * op.Wo * (op.Cin / n);
-        if (es == 2)
+        if (f16)
+            hipLaunchKernelGGL(maxpool3_kernel<f16_t>, dim3(ex_grid(total)), blk, 0, st, (const f16_t *)op.in, (f16_t *)op.out, op.B, op.H, op.W,
+                               op.Cin, op.in_cs, op.Ho, op.Wo, op.out_cs);
+        else if (es == 2)
             hipLaunchKernelGGL(maxpool3_kernel<bf16_t>, dim3(ex_grid(total)), blk, 0, st, (const bf16_t *)op.in, (bf16_t *)op.out, op.B, op.H, op.W,
                                op.Cin, op.in_cs, op.Ho, op.Wo, op.out_cs);
         else

@@ -32,6 +32,7 @@ struct Gemm1Args {
     int Cin, in_cs, Cout, out_cs, res_cs, relu, wrows;
     int tiles_n, blocks_m;
     int xcd;
+    int f16;             // host side only: fp16 plan
 };
 
 template <int MT, int NT, int WM, int WN, int SLOTS>
@@ -58,7 +59,7 @@ typedef __attribute__((address_space(3))) void lds_void_g1;
 // rebuilt from wave-uniform scalars at every call (4 SGPRs each, no memory traffic).
 template <int PA, int PB, int WAVES, int BM>
 __device__ __forceinline__ void gemm1_issue(const char *w0, int w_bytes, const char *in0, int in_bytes, char *slot,
-                                            const int (&offa)[PA], const int (&offb)[PB], int wv, int s)
+                                            const int *offa, const int *offb, int wv, int s)
 {
     const auto r_w = __builtin_amdgcn_make_buffer_rsrc((void *)w0, 0, w_bytes, 0x00020000);
     const auto r_in = __builtin_amdgcn_make_buffer_rsrc((void *)in0, 0, in_bytes, 0x00020000);
@@ -70,11 +71,12 @@ __device__ __forceinline__ void gemm1_issue(const char *w0, int w_bytes, const c
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r_in, (lds_void_g1 *)(slot + BM * 128 + (wv + j * WAVES) * 1024), 16, offb[j], s * 128, 0, 0);
 }
 
-template <int MT, int NT, int WM, int WN, int SLOTS, int OCC>   // OCC: waves per SIMD the register allocation must allow (2 workgroups per CU: 4 for 8 waves)
+template <typename T, int MT, int NT, int WM, int WN, int SLOTS, int OCC>   // T: bf16_t | f16_t; OCC: waves per SIMD the register allocation must allow (2 workgroups per CU: 4 for 8 waves)
 __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm1_kernel(Gemm1Args a)
 {
     using C = Gemm1Cfg<MT, NT, WM, WN, SLOTS>;
-    using E = ET<bf16_t>;
+    using E = ET<T>;
+    static_assert(sizeof(T) == 2, "2-byte element types");
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
 
     const int tid = threadIdx.x;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void gemm1_kernel(Gemm1Args a)
     e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = (int)(a.N >> 4); e.Wo = 16; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = H3D_OUT_NHWC;
     __syncthreads();                              // nobody reads the ring any more
-    tile_epilogue_lds<MT, NT>(acc, e, 0, (int)(p0 >> 4), 0, cout0 + wm * MT * 32, wn, l, smem + wv * epi_lds_stride<MT, NT>());
+    tile_epilogue_lds<T, MT, NT>(acc, e, 0, (int)(p0 >> 4), 0, cout0 + wm * MT * 32, wn, l, smem + wv * epi_lds_stride<MT, NT>());
 }
 
 template <int MT, int NT, int WM, int WN, int SLOTS, int WGS = 1>   // WGS: workgroups per CU the LDS and register budgets are cut for
@@ -191,8 +193,9 @@ static int launch_gemm1_cfg(const Gemm1Args &a0, hipStream_t st)
     a.tiles_n = (int)((a.N + C::BN - 1) / C::BN);
     a.blocks_m = cdiv(a.Cout, C::BM);
     a.xcd = h3d_xcd_mode();
-    if (h3d_note_kernel("gemm1_kernel<%d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, SLOTS, OCC)) return H3D_OK;
-    hipLaunchKernelGGL((gemm1_kernel<MT, NT, WM, WN, SLOTS, OCC>), dim3(a.tiles_n * a.blocks_m), dim3(C::THREADS), 0, st, a);
+    if (h3d_note_kernel("gemm1_kernel<%s, %d, %d, %d, %d, %d, %d>", a.f16 ? "f16_t" : "unsigned short", MT, NT, WM, WN, SLOTS, OCC)) return H3D_OK;
+    if (a.f16) hipLaunchKernelGGL((gemm1_kernel<f16_t, MT, NT, WM, WN, SLOTS, OCC>), dim3(a.tiles_n * a.blocks_m), dim3(C::THREADS), 0, st, a);
+    else hipLaunchKernelGGL((gemm1_kernel<bf16_t, MT, NT, WM, WN, SLOTS, OCC>), dim3(a.tiles_n * a.blocks_m), dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("gemm1_kernel");
     return H3D_OK;
 }
@@ -201,7 +204,7 @@ static int launch_gemm1_cfg(const Gemm1Args &a0, hipStream_t st)
 // the lean NHWC epilogue, a pixel count the width-16 view covers exactly, a grid worth the tiles)
 bool h3d_gemm1_takes(const h3d_op &op)
 {
-    if (op.dtype != H3D_BF16 || op.ksize != 1 || (op.stride != 1 && op.stride != 2) || op.out_mode != H3D_OUT_NHWC) return false;
+    if ((op.dtype != H3D_BF16 && op.dtype != H3D_F16) || op.ksize != 1 || (op.stride != 1 && op.stride != 2) || op.out_mode != H3D_OUT_NHWC) return false;
     if (op.stride == 2 && (long long)op.B * op.H * op.W * op.in_cs * 2 >= 0x7ffffff0ll) return false;   // absolute 32-bit offsets
     if (op.reserved & 0x3000) return false;                  // tuning overrides 0x1000 (tile shape), 0x2000: the halo-tile kernel of csrc/conv.hip
     const long long N = (long long)op.B * op.Ho * op.Wo;
@@ -224,6 +227,7 @@ int h3d_launch_gemm1(const h3d_op &op, hipStream_t st)
     a.N = (long long)op.B * op.Ho * op.Wo; a.Cin = op.Cin; a.in_cs = op.in_cs; a.Cout = op.Cout; a.out_cs = op.out_cs;
     a.res_cs = op.in2_cs; a.relu = op.relu; a.wrows = op.wrows; a.tiles_n = a.blocks_m = 0; a.xcd = 0;
     a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo; a.stride = op.stride;
+    a.f16 = op.dtype == H3D_F16;
     // a tile's epilogue reads the bias of ALL its channel rows unguarded, and its filter rows must exist or lie past the end
     // of the bank: a channel block of BM rows needs cdiv(Cout, BM) * BM packed rows (128 is guaranteed, see above)
     const bool ok256 = cdiv(op.Cout, 256) * 256 <= op.wrows;

@@ -143,8 +143,12 @@ __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][N
                     fb[n].lo = f32x4{x[0], x[1], x[2], x[3]};
                     fb[n].hi = f32x4{x[4], x[5], x[6], x[7]};
                 } else {
-                    uint32_t pk[4] = {pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7])};
-                    if constexpr (BIASC) {
+                    if constexpr (std::is_same_v<T, f16_t>) {       // fp16: ReLU and the saturation at 65504 in one v_med3_f32 each
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] = __builtin_amdgcn_fmed3f(x[j], 0.f, 65504.f);
+                    }
+                    uint32_t pk[4] = {EP<T>::pack2(x[0], x[1]), EP<T>::pack2(x[2], x[3]), EP<T>::pack2(x[4], x[5]), EP<T>::pack2(x[6], x[7])};
+                    if constexpr (BIASC && !std::is_same_v<T, f16_t>) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             pk[j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[j]), s16x2{0, 0}));
@@ -479,7 +483,8 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.in2) H3D_FAIL(H3D_ERR_ARG, "heads: null pointer");
     const h3d_heads_desc *d = (const h3d_heads_desc *)op.in2;
-    const int es = op.dtype == H3D_BF16 ? 2 : 4;
+    const int es = h3d_dtype_bytes(op.dtype);
+    if (!es) H3D_FAIL(H3D_ERR_DTYPE, "heads: dtype %d", op.dtype);
     if (op.Cin != HC_IN || op.in_cs % (16 / es) || op.in_cs < HC_IN)
         H3D_FAIL(H3D_ERR_SHAPE, "heads: input must have %d channels (got %d, stride %d)", HC_IN, op.Cin, op.in_cs);
     if (op.Cout <= 0 || op.Cout % HC_SLAB || op.Cout > 256)
@@ -503,12 +508,11 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
     }
     int m2 = 1;
     for (int i = 0; i < d->nheads; ++i) m2 = max(m2, (d->head[i].C + 31) / 32);   // row tiles of the widest head
-    const int th = op.dtype == H3D_BF16 ? 16 : 8;
+    const int th = es == 2 ? 16 : 8;
     a.tiles_x = cdiv(op.W, 32); a.tiles_y = cdiv(op.H, th);
     const dim3 grid(op.B * a.tiles_x * a.tiles_y), blk(512);
-    if (op.dtype != H3D_BF16 && op.dtype != H3D_F32) H3D_FAIL(H3D_ERR_DTYPE, "heads: dtype %d", op.dtype);
     const bool biasc = !(op.reserved & 0x200);    // tuning override (tools/ab_heads.py): 0x200 = separate bias / zeroing pass
-    if (h3d_note_kernel("heads_kernel<%s, %d, %d, %s>", op.dtype == H3D_BF16 ? "unsigned short" : "float", th, m2, biasc ? "true" : "false"))
+    if (h3d_note_kernel("heads_kernel<%s, %d, %d, %s>", op.dtype == H3D_BF16 ? "unsigned short" : op.dtype == H3D_F16 ? "f16_t" : "float", th, m2, biasc ? "true" : "false"))
         return H3D_OK;
 #define H3D_HEADS_LAUNCH(T, TH, M2)                                                                 \
     do {                                                                                             \
@@ -519,6 +523,10 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
         if (m2 == 1) H3D_HEADS_LAUNCH(bf16_t, 16, 1);
         else if (m2 == 2) H3D_HEADS_LAUNCH(bf16_t, 16, 2);
         else H3D_HEADS_LAUNCH(bf16_t, 16, 3);
+    } else if (op.dtype == H3D_F16) {
+        if (m2 == 1) H3D_HEADS_LAUNCH(f16_t, 16, 1);
+        else if (m2 == 2) H3D_HEADS_LAUNCH(f16_t, 16, 2);
+        else H3D_HEADS_LAUNCH(f16_t, 16, 3);
     } else {
         if (m2 == 1) H3D_HEADS_LAUNCH(float, 8, 1);
         else if (m2 == 2) H3D_HEADS_LAUNCH(float, 8, 2);

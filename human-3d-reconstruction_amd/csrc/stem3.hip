@@ -23,9 +23,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_s3;
 
 struct Stem3Args {
     const float *img;      // [B,3,H,W] fp32
-    const bf16_t *w;       // [16][7][32] stem (k = dx*4 + c) | [5][16][32] level0 (k = tapsel*16 + c) | [32][9][16] level1
+    const uint16_t *w;     // (bf16 | fp16) [16][7][32] stem (k = dx*4 + c) | [5][16][32] level0 (k = tapsel*16 + c) | [32][9][16] level1
     const float *bias;     // [16 | 16 | 32]
-    bf16_t *out;           // [B,Ho,Wo,out_cs] level1
+    void *out;             // [B,Ho,Wo,out_cs] level1
     int B, H, W, Ho, Wo, out_cs;
     int tiles_x, tiles_y;
     int dbg;               // ABLATE builds: stop after phase dbg (1..3)
@@ -42,15 +42,26 @@ constexpr int S3K_LDS = S3K_LDS_I + S3K_LDS_S + S3K_LDS_L + 4096;     // + slack
 // pairs (v_pk_max_i16 against 0: a negative bf16 is a negative int16, rounding never changes the sign, so
 // round(relu(x)) == relu(round(x)) bit for bit) and the image test is a select.  (-2 % on the kernel: its waves are parked
 // on the four barriers of a tile 55 % of the time, not short of vector issue slots.)
+template <typename T>      // (the same holds for fp16: sign-magnitude, rounding keeps the sign)
 __device__ __forceinline__ u32x2 stem3_epi(const f32x4_s3 &acc, const float (&b)[4], bool in)
 {
     typedef short s16x2_s3 __attribute__((ext_vector_type(2)));
-    uint32_t lo = pack_bf16x2(acc[0] + b[0], acc[1] + b[1]), hi = pack_bf16x2(acc[2] + b[2], acc[3] + b[3]);
+    uint32_t lo = EP<T>::pack2(acc[0] + b[0], acc[1] + b[1]), hi = EP<T>::pack2(acc[2] + b[2], acc[3] + b[3]);
     lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_s3, lo), s16x2_s3{0, 0}));
     hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_s3, hi), s16x2_s3{0, 0}));
     return u32x2{in ? lo : 0u, in ? hi : 0u};
 }
 
+template <typename T>
+__device__ __forceinline__ f32x4_s3 stem3_mfma16(const u32x4 &fa, const u32x4 &fb, const f32x4_s3 &acc)
+{
+    if constexpr (std::is_same_v<T, f16_t>)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa), __builtin_bit_cast(f16x8_t, fb), acc, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb), acc, 0, 0, 0);
+}
+
+template <typename T>      // bf16_t | f16_t
 __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
 {
     __shared__ __attribute__((aligned(16))) char smem[S3K_LDS];
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ix = 4 * j - 3 + e;
-                if (ix >= 0 && ix < S3K_IW) s_i[iy * S3K_IW + ix] = uint2{pack_bf16x2(pc0[e], pc1[e]), pack_bf16x2(pc2[e], 0.f)};
+                if (ix >= 0 && ix < S3K_IW) s_i[iy * S3K_IW + ix] = uint2{EP<T>::pack2(pc0[e], pc1[e]), EP<T>::pack2(pc2[e], 0.f)};
             }
         }
     };
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     u32x4 fa0[7], fa1[5];
 #pragma unroll
     for (int dy = 0; dy < 7; ++dy) fa0[dy] = *reinterpret_cast<const u32x4 *>(a.w + (p * 7 + dy) * 32 + 8 * q);
-    const bf16_t *w1 = a.w + 16 * 7 * 32;
+    const uint16_t *w1 = a.w + 16 * 7 * 32;
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) fa1[ks] = *reinterpret_cast<const u32x4 *>(w1 + (ks * 16 + p) * 32 + 8 * q);
     float b0[4], b1[4];
@@ -131,13 +142,12 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
         for (int dy = 0; dy < 7; ++dy) {
             const uint2 lo = s_i[(sy + dy) * S3K_IW + sx + 2 * q], hi = s_i[(sy + dy) * S3K_IW + sx + 2 * q + 1];
             const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa0[dy]), __builtin_bit_cast(bf16x8_t, fb), acc,
-                                                          0, 0, 0);
+            acc = stem3_mfma16<T>(fa0[dy], fb, acc);
         }
         if (sx < S3K_SW) {
             const int gy = sy0 + sy, gx = sx0 + sx;
             const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = stem3_epi(acc, b0, in);
+            *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = stem3_epi<T>(acc, b0, in);
         }
     }
     __syncthreads();
@@ -167,8 +177,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const u32x4 fb = *reinterpret_cast<const u32x4 *>(s_s + lyv[u] * S3K_ROWB + lxv[u] * S3K_PXB + toff[ks]);
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa1[ks]), __builtin_bit_cast(bf16x8_t, fb),
-                                                                 acc[u], 0, 0, 0);
+                acc[u] = stem3_mfma16<T>(fa1[ks], fb, acc[u]);
             }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
             if (lx < S3K_LW) {
                 const int gy = ly0 + ly, gx = lx0 + lx;
                 const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                *reinterpret_cast<u32x2 *>(s_l + ly * S3K_ROWB + lx * S3K_PXB + q * 8) = stem3_epi(acc[u], b1, in);
+                *reinterpret_cast<u32x2 *>(s_l + ly * S3K_ROWB + lx * S3K_PXB + q * 8) = stem3_epi<T>(acc[u], b1, in);
             }
         }
     }
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     // ---- P3: level1 (3x3 stride 2, 32 channels): waves 0..3, one 32-pixel N tile each -------------------------
     if (wv < 4) {
         const int r = l & 31, h = l >> 5;
-        const bf16_t *w2 = a.w + 16 * 7 * 32 + 5 * 16 * 32;
+        const uint16_t *w2 = a.w + 16 * 7 * 32 + 5 * 16 * 32;
         const int py = 2 * wv + (r >> 4), px = r & 15;
         const char *base = s_l + (2 * py) * S3K_ROWB + (2 * px) * S3K_PXB + h * 16;
         f32x16 acc[1][1];
@@ -198,13 +207,14 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
         for (int tap = 0; tap < 9; ++tap) {
             const u32x4 fa = *reinterpret_cast<const u32x4 *>(w2 + (r * 9 + tap) * 16 + 8 * h);
             const u32x4 fb = *reinterpret_cast<const u32x4 *>(base + (tap / 3) * S3K_ROWB + (tap % 3) * S3K_PXB);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb),
-                                                                acc[0][0], 0, 0, 0);
+            typename ET<T>::frag fa_, fb_;
+            fa_.v = fa; fb_.v = fb;
+            ET<T>::mma(acc[0][0], fa_, fb_);
         }
         EpiArgs e;
         e.bias = a.bias + 32; e.res = nullptr; e.out = (char *)a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = 32;
         e.out_cs = a.out_cs; e.res_cs = 0; e.relu = 1; e.out_mode = H3D_OUT_NHWC;
-        tile_epilogue<bf16_t, 1, 1, true>(acc, e, b, oy1, ox1, 0, wv, r, h);
+        tile_epilogue<T, 1, 1, true>(acc, e, b, oy1, ox1, 0, wv, r, h);
     }
     }   // tiles of this workgroup
 }
@@ -212,18 +222,19 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
 int h3d_launch_stem3(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "stem3: null pointer");
-    if (op.dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "stem3: bf16 plans only (dtype %d)", op.dtype);
+    if (op.dtype != H3D_BF16 && op.dtype != H3D_F16) H3D_FAIL(H3D_ERR_DTYPE, "stem3: bf16 / fp16 plans only (dtype %d)", op.dtype);
     if (op.Cin != 3 || op.Cout != 32 || op.Ho != (op.H - 1) / 2 + 1 || op.Wo != (op.W - 1) / 2 + 1 || op.out_cs % 4 || op.out_cs < 32)
         H3D_FAIL(H3D_ERR_SHAPE, "stem3: expects 3 -> 16 -> 16 -> 32 channels, output %dx%d (got %d -> %d, %dx%d)", (op.H - 1) / 2 + 1,
                  (op.W - 1) / 2 + 1, op.Cin, op.Cout, op.Ho, op.Wo);
     if (((uintptr_t)op.bias & 15) || ((uintptr_t)op.w & 15)) H3D_FAIL(H3D_ERR_ARG, "stem3: weights / bias must be 16-byte aligned");
     Stem3Args a;
-    a.img = (const float *)op.in; a.w = (const bf16_t *)op.w; a.bias = op.bias; a.out = (bf16_t *)op.out;
+    a.img = (const float *)op.in; a.w = (const uint16_t *)op.w; a.bias = op.bias; a.out = op.out;
     a.B = op.B; a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo; a.out_cs = op.out_cs;
     a.tiles_x = cdiv(op.Wo, 16); a.tiles_y = cdiv(op.Ho, 8);
     a.dbg = op.reserved;
-    if (h3d_note_kernel("stem3_kernel")) return H3D_OK;
-    hipLaunchKernelGGL(stem3_kernel, dim3(cdiv(op.B * a.tiles_x * a.tiles_y, S3K_TPB)), dim3(512), 0, st, a);
+    if (h3d_note_kernel("stem3_kernel<%s>", op.dtype == H3D_F16 ? "f16_t" : "unsigned short")) return H3D_OK;
+    if (op.dtype == H3D_F16) hipLaunchKernelGGL(stem3_kernel<f16_t>, dim3(cdiv(op.B * a.tiles_x * a.tiles_y, S3K_TPB)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(stem3_kernel<bf16_t>, dim3(cdiv(op.B * a.tiles_x * a.tiles_y, S3K_TPB)), dim3(512), 0, st, a);
     H3D_CHECK_LAUNCH("stem3_kernel");
     return H3D_OK;
 }

@@ -3,7 +3,8 @@
 constructor arguments and state_dict keys (weight, bias, conv_offset_mask.{weight,bias}).
 
 Backward (dcn_v2_backward) and PS-ROI pooling are out of scope:
-inference only -- calling with autograd enabled on tensors that require grad raises."""
+inference only -- an INPUT that requires grad (with autograd enabled) raises; parameters may require grad (the
+nn.Parameter default), results are computed without a graph and returned detached."""
 import math
 
 import torch
@@ -57,14 +58,15 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
 
 def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
     """`_DCNv2.apply` argument order (dcn_v2.py:18-33), forward only."""
-    if torch.is_grad_enabled() and any(t.requires_grad for t in (input, offset, mask, weight, bias)):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (input, offset, mask)):
         raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): "
-                           "call under torch.no_grad()")
+                           "an input tensor requires grad")
     sh, sw = _pair(stride)
     ph, pw = _pair(padding)
     dh, dw = _pair(dilation)
     kh, kw = weight.shape[2:4]
-    return dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_groups)
+    with torch.no_grad():       # (parameters require grad by default; the result carries no graph)
+        return dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_groups)
 
 
 class DCNv2(nn.Module):
@@ -118,10 +120,9 @@ class DCN(DCNv2):
         ps = (self.weight, self.bias, self.conv_offset_mask.weight, self.conv_offset_mask.bias)
         key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (str(device),)
         if getattr(self, "_pack_key", None) != key:
-            pw = object.__new__(engine.PackedWeights)
-            pw.sd = {"w": self.weight.detach().float().cpu(), "b": self.bias.detach().float().cpu(),
-                     "ow": self.conv_offset_mask.weight.detach().float().cpu(), "ob": self.conv_offset_mask.bias.detach().float().cpu()}
-            pw.dtype, pw.device, pw.t = "f32", torch.device(device), {}
+            pw = engine.PackedWeights.from_tensors(
+                {"w": self.weight, "b": self.bias, "ow": self.conv_offset_mask.weight, "ob": self.conv_offset_mask.bias},
+                "f32", device)
             wp, bp, cout, cin, k, rows = pw.conv("w", "b", None, as_half=True)
             wo, bo = pw.offset_conv("ow", "ob", rows)
             self._pack = (wp, wo, torch.cat([bp.cpu(), bo]).contiguous().to(device), rows)
@@ -132,10 +133,16 @@ class DCN(DCNv2):
         """conv_offset_mask -> chunk/cat/sigmoid -> dcn_v2_conv (dcn_v2.py:118-128).  In the configuration the model uses
         (model.py:355) all of it is ONE launch of the fused DeformConv kernel in fp32 parity mode (offsets and mask never
         reach memory); other configurations compute the offset conv with torch and call the operator."""
-        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): call under torch.no_grad()")
+        if torch.is_grad_enabled() and input.requires_grad:
+            raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): the input requires grad")
         if not input.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
+        # (parameters require grad by default: `model.eval(); dcn(x)` outside no_grad must work as it does in the reference;
+        #  the result is computed without a graph and returned detached)
+        with torch.no_grad():
+            return self._forward(input)
+
+    def _forward(self, input):
         if self._fused_ok(input):
             from ._lib import H3dOp
             x = input.contiguous()

@@ -24,8 +24,9 @@ import torch
 from . import _lib, arch, arch_hg, arch_res
 from ._lib import H3dOp
 
-_TORCH_DT = {"bf16": torch.bfloat16, "f32": torch.float32}
-_H3D_DT = {"bf16": _lib.H3D_BF16, "f32": _lib.H3D_F32}
+_TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+_H3D_DT = {"bf16": _lib.H3D_BF16, "f16": _lib.H3D_F16, "f32": _lib.H3D_F32}
+LOWP = ("bf16", "f16")      # the 2-byte plans: same kernels, lowering and tile choices; "f16" = BASELINE configs[4]'s arithmetic
 
 
 def _t(v):
@@ -77,6 +78,17 @@ class PackedWeights:
                 for leaf in ("weight", "bias", "running_mean", "running_var"):
                     self.sd["%s.actf.0.%s" % (p, leaf)] = self.sd["%s.%s" % (bn, leaf)]
 
+    @classmethod
+    def from_tensors(cls, tensors, dtype, device):
+        """A packer over a bare {name: tensor} table (no architecture key check): the stand-alone `DCN` module
+        (h3d_amd.dcn_v2.DCN) packs its four parameters with the same `conv` / `offset_conv` routines as the network."""
+        self = cls.__new__(cls)
+        self.heads, self.use_dcn, self.dtype, self.device = {}, True, dtype, torch.device(device)
+        self.head_conv, self.arch = 0, "bare"
+        self.sd = {k: _t(v) for k, v in tensors.items()}
+        self.t = {}
+        return self
+
     def _fold(self, w, b, bn):
         """conv(+bias) followed by eval BatchNorm `bn` -> (w', b')."""
         if b is None:
@@ -102,7 +114,7 @@ class PackedWeights:
             wp[:co] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
             bp = torch.zeros(rows)
             bp[:co] = b
-            td = torch.float16 if (as_half and self.dtype == "bf16") else _TORCH_DT[self.dtype]
+            td = torch.float16 if (as_half and self.dtype in LOWP) else _TORCH_DT[self.dtype]
             self.t[key] = (wp.to(td).contiguous().to(self.device),
                            bp.contiguous().to(self.device), cout, ci, kh, rows)
         return self.t[key]
@@ -122,7 +134,7 @@ class PackedWeights:
             img = self._stage_image(wp)
             bp = torch.zeros(G * 32)
             bp[:co] = b
-            self.t[key] = (img.to(torch.bfloat16).contiguous().to(self.device), bp.contiguous().to(self.device),
+            self.t[key] = (img.to(_TORCH_DT[self.dtype]).contiguous().to(self.device), bp.contiguous().to(self.device),
                            co, ci, G * 32)
         return self.t[key]
 
@@ -161,11 +173,11 @@ class PackedWeights:
         key = ("stem",)
         if key not in self.t:
             w, b = self._fold(self.sd["base.base_layer.0.weight"], None, "base.base_layer.1")
-            if self.dtype == "bf16":
+            if self.dtype in LOWP:
                 # MFMA stem (csrc/conv.hip stem_mfma_kernel): [16][7 dy][32] bf16 with k = dx*4 + c
                 wp = torch.zeros(16, 7, 8, 4)
                 wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)          # [o][dy][dx][c]
-                w = wp.reshape(16, 7, 32).to(torch.bfloat16)
+                w = wp.reshape(16, 7, 32).to(_TORCH_DT[self.dtype])
             self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
         return self.t[key]
 
@@ -178,7 +190,7 @@ class PackedWeights:
             co = w.shape[0]
             wp = torch.zeros(co, 7, 8, 4)
             wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)          # [o][dy][dx][c]
-            self.t[key] = (wp.reshape(co, 7, 32).to(torch.bfloat16).contiguous().to(self.device), b.float().contiguous().to(self.device))
+            self.t[key] = (wp.reshape(co, 7, 32).to(_TORCH_DT[self.dtype]).contiguous().to(self.device), b.float().contiguous().to(self.device))
         return self.t[key]
 
     def stem3(self):
@@ -194,7 +206,7 @@ class PackedWeights:
             for tap in range(9):
                 t1[tap // 2, :, tap % 2, :] = w1t[:, tap, :]
             w2t = w2.permute(0, 2, 3, 1).reshape(32, 9, 16)
-            flat = torch.cat([w0.cpu().float().reshape(-1), t1.reshape(-1), w2t.reshape(-1)]).to(torch.bfloat16)
+            flat = torch.cat([w0.cpu().float().reshape(-1), t1.reshape(-1), w2t.reshape(-1)]).to(_TORCH_DT[self.dtype])
             bias = torch.cat([b0.cpu().float(), b1.float(), b2.float()])
             self.t[key] = (flat.contiguous().to(self.device), bias.contiguous().to(self.device))
         return self.t[key]
@@ -217,7 +229,7 @@ class PackedWeights:
                     row = (i & 3) + 8 * (i >> 2) + 4 * hh
                     wp[row] = w[ch].permute(1, 2, 0).reshape(9, ci)
                     bp[row] = b[ch]
-            td = torch.float16 if self.dtype == "bf16" else torch.float32
+            td = torch.float16 if self.dtype in LOWP else torch.float32
             self.t[key] = (wp.to(td).contiguous().to(self.device), bp)
         return self.t[key]
 
@@ -319,6 +331,7 @@ class Plan:
         fuse_upnode=True,      # False: up-sample + add always as its own launch in front of the 64-channel node DeformConvs
         fuse_upnode_min_f=2,   # ... from this up-sampling factor.  Same box, batch 64, up-sampling + node over the five layers:
                                # 1.234 ms as two launches each, 1.194 with the 4x layer folded, 1.156 with all five
+        fuse_updcn3=False,     # True: IDAUp's up-sample + add folded into the apron staging of the node DeformConv (csrc/dcn3.hip UP)
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
@@ -341,7 +354,7 @@ class Plan:
                                "to (x|31)+1 (datasets/coco.py:160-163)" % (H, W))
         self.pw, self.B, self.H, self.W = pw, B, H, W
         self.dtype = pw.dtype
-        self.es = 2 if pw.dtype == "bf16" else 4
+        self.es = 2 if pw.dtype in LOWP else 4
         self.ops = []
         self.keep = []          # tensors the ops point into
         self.images = torch.empty(B, 3, H, W, dtype=torch.float32, device=pw.device)
@@ -372,7 +385,7 @@ class Plan:
     def conv(self, x, wkey, out=None, bkey=None, bn=None, stride=1, relu=True, res=None, out_mode=_lib.OUT_NHWC,
              pad_cout_to=None, out_tensor=None):
         wshape = self.pw.sd[wkey].shape
-        if (self.stream_convs and self.pw.dtype == "bf16" and wshape[2] == 3 and wshape[1] % 16 == 0
+        if (self.stream_convs and self.pw.dtype in LOWP and wshape[2] == 3 and wshape[1] % 16 == 0
                 and (stride == 1 or (stride == 2 and wshape[1] >= self.stream_s2_min_cin and self.stream_s2))
                 and out_mode == _lib.OUT_NHWC and pad_cout_to is None):
             return self._conv_stream(x, wkey, out, bkey, bn, relu, res, stride)
@@ -392,7 +405,7 @@ class Plan:
             optr, ocs = out_tensor.data_ptr(), cout
         tune = 0
         if (k == 1 and stride == 1 and self.conv1x1_th16_min_cin and cin >= self.conv1x1_th16_min_cin and cin % 64 == 0
-                and cout > 32 and self.pw.dtype == "bf16"):
+                and cout > 32 and self.pw.dtype in LOWP):
             tune = 0x1000 | ((4 if cout > 64 else 2) << 4) | 2       # csrc/conv.hip tuning override: MT, TH = 16
         self._op(_lib.OP_CONV, in_=x.ptr, in2=res.ptr if res is not None else None, w=wp.data_ptr(),
                  bias=bp.data_ptr(), out=optr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs,
@@ -498,7 +511,7 @@ class Plan:
                      stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
             return out
         w = self.pw.sd[p + ".conv.weight"]
-        if (self.pw.use_dcn and self.fuse_offsets and self.pw.dtype == "bf16"
+        if (self.pw.use_dcn and self.fuse_offsets and self.pw.dtype in LOWP
                 and (self.stream_dcn3 or (self.dense_dcn3 and w.shape[0] <= 64
                                           # two workgroups per CU only pay with >= 2 x 256 tiles (measured: the 32x32 layer
                                           # of a batch-64 plan, 256 tiles, 0.062 -> 0.076 ms)
@@ -525,6 +538,8 @@ class Plan:
                      relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
             return out
         if self.pw.use_dcn:
+            if self.pw.dtype == "f16":
+                raise RuntimeError("fp16 plans run the fused DeformConv kernel only (fuse_offsets=False is a bf16 / f32 debugging path)")
             om = self.conv(x, p + ".conv.conv_offset_mask.weight", bkey=p + ".conv.conv_offset_mask.bias",
                            relu=False, out_mode=_lib.OUT_NHWC_F32, pad_cout_to=32)
             return self.dcn(x, om, p + ".conv.weight", p + ".conv.bias", p + ".actf.0", out)
@@ -560,7 +575,7 @@ class Plan:
     def _lower(self):
         B, H, W = self.B, self.H, self.W
         C = arch.CHANNELS
-        if self.fuse_stem and self.pw.dtype == "bf16" and C[0] == 16 and C[1] == 32:
+        if self.fuse_stem and self.pw.dtype in LOWP and C[0] == 16 and C[1] == 32:
             # base_layer + level0 + level1 in one launch: the two full-resolution maps never reach HBM (nothing else
             # reads them: DLAUp starts at level 2)
             w, b = self.pw.stem3()
@@ -633,7 +648,7 @@ class Plan:
         """Conv2d(3, cout, 7, stride 2, padding 3) + BN + ReLU from the NCHW fp32 images."""
         H, W = self.H, self.W
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        if self.dtype == "bf16" and self.stem_s2_direct:
+        if self.dtype in LOWP and self.stem_s2_direct:
             w, b = self.pw.stem_s2(wkey, bkey, bn)
             x = self._alloc(Ho, Wo, cout)
             self._op(_lib.OP_STEM, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=x.ptr, H=H, W=W, Cin=3, in_cs=3,
@@ -747,7 +762,7 @@ class DLAEngine:
 
     def __init__(self, state_dict, heads, use_dcn, dtype="bf16", device="cuda", head_conv=256, arch_name="dla34"):
         if dtype not in _TORCH_DT:
-            raise ValueError("dtype must be 'bf16' or 'f32'")
+            raise ValueError("dtype must be 'bf16', 'f16' or 'f32'")
         _lib.lib()                                     # fail loudly now if the HIP library is missing
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -776,7 +791,7 @@ class DLAEngine:
             raise RuntimeError("expected images [B,3,H,W], got %s" % (tuple(images.shape),))
         B, _, H, W = images.shape
         if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 8 and self.pw.arch == "dla34":
-            return self._forward_split(images)
+            return self._forward_split(images, slot)
         plan = self.plan(B, H, W, slot)
         with torch.cuda.device(self.device):
             if images.dtype == torch.float32 and images.is_contiguous():
@@ -786,14 +801,16 @@ class DLAEngine:
                 plan.op_array[0].in_ = plan.images.data_ptr()
             return plan.run()
 
-    def _forward_split(self, images):
+    def _forward_split(self, images, slot=0):
         """Sub-batches on separate HIP streams: the small-grid layers (level4/5, the 16x16 / 32x32 neck
         layers: 128-512 workgroups on 256 CUs) and every kernel's tail overlap with the other
-        sub-batch's launches.  Outputs are written into one full-batch tensor per head."""
+        sub-batch's launches.  Outputs are written into one full-batch tensor per head.  Every `slot` has its own
+        sub-plans, output tensors and internal streams: two batches in flight on different slots share nothing but
+        the packed weights."""
         B, _, H, W = images.shape
         n = self.streams
         sub = B // n
-        key = ("split", B, H, W)
+        key = ("split", B, H, W, slot)
         with torch.cuda.device(self.device):
             if key not in self.plans:
                 plans = [Plan(self.pw, sub, H, W, **self._flags())
@@ -817,7 +834,8 @@ class DLAEngine:
                     done = torch.cuda.Event()
                     done.record(st)
                 cur.wait_event(done)
-            self._keepalive = images
+            self._keepalive = getattr(self, "_keepalive", {})
+            self._keepalive[slot] = images
             return full
 
     __call__ = forward

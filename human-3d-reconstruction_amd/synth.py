@@ -120,6 +120,13 @@ def synth_images(batch, h=512, w=512, seed=317):
     return normalish("images", (batch, 3, h, w), 0.0, 1.0, seed)
 
 
+def synth_image_batch(batch, h=512, w=512, seed=317, first=0):
+    """`batch` INDEPENDENT images (image i is a pure function of (seed, first + i), so a rank's shard [lo, hi) of a global
+    batch is synth_image_batch(hi - lo, ..., first=lo)); generated one image at a time (small temporaries: 64 images of
+    512x512 take 3 s where the one-shot generator needs 18)."""
+    return np.concatenate([normalish("images.%d" % (first + i), (1, 3, h, w), 0.0, 1.0, seed) for i in range(batch)])
+
+
 def synth_heads(batch, h=128, w=128, num_joints=17, seed=0):
     """Decode-only inputs shaped like post-_sigmoid network heads.
 

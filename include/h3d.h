@@ -31,6 +31,8 @@ extern "C" {
 
 #define H3D_F32 0
 #define H3D_BF16 1
+#define H3D_F16 2 /* IEEE fp16 activations and weights, fp32 accumulation (BASELINE configs[4]: `--arch resdcn_101` runs in fp16,
+                     experiments/ctdet_coco_resdcn101.sh:3); stored values saturate at +-65504 */
 
 /* Last error text of the calling thread (thread_local), for the Python shim's RuntimeError. */
 const char *h3d_last_error(void);

@@ -21,16 +21,18 @@ BN_EPS = 1e-5
 
 
 class DLAOracle:
-    def __init__(self, state_dict, heads, use_dcn, down_ratio=4, last_level=5, acc_dtype=None, emulate_bf16=False):
-        """emulate_bf16: round every conv / DeformConv input and every conv weight to bf16 (fp32 accumulation, as
-        the MFMA does).  NOT a model of the GPU kernels' exact rounding points (they fold BatchNorm into the weights
-        before rounding and keep DeformConv filters in fp16): an independent bf16 evaluation of the same graph whose
-        distance from the fp32 result says how much of the GPU's bf16 error is the arithmetic's, not a bug's
-        (tests/test_gpu_fullsize.py)."""
+    def __init__(self, state_dict, heads, use_dcn, down_ratio=4, last_level=5, acc_dtype=None, emulate_bf16=False, emulate=None):
+        """emulate ('bf16' | 'f16'; emulate_bf16=True is 'bf16'): round every conv / DeformConv input and every conv weight
+        to that type (fp32 accumulation, as the MFMA does).  NOT a model of the GPU kernels' exact rounding points (they
+        fold BatchNorm into the weights before rounding and keep DeformConv filters in fp16): an independent low-precision
+        evaluation of the same graph whose distance from the fp32 result says how much of the GPU's error is the
+        arithmetic's, not a bug's (tests/test_gpu_fullsize.py)."""
         self.sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.asarray(v)))
                    for k, v in state_dict.items()}
-        self.q = (lambda t: t.to(torch.bfloat16).float()) if emulate_bf16 else (lambda t: t)
-        if emulate_bf16:
+        emulate = "bf16" if emulate_bf16 else emulate
+        td = {None: None, "bf16": torch.bfloat16, "f16": torch.float16}[emulate]
+        self.q = (lambda t: t.to(td).float()) if td is not None else (lambda t: t)
+        if td is not None:
             self.sd = {k: (self.q(v) if v.dim() == 4 else v) for k, v in self.sd.items()}
         self.heads = heads
         self.use_dcn = use_dcn

@@ -20,11 +20,17 @@ BN_EPS = 1e-5
 
 
 class HourglassOracle:
-    def __init__(self, state_dict, heads, nstack=2, emulate_bf16=False):
+    def __init__(self, state_dict, heads, nstack=2, emulate_bf16=False, emulate=None):
+        """emulate ('bf16' | 'f16'; emulate_bf16=True is 'bf16'): an independent low-precision evaluation of the same graph --
+        conv weights and every STORED activation (the output of each conv + BN (+ residual) + ReLU unit, of each skip conv,
+        of each up-sample + add) rounded to that type, fp32 accumulation: the rounding points of a plan whose activations
+        live in HBM as 2-byte elements (the head outputs stay fp32)."""
         self.sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.asarray(v))) for k, v in state_dict.items()}
         self.heads, self.nstack = heads, nstack
-        self.q = (lambda t: t.to(torch.bfloat16).float()) if emulate_bf16 else (lambda t: t)
-        if emulate_bf16:
+        emulate = "bf16" if emulate_bf16 else emulate
+        td = {None: None, "bf16": torch.bfloat16, "f16": torch.float16}[emulate]
+        self.q = (lambda t: t.to(td).float()) if td is not None else (lambda t: t)
+        if td is not None:
             self.sd = {k: (self.q(v) if v.dim() == 4 else v) for k, v in self.sd.items()}
 
     def _bn(self, x, p):
@@ -38,13 +44,13 @@ class HourglassOracle:
         y = self._conv(x, p + ".conv", stride, (k - 1) // 2)
         if with_bn:
             y = self._bn(y, p + ".bn")
-        return F.relu(y)
+        return self.q(F.relu(y))
 
     def _residual(self, x, p, stride=1):
         y = F.relu(self._bn(self._conv(x, p + ".conv1", stride, 1), p + ".bn1"))
         y = self._bn(self._conv(y, p + ".conv2", 1, 1), p + ".bn2")
-        skip = self._bn(self._conv(x, p + ".skip.0", stride, 0), p + ".skip.1") if (p + ".skip.0.weight") in self.sd else x
-        return F.relu(y + skip)
+        skip = self.q(self._bn(self._conv(x, p + ".skip.0", stride, 0), p + ".skip.1")) if (p + ".skip.0.weight") in self.sd else x
+        return self.q(F.relu(y + skip))
 
     def _seq(self, x, p, n, first_stride=1):
         for j in range(n):
@@ -56,7 +62,7 @@ class HourglassOracle:
         low1 = self._seq(x, p + ".low1", modules[0], 2)
         low2 = self._kp(low1, p + ".low2", n - 1, modules[1:]) if n > 1 else self._seq(low1, p + ".low2", modules[1])
         low3 = self._seq(low2, p + ".low3", modules[0])
-        return up1 + F.interpolate(low3, scale_factor=2, mode="nearest")
+        return self.q(up1 + F.interpolate(low3, scale_factor=2, mode="nearest"))
 
     def forward(self, image):
         inter = self._convolution(image, "pre.0", 7, 2)
@@ -71,9 +77,9 @@ class HourglassOracle:
                 out[head] = self._conv(y, "%s.%d.1" % (head, i))
             outs.append(out)
             if i < self.nstack - 1:
-                inter = self._bn(self._conv(inter, "inters_.%d.0" % i), "inters_.%d.1" % i) + \
+                inter = self.q(self._bn(self._conv(inter, "inters_.%d.0" % i), "inters_.%d.1" % i)) + \
                     self._bn(self._conv(cnv, "cnvs_.%d.0" % i), "cnvs_.%d.1" % i)
-                inter = self._residual(F.relu(inter), "inters.%d" % i)
+                inter = self._residual(self.q(F.relu(inter)), "inters.%d" % i)
         return outs
 
     __call__ = forward

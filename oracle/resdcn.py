@@ -19,11 +19,16 @@ DECONV = (256, 128, 64)
 
 
 class ResDCNOracle:
-    def __init__(self, state_dict, heads, emulate_bf16=False):
+    def __init__(self, state_dict, heads, emulate_bf16=False, emulate=None):
+        """emulate ('bf16' | 'f16'; emulate_bf16=True is 'bf16'): conv weights and every STORED activation (the output of each
+        conv + BN (+ residual) + ReLU unit and of each down-sample conv) rounded to that type, fp32 accumulation -- the
+        rounding points of a plan whose activations live in HBM as 2-byte elements (see oracle/hourglass.py)."""
         self.sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.asarray(v))) for k, v in state_dict.items()}
         self.heads = heads
-        self.q = (lambda t: t.to(torch.bfloat16).float()) if emulate_bf16 else (lambda t: t)
-        if emulate_bf16:
+        emulate = "bf16" if emulate_bf16 else emulate
+        td = {None: None, "bf16": torch.bfloat16, "f16": torch.float16}[emulate]
+        self.q = (lambda t: t.to(td).float()) if td is not None else (lambda t: t)
+        if td is not None:
             self.sd = {k: (self.q(v) if v.dim() == 4 else v) for k, v in self.sd.items()}
 
     def _bn(self, x, p):
@@ -38,12 +43,12 @@ class ResDCNOracle:
         y = F.relu(self._bn(self._conv(y, p + ".conv2", stride, 1), p + ".bn2"))
         y = self._bn(self._conv(y, p + ".conv3"), p + ".bn3")
         if (p + ".downsample.0.weight") in self.sd:
-            x = self._bn(self._conv(x, p + ".downsample.0", stride), p + ".downsample.1")
-        return F.relu(y + x)
+            x = self.q(self._bn(self._conv(x, p + ".downsample.0", stride), p + ".downsample.1"))
+        return self.q(F.relu(y + x))
 
     def forward(self, x):
         sd = self.sd
-        x = F.relu(self._bn(self._conv(x, "conv1", 2, 3), "bn1"))
+        x = self.q(F.relu(self._bn(self._conv(x, "conv1", 2, 3), "bn1")))
         x = F.max_pool2d(x, 3, 2, 1)
         for li, n in enumerate(LAYERS, start=1):
             for b in range(n):

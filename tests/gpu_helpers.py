@@ -8,8 +8,9 @@ import h3d_amd  # noqa: F401
 from h3d_amd import _lib
 from h3d_amd._lib import H3dOp
 
-TD = {"f32": torch.float32, "bf16": torch.bfloat16}
-HD = {"f32": _lib.H3D_F32, "bf16": _lib.H3D_BF16}
+TD = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+HD = {"f32": _lib.H3D_F32, "bf16": _lib.H3D_BF16, "f16": _lib.H3D_F16}
+TN = {"f32": "float", "bf16": "unsigned short", "f16": "f16_t"}      # element-type names inside the kernel symbols
 DEV = "cuda:0"
 
 
@@ -102,6 +103,11 @@ def bf16_round(t):
     return t.to(torch.bfloat16).float()
 
 
+def lowp_round(t, dtype):
+    """Round to the plan's storage type (f32: unchanged)."""
+    return t if dtype == "f32" else t.to(TD[dtype]).float()
+
+
 def rnd(key, shape, lo=-1.0, hi=1.0, seed=0):
     from h3d_amd import synth
     return torch.from_numpy(synth.uniform(key, shape, lo, hi, seed))
@@ -120,10 +126,7 @@ def kernel_name(op):
 def fake_pw(sd, dtype):
     """engine.PackedWeights over an ad-hoc {key: tensor} table (no architecture check)."""
     from h3d_amd import engine
-    pw = object.__new__(engine.PackedWeights)
-    pw.sd = {k: v.float() for k, v in sd.items()}
-    pw.dtype, pw.device, pw.t = dtype, torch.device(DEV), {}
-    return pw
+    return engine.PackedWeights.from_tensors(sd, dtype, DEV)
 
 
 class Built:
@@ -141,22 +144,22 @@ class Built:
         return self.read()
 
 
-def conv_stream_op(x, w, b, stride=1, relu=True, res=None, reserved=0, in_pad=0, out_pad=0):
-    """H3D_OP_CONV_STREAM (bf16) for NCHW fp32 cpu tensors; in_pad/out_pad: live inside wider buffers."""
+def conv_stream_op(x, w, b, stride=1, relu=True, res=None, reserved=0, in_pad=0, out_pad=0, dtype="bf16"):
+    """H3D_OP_CONV_STREAM (bf16 / fp16 plans) for NCHW fp32 cpu tensors; in_pad/out_pad: live inside wider buffers."""
     B, Ci, H, W = x.shape
-    pw = fake_pw({"w": w, "b": b}, "bf16")
+    pw = fake_pw({"w": w, "b": b}, dtype)
     wimg, bp, cout, cin, rows = pw.conv_stream("w", "b")
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    xin, xptr = nhwc(x, "bf16", Ci + in_pad, in_pad // 2 // 8 * 8)
+    xin, xptr = nhwc(x, dtype, Ci + in_pad, in_pad // 2 // 8 * 8)
     keep = [wimg, bp, xin]
     rptr, rcs = None, 0
     if res is not None:
-        rbuf, rptr = nhwc(res, "bf16")
+        rbuf, rptr = nhwc(res, dtype)
         rcs = res.shape[1]
         keep.append(rbuf)
     ocs, coff = cout + out_pad, out_pad // 2 // 8 * 8
-    out = torch.full((B, Ho, Wo, ocs), 7.0, dtype=torch.bfloat16, device=DEV)
-    op = mk(_lib.OP_CONV_STREAM, "bf16", in_=xptr, in2=rptr, w=wimg.data_ptr(), bias=bp.data_ptr(),
+    out = torch.full((B, Ho, Wo, ocs), 7.0, dtype=TD[dtype], device=DEV)
+    op = mk(_lib.OP_CONV_STREAM, dtype, in_=xptr, in2=rptr, w=wimg.data_ptr(), bias=bp.data_ptr(),
             out=out.data_ptr() + coff * 2, B=B, H=H, W=W, Cin=Ci, in_cs=Ci + in_pad, in2_cs=rcs, Ho=Ho, Wo=Wo, Cout=cout,
             out_cs=ocs, ksize=3, stride=stride, relu=int(relu), out_mode=_lib.OUT_NHWC, wrows=rows, reserved=reserved)
 
@@ -196,13 +199,13 @@ def dcn_fused_op(kind, x, w, b, wo, bo, dtype="bf16", reserved=0, skip=None, w_u
         opk, wptr, in2 = _lib.OP_DCN_FUSED, wp.data_ptr(), wop.data_ptr()
         keep += [wp, wop, bias, xin]
     else:
-        assert dtype == "bf16"
+        assert dtype in ("bf16", "f16") and (dtype == "bf16" or kind == "stream")
         ck = int(_lib.lib().h3d_dcn_fused_ck(Ci, w.shape[0])) if kind == "stream" else 16
         wimg, woimg, bias, cout, cin, rows = pw.dcn_stream("p", ck)
         wptr = wimg.data_ptr()
         keep += [wimg, woimg, bias]
         if kind == "stream":
-            xin, xptr = nhwc(x, "bf16")
+            xin, xptr = nhwc(x, dtype)
             opk, in2 = _lib.OP_DCN_FUSED_STREAM, woimg.data_ptr()
         elif kind == "f16":
             xin = x.permute(0, 2, 3, 1).contiguous().to(torch.float16).to(DEV)

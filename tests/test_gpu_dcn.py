@@ -151,6 +151,24 @@ def test_dcn_module_model_configuration_is_one_fused_launch_and_matches_oracle()
     assert mod._fused_ok(x.to(DEV)) and not dcn_v2.DCN(16, 8, (3, 3), 2, 1).to(DEV)._fused_ok(x.to(DEV))
 
 
+def test_dcn_module_runs_outside_no_grad_like_the_reference_module():
+    # nn.Parameter requires grad by default, so `model.eval(); dcn(x)` outside torch.no_grad() used to raise.
+    # The reference module runs there; ours computes without a graph and returns a detached tensor.  An input that itself
+    # requires grad asks for dcn_v2_backward (out of scope): that still raises.
+    torch.manual_seed(0)
+    mod = dcn_v2.DCN(32, 16, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV).eval()
+    x = rnd("x", (1, 32, 12, 12)).to(DEV)
+    y = mod(x)
+    assert not y.requires_grad
+    with torch.no_grad():
+        np.testing.assert_array_equal(y.cpu().numpy(), mod(x).cpu().numpy())
+    with pytest.raises(RuntimeError, match="inference-only"):
+        mod(x.clone().requires_grad_(True))
+    # the general (non-fused) configuration goes through the operator: same rule
+    mod2 = dcn_v2.DCN(16, 8, kernel_size=(3, 3), stride=2, padding=1).to(DEV).eval()
+    assert not mod2(rnd("x2", (1, 16, 12, 12)).to(DEV)).requires_grad
+
+
 NET_CASES = [(2, 64, 64, 16, 16), (1, 128, 64, 24, 40), (1, 256, 128, 16, 16), (1, 512, 256, 8, 8), (1, 32, 16, 20, 20)]
 
 

@@ -94,17 +94,21 @@ def test_full_size_f32_mode_indices_match_oracle(setup):
     m = oim.index_match(got, res["inds"].cpu().numpy(), ref, K=100)
     print("f32 mode: index_match %s" % m)
     assert m["robust_prefix_equal"] and m["agreement"] >= 0.95 and m["set_overlap"] >= 0.98, m
+    # ... and the bit-match clause is not vacuous here: some ranks are provably stable under the measured score error
+    # (bench.py's parity_mode record on the same weights: robust_prefix 5, equal_prefix 100)
+    assert m["robust_prefix"] > 0, m
 
 
-def _bf16_vs_emulation(got, ref, emu, what, ratio=2.0):
-    # (ratio 2 for these backbones: the GPU path rounds the output of every skip / down-sample conv to bf16 before the
-    #  residual add, which the CPU emulation -- rounding conv INPUTS only -- does not; measured 1.2-1.8x; f32 mode pins
-    #  the wiring at 2e-3 in tests/test_gpu_backbones.py)
+def _lowp_vs_emulation(got, ref, emu, what, ratio=BF16_RATIO):
+    # the CPU emulation rounds where the plan rounds (conv weights and every stored activation, including the skip /
+    # down-sample conv outputs in front of the residual adds: oracle/hourglass.py, oracle/resdcn.py), so the same 1.5x
+    # as for DLA-34 applies, in max-norm and in rms (round 2 had 3x / 2x here against an emulation that rounded conv
+    # inputs only; f32 mode pins the wiring at 2e-3 in tests/test_gpu_backbones.py)
     emax, erms = float(np.abs(got - ref).max()), float(np.sqrt(np.mean((got - ref) ** 2)))
     tmax, trms = float(np.abs(emu - ref).max()), float(np.sqrt(np.mean((emu - ref) ** 2)))
-    print("%s: GPU bf16 error (max %.4g, rms %.4g) vs CPU bf16 emulation (max %.4g, rms %.4g); head scale %.3g"
+    print("%s: GPU error (max %.4g, rms %.4g) vs CPU emulation of the same arithmetic (max %.4g, rms %.4g); head scale %.3g"
           % (what, emax, erms, tmax, trms, float(np.abs(ref).max())))
-    assert emax <= 1.5 * ratio * tmax + 1e-3 and erms <= ratio * trms + 1e-4, (what, emax, erms, tmax, trms)
+    assert emax <= ratio * tmax + 1e-3 and erms <= ratio * trms + 1e-4, (what, emax, erms, tmax, trms)
 
 
 def test_full_size_hourglass_shard_vs_oracle():
@@ -127,7 +131,7 @@ def test_full_size_hourglass_shard_vs_oracle():
     for i, (o, r, e) in enumerate(zip(outs, ref, emu)):
         for k in opt.heads:
             assert torch.equal(o[k], o[k][:1].expand_as(o[k])), (i, k)
-            _bf16_vs_emulation(o[k][:1].cpu().numpy(), r[k].numpy(), e[k].numpy(), "hourglass stack %d %s" % (i, k))
+            _lowp_vs_emulation(o[k][:1].cpu().numpy(), r[k].numpy(), e[k].numpy(), "hourglass stack %d %s" % (i, k))
     res = det.run(xs)
     h = {k: v[:1].cpu().numpy() for k, v in res["heads"].items()}
     dref = odec.multi_pose_decode(utils._sigmoid(res["heads"]["hm"][:1].clone()).cpu().numpy(), h["wh"], h["hps"], h["reg"],
@@ -138,25 +142,31 @@ def test_full_size_hourglass_shard_vs_oracle():
     torch.cuda.empty_cache()
 
 
-def test_full_size_resdcn_shard_vs_oracle():
-    """BASELINE configs[4]: ResNet-101-DCN ctdet at 768x768, batch 256 over 8 GPUs = 32 images per GPU (bf16 here where
-    the config says fp16).  One synthetic image repeated 32 times vs the oracle restatement (parity unpinned)."""
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_full_size_resdcn_shard_vs_oracle(dtype):
+    """BASELINE configs[4]: ResNet-101-DCN ctdet at 768x768 fp16, batch 256 over 8 GPUs = 32 images per GPU -- in the
+    config's own arithmetic (dtype f16: H3D_F16 plans) and in bf16.  One synthetic image repeated 32 times vs the oracle
+    restatement (parity unpinned) and its emulation of the same arithmetic."""
     from h3d_amd import arch_res
     from h3d_amd.detector import make_detector
     from oracle import resdcn as ores
-    opt = Opt(arch="resdcn_101", task="ctdet", input_h=768, input_w=768, dtype="bf16", K=100)
+    opt = Opt(arch="resdcn_101", task="ctdet", input_h=768, input_w=768, dtype=dtype, K=100)
     sd = synth.synth_state_dict(arch_res.state_dict_shapes(opt.heads, 64), seed=0, gain=0.9, offset_scale=1.0)
     det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
     one = synth.synth_images(1, 768, 768, seed=317)
     with torch.no_grad():
         ref = ores.ResDCNOracle(sd, opt.heads)(torch.from_numpy(one))[0]
-        emu = ores.ResDCNOracle(sd, opt.heads, emulate_bf16=True)(torch.from_numpy(one))[0]
+        emu = ores.ResDCNOracle(sd, opt.heads, emulate=dtype)(torch.from_numpy(one))[0]
     xs = torch.from_numpy(one).to(DEV).repeat(32, 1, 1, 1).contiguous()
     res = det.run(xs)
+    if dtype == "f16":
+        from gpu_helpers import kernel_name
+        names = {kernel_name(op) for op in det.model.engine(torch.device(DEV)).plan(32, 768, 768).ops}
+        assert all("f16_t" in n for n in names), sorted(n for n in names if "f16_t" not in n)
     for k in opt.heads:
         v = res["heads"][k]
         assert torch.equal(v, v[:1].expand_as(v)), k
-        _bf16_vs_emulation(v[:1].cpu().numpy(), ref[k].numpy(), emu[k].numpy(), "resdcn %s" % k)
+        _lowp_vs_emulation(v[:1].cpu().numpy(), ref[k].numpy(), emu[k].numpy(), "resdcn %s %s" % (dtype, k))
     assert res["dets"].shape == (32, 100, 6) and torch.equal(res["dets"], res["dets"][:1].expand_as(res["dets"]))
     del det, res
     torch.cuda.empty_cache()

@@ -68,6 +68,46 @@ def test_bf16_mode_within_stated_tolerance(use_dcn):
     print("bf16 max abs head error (dcn=%s): %.4f" % (use_dcn, worst))
 
 
+F16_TOL = 0.012    # abs: 1/8 of bf16's step (3 more mantissa bits per stored activation), same 2x margin (measured worst below)
+
+
+@pytest.mark.parametrize("use_dcn", [False, True])
+def test_f16_mode_within_stated_tolerance(use_dcn):
+    """fp16 plans (H3D_F16: the arithmetic BASELINE configs[4] names; also `dla_net(..., dtype="f16")`): same kernels with
+    v_mfma_f32_32x32x16_f16 and fp16 epilogues.  Heads vs the fp32 oracle, and no worse than 1.5x an independent fp16
+    evaluation of the same graph on the CPU."""
+    m, sd = _net(use_dcn, "f16")
+    xs = synth.synth_images(2, 128, 128, seed=7)
+    out = m(torch.from_numpy(xs).to(DEV))[0]
+    eng = m.engine(torch.device(DEV))
+    from gpu_helpers import kernel_name
+    names = {kernel_name(op) for op in eng.plan(2, 128, 128).ops}
+    assert all("f16_t" in n for n in names), sorted(n for n in names if "f16_t" not in n)     # no bf16 kernel sneaks into an fp16 plan
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, HEADS, use_dcn=use_dcn)(torch.from_numpy(xs))[0]
+        emu = odla.DLAOracle(sd, HEADS, use_dcn=use_dcn, emulate="f16")(torch.from_numpy(xs))[0]
+    worst = 0.0
+    for k in HEADS:
+        e = float(np.abs(out[k].cpu().numpy() - ref[k].numpy()).max())
+        t = float((emu[k] - ref[k]).abs().max())
+        worst = max(worst, e)
+        assert e < F16_TOL and e <= 1.5 * t + 1e-3, (k, e, t)
+    print("f16 max abs head error (dcn=%s): %.5f" % (use_dcn, worst))
+    again = m(torch.from_numpy(xs).to(DEV))[0]
+    for k in HEADS:
+        assert torch.equal(out[k], again[k]), k
+
+
+def test_f16_plan_saturates_instead_of_overflowing():
+    # stored activations of an fp16 plan saturate at +-65504 (v_med3_f32 in the epilogues); an input scaled far beyond
+    # the fp16 range must give finite heads, not inf / nan
+    m, _ = _net(False, "f16")
+    xs = torch.from_numpy(synth.synth_images(1, 64, 64, seed=3) * 3.0e4).to(DEV)
+    out = m(xs)[0]
+    for k in HEADS:
+        assert bool(torch.isfinite(out[k]).all()), k
+
+
 def test_batch_position_invariance_and_determinism():
     m, _ = _net(True, "bf16")
     xs = torch.from_numpy(synth.synth_images(3, 64, 64, seed=3)).to(DEV)
@@ -413,6 +453,35 @@ def test_plan_slots_on_two_streams_give_identical_results():
         assert torch.equal(d, ref["dets"]) and torch.equal(v, ref["verts"]), i
     eng = det.model.engine(torch.device(DEV))
     assert eng.plan(4, 128, 192, 0) is not eng.plan(4, 128, 192, 1)
+
+
+def test_plan_slots_combined_with_sub_batch_streams():
+    # engine.streams > 1 (sub-batches on internal HIP streams) used to ignore `slot`: two batches in flight on
+    # different slots shared one set of sub-plans, output tensors and internal streams (a silent race).  Now every slot
+    # owns its own: interleaving both slots with the split on must reproduce the one-stream, one-slot results bit for bit.
+    opt = Opt(input_h=128, input_w=128, dtype="bf16", K=40, smpl=True, smpl_people=8)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=1.25)
+    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    xa = torch.from_numpy(synth.synth_images(16, 128, 128, seed=1)).to(DEV)
+    xb = torch.from_numpy(synth.synth_images(16, 128, 128, seed=2)).to(DEV)
+    ra = {k: v.clone() for k, v in det.run(xa).items() if k in ("dets", "verts")}
+    rb = {k: v.clone() for k, v in det.run(xb).items() if k in ("dets", "verts")}
+    torch.cuda.synchronize()
+    eng = det.model.engine(torch.device(DEV))
+    eng.streams = 2
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for i in range(6):
+        with torch.cuda.stream(streams[i % 2]):
+            r = det.run(xa if i % 2 == 0 else xb, slot=i % 2)
+            outs.append((r["dets"].clone(), r["verts"].clone()))
+    torch.cuda.synchronize()
+    eng.streams = 1
+    assert ("split", 16, 128, 128, 0) in eng.plans and ("split", 16, 128, 128, 1) in eng.plans
+    assert eng.plans[("split", 16, 128, 128, 0)][1]["hm"].data_ptr() != eng.plans[("split", 16, 128, 128, 1)][1]["hm"].data_ptr()
+    for i, (d, v) in enumerate(outs):
+        ref = ra if i % 2 == 0 else rb
+        assert torch.equal(d, ref["dets"]) and torch.equal(v, ref["verts"]), i
 
 
 def test_flip_test_on_a_mirror_symmetric_input_keeps_symmetry_and_runs_both_passes():

@@ -15,7 +15,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from gpu_helpers import DEV, Built, bf16_round, conv_stream_op, dcn_fused_op, dcn_fused_reference, kernel_name, rnd
+from gpu_helpers import DEV, TN, Built, bf16_round, conv_stream_op, dcn_fused_op, dcn_fused_reference, kernel_name, lowp_round, rnd
 from h3d_amd import _lib
 
 pytestmark = pytest.mark.gpu
@@ -58,19 +58,29 @@ CONV2_CASES = [
 ]
 
 
-def _conv2_built(case):
+def _conv2_built(case, dtype="bf16"):
     ov, B, Ci, Co, H, W, s, relu, use_res, ipad, opad = case
-    x = bf16_round(rnd("x", (B, Ci, H, W)))
-    w = bf16_round(rnd("w", (Co, Ci, 3, 3)) * (1.5 / np.sqrt(Ci * 9)))
+    x = lowp_round(rnd("x", (B, Ci, H, W)), dtype)
+    w = lowp_round(rnd("w", (Co, Ci, 3, 3)) * (1.5 / np.sqrt(Ci * 9)), dtype)
     b = rnd("b", (Co,))
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
-    res = bf16_round(rnd("r", (B, Co, Ho, Wo))) if use_res else None
-    return x, w, b, res, conv_stream_op(x, w, b, s, relu, res, ov, ipad, opad)
+    res = lowp_round(rnd("r", (B, Co, Ho, Wo)), dtype) if use_res else None
+    return x, w, b, res, conv_stream_op(x, w, b, s, relu, res, ov, ipad, opad, dtype=dtype)
 
 
+# fp16 plans (H3D_F16, BASELINE configs[4]) run the same templates with v_mfma_f32_32x32x16_f16 and an fp16 epilogue: the
+# variants a ResNet-101-DCN / DLA-34 fp16 plan selects + one of every structural kind (PIPE, one slot, stride 2, residual,
+# concat buffers)
+CONV2_F16_CASES = [c for c in CONV2_CASES if c[0] in (0, 0x404, 0x6410, 0x6408, 0x6208, 0x5108, 0x4408, 0x204)]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("case", CONV2_CASES, ids=lambda c: "%#x-%dx%d-%dx%d-s%d-b%d" % (c[0], c[2], c[3], c[4], c[5], c[6], c[1]))
-def test_conv_stream_variant_matches_torch(case):
-    x, w, b, res, built = _conv2_built(case)
+def test_conv_stream_variant_matches_torch(case, dtype):
+    if dtype == "f16" and case not in CONV2_F16_CASES:
+        pytest.skip("fp16: a subset of the variants")
+    x, w, b, res, built = _conv2_built(case, dtype)
+    assert built.name.startswith("conv2_kernel<%s, " % TN[dtype]), built.name
     s, relu = case[6], case[7]
     ref = F.conv2d(x.double(), w.double(), b.double(), s, 1)
     if res is not None:
@@ -78,10 +88,10 @@ def test_conv_stream_variant_matches_torch(case):
     if relu:
         ref = F.relu(ref)
     got = built.run()
-    # bf16 operands are exact in the reference, accumulation is fp32: what is left is the final rounding to bf16
+    # bf16 / fp16 operands are exact in the reference, accumulation is fp32: what is left is the final rounding (2^-9 / 2^-12 relative)
     scale = max(1.0, float(ref.abs().max()))
     err = float((got - ref.float()).abs().max())
-    assert err <= 2.0 ** -8 * scale, "%s: max err %.3g (scale %.2f)" % (built.name, err, scale)
+    assert err <= (2.0 ** -8 if dtype == "bf16" else 2.0 ** -11) * scale, "%s: max err %.3g (scale %.2f)" % (built.name, err, scale)
     # the 16 x 32 px x 128 ch workgroups must be deterministic (DMA ring / counted waits)
     again = built.run()
     assert torch.equal(got, again), built.name
@@ -89,7 +99,8 @@ def test_conv_stream_variant_matches_torch(case):
 
 def test_conv_stream_auto_selection_reaches_the_wide_variants():
     names = {_conv2_built(c)[4].name for c in CONV2_CASES if c[0] == 0 and c[6] == 1}
-    assert {"conv2_kernel<4, 16, 2, 1, 2, 1, true>", "conv2_kernel<4, 8, 2, 1, 2, 1, true>", "conv2_kernel<2, 8, 2, 1, 2, 1, true>"} <= names, names
+    assert {"conv2_kernel<unsigned short, 4, 16, 2, 1, 2, 1, true>", "conv2_kernel<unsigned short, 4, 8, 2, 1, 2, 1, true>",
+            "conv2_kernel<unsigned short, 2, 8, 2, 1, 2, 1, true>"} <= names, names
 
 
 # ---- csrc/dcn3.hip, csrc/dcn4.hip ------------------------------------------------------------------------
@@ -130,6 +141,15 @@ DCN_CASES = [
     ("updcn2", "bf16", 0, 1, 64, 32, 10, 18, 3.0),         # dcn4<1,.,1,1>
     # selected the natural way by the workgroup count (>= 192 x 128-channel workgroups / >= 512 tiles)
     ("fused", "bf16", 0, 12, 128, 128, 64, 64, 0.5),       # 192 workgroups -> MT = 4 without an override
+    # fp16 plans (H3D_F16): the apron needs no conversion while it is staged; everything else as in bf16 plans
+    ("stream", "f16", 0, 2, 128, 64, 24, 40, 0.5),         # dcn3<f16,2,16,2,WDMA,256>
+    ("stream", "f16", 0, 2, 64, 64, 40, 24, 6.0),          #   ... patches AND pass 2
+    ("stream", "f16", 0, 1, 64, 32, 20, 20, 12.0),         # dcn3<f16,1,16,2,WDMA,256>
+    ("stream", "f16", 0x400, 1, 256, 256, 24, 24, 8.0),    # dcn3<f16,4,16,4,WDMA,256> (ResNet-101-DCN's first up-sampling stage in miniature)
+    ("stream", "f16", 0, 1, 256, 256, 16, 16, 3.0),        # small grid: 64-channel workgroups
+    ("stream", "f16", 0, 1, 48, 64, 20, 20, 3.0),          # Cin = 16 (mod 32): no patches
+    ("fused", "f16", 0, 1, 64, 32, 20, 36, 3.0),           # register-staged filters: dcn3<f16,1,32,2>
+    ("fused", "f16", 0x400, 1, 128, 128, 24, 40, 0.5),     # dcn3<f16,4,16,2>
 ]
 
 
@@ -142,9 +162,9 @@ def _dcn_built(case):
     wo = rnd("wo", (27, Ci, 3, 3)) * (a * oscale * np.sqrt(3.0))      # offsets ~ N(0, oscale^2)-ish like synth weights
     bo = rnd("bo", (27,), -0.1, 0.1)
     skip = w_up = None
-    if dtype == "bf16":
-        w, wo = w.half().float(), wo.half().float()                       # DCN filters are fp16 in bf16 plans
-        x = bf16_round(x)
+    if dtype in ("bf16", "f16"):
+        w, wo = w.half().float(), wo.half().float()                       # DCN filters are fp16 in bf16 and fp16 plans
+        x = lowp_round(x, dtype)
     if kind.startswith("updcn"):
         f = int(kind[-1])
         skip = bf16_round(rnd("skip", (B, Ci, H * f, W * f)))
@@ -168,7 +188,8 @@ def test_dcn_fused_variant_matches_oracle(case):
     err = float((got - ref).abs().max())
     # f32: exact fmaf chains, offsets from an fp32 conv (sampling positions move by ~1e-6 px).
     # bf16: fp16 blend (2^-11 per sample) + f16 MFMA with fp32 accumulation + one bf16 rounding of the output (2^-9)
-    tol = 2e-4 * scale if dtype == "f32" else 1.2e-2 * scale
+    # fp16: the same blend and MFMA, fp16 rounding of the output (2^-12)
+    tol = 2e-4 * scale if dtype == "f32" else (1.2e-2 if dtype == "bf16" else 4e-3) * scale
     frac_far = float((om[:, :18].abs() > 1.0).float().mean())
     assert err <= tol, "%s: max err %.3g > %.3g (scale %.2f, |offset|>1 for %.0f%%)" % (built.name, err, tol, scale, 100 * frac_far)
     assert torch.equal(got, built.run()), built.name
