@@ -68,7 +68,7 @@ def op_flops(op):
 def op_bytes(op):
     """Algorithmic HBM bytes of one plan op: every operand read once, every result written once (weights excluded: they
     stay in L2 / the Infinity Cache across the batch)."""
-    es = 2 if op.dtype == _lib.H3D_BF16 else 4
+    es = 4 if op.dtype == _lib.H3D_F32 else 2
     pin, pout = op.B * op.H * op.W, op.B * op.Ho * op.Wo
     if op.kind in (_lib.OP_STEM, _lib.OP_STEM3, _lib.OP_IM2COL):
         return 4.0 * pin * op.Cin + es * pout * op.Cout
@@ -641,7 +641,7 @@ def main():
                                    "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)}      # algorithmic HBM bytes / time
                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             print("[bench] kernels %s" % json.dumps(line["kernels"]), file=sys.stderr, flush=True)
-            if dla and args.dtype != "f32":
+            if dla and args.dtype == "bf16":       # (the unfused twin plan it needs exists for bf16 / f32 only)
                 line["dcn_apron"] = dcn_apron_stats(det, images[:2].contiguous(), dev)
             if world == 1 and dla:
                 line["boundary_op"] = boundary_op_times(min(batch, 16), dev)

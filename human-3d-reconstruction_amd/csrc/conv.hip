@@ -671,7 +671,10 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
     } else {
         if (op.Ho != op.H || op.Wo != op.W) H3D_FAIL(H3D_ERR_SHAPE, "copy: shape");
         const size_t npix = (size_t)op.B * op.H * op.W;
-        if (es == 2)
+        if (f16)
+            hipLaunchKernelGGL(copy_kernel<f16_t>, grid, blk, 0, st, (const f16_t *)op.in, (f16_t *)op.out, npix, op.Cin,
+                               op.in_cs, op.out_cs);
+        else if (es == 2)
             hipLaunchKernelGGL(copy_kernel<bf16_t>, grid, blk, 0, st, (const bf16_t *)op.in, (bf16_t *)op.out, npix, op.Cin,
                                op.in_cs, op.out_cs);
         else

@@ -811,6 +811,8 @@ static int launch_dcn3_lowp(const h3d_op &op, const Dcn3Args &a, bool wdma, hipS
     return launch_dcn3_cfg<T, 4, 16, 2>(a, st);
 }
 
+int h3d_launch_dcn5(const h3d_op &op, hipStream_t st);      // csrc/dcn5.hip: fp16 plans, every operand by LDS-DMA
+
 int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
 {
     const bool wdma = op.kind == H3D_OP_DCN_FUSED_STREAM;
@@ -836,6 +838,9 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.G = op.wrows / 32;
     if (wdma && (size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
     if (op.dtype == H3D_BF16) return launch_dcn3_lowp<bf16_t>(op, a, wdma, st);
+    // fp16 plans: the apron needs no conversion, so it arrives by LDS-DMA like the filters (csrc/dcn5.hip); tuning overrides
+    // 0x1000 (no patch slots) and 0x2000 keep this file's register-staged apron (A/B, tests)
+    if (op.dtype == H3D_F16 && wdma && !(op.reserved & 0x3000)) return h3d_launch_dcn5(op, st);
     if (op.dtype == H3D_F16) return launch_dcn3_lowp<f16_t>(op, a, wdma, st);
     if (op.dtype == H3D_F32) {
         if (op.Cout <= 32) return launch_dcn3_cfg<float, 1, 16, 2>(a, st);

@@ -236,9 +236,12 @@ int h3d_launch_extra(const h3d_op &op, hipStream_t st)
     if (op.kind == H3D_OP_DEPTH2SPACE) {
         if (op.Cin != 4 * op.Cout || op.Cout % n || op.Ho != 2 * op.H || op.Wo != 2 * op.W)
             H3D_FAIL(H3D_ERR_SHAPE, "depth2space: [B,H,W,4C] -> [B,2H,2W,C] expected (Cin=%d Cout=%d)", op.Cin, op.Cout);
-        if (h3d_note_kernel("depth2space_kernel<%s>", es == 2 ? "unsigned short" : "float")) return H3D_OK;
+        if (h3d_note_kernel("depth2space_kernel<%s>", f16 ? "f16_t" : es == 2 ? "unsigned short" : "float")) return H3D_OK;
         const size_t total = (size_t)op.B * op.Ho * op.Wo * (op.Cout / n);
-        if (es == 2)
+        if (f16)
+            hipLaunchKernelGGL(depth2space_kernel<f16_t>, dim3(ex_grid(total)), blk, 0, st, (const f16_t *)op.in, (f16_t *)op.out, op.B, op.H,
+                               op.W, op.Cout, op.in_cs, op.out_cs);
+        else if (es == 2)
             hipLaunchKernelGGL(depth2space_kernel<bf16_t>, dim3(ex_grid(total)), blk, 0, st, (const bf16_t *)op.in, (bf16_t *)op.out, op.B, op.H,
                                op.W, op.Cout, op.in_cs, op.out_cs);
         else

@@ -142,12 +142,19 @@ DCN_CASES = [
     # selected the natural way by the workgroup count (>= 192 x 128-channel workgroups / >= 512 tiles)
     ("fused", "bf16", 0, 12, 128, 128, 64, 64, 0.5),       # 192 workgroups -> MT = 4 without an override
     # fp16 plans (H3D_F16): the apron needs no conversion while it is staged; everything else as in bf16 plans
-    ("stream", "f16", 0, 2, 128, 64, 24, 40, 0.5),         # dcn3<f16,2,16,2,WDMA,256>
+    ("stream", "f16", 0, 2, 128, 64, 24, 40, 0.5),         # dcn5<2,2,.,256>: apron AND filters by LDS-DMA (csrc/dcn5.hip)
+    ("stream", "f16", 0, 1, 256, 64, 16, 32, 3.0),
     ("stream", "f16", 0, 2, 64, 64, 40, 24, 6.0),          #   ... patches AND pass 2
-    ("stream", "f16", 0, 1, 64, 32, 20, 20, 12.0),         # dcn3<f16,1,16,2,WDMA,256>
-    ("stream", "f16", 0x400, 1, 256, 256, 24, 24, 8.0),    # dcn3<f16,4,16,4,WDMA,256> (ResNet-101-DCN's first up-sampling stage in miniature)
+    ("stream", "f16", 0, 1, 64, 32, 20, 20, 12.0),         # dcn5<1,2,.,256>
+    ("stream", "f16", 0x400, 1, 128, 128, 16, 32, 3.0),    # dcn5<4,4,.,256>: margin-4 apron
+    ("stream", "f16", 0x400, 1, 256, 256, 24, 24, 8.0),    #   (ResNet-101-DCN's first up-sampling stage in miniature)
     ("stream", "f16", 0, 1, 256, 256, 16, 16, 3.0),        # small grid: 64-channel workgroups
-    ("stream", "f16", 0, 1, 48, 64, 20, 20, 3.0),          # Cin = 16 (mod 32): no patches
+    ("stream", "f16", 0, 1, 48, 64, 20, 20, 3.0),          # Cin = 16 (mod 32): three stages (csrc/dcn5.hip has no two-stage unrolling)
+    ("stream", "f16", 0, 1, 64, 64, 16, 16, 40.0),         #   ... nearly every sample outside the apron or the image
+    ("stream", "f16", 0, 12, 128, 128, 64, 64, 0.5),       # >= 192 workgroups: dcn5<4,4> without an override
+    ("stream", "f16", 0x2000, 2, 128, 64, 24, 40, 0.5),    # 0x2000: csrc/dcn3.hip's register-staged apron on an fp16 input (dcn3<f16,2,16,2,WDMA,256>)
+    ("stream", "f16", 0x2400, 1, 256, 256, 24, 24, 8.0),   #   ... dcn3<f16,4,16,4,WDMA,256>
+    ("stream", "f16", 0x1000, 1, 64, 32, 20, 20, 12.0),    # 0x1000: no patch slots, dcn3<f16,1,16,1,WDMA,0>
     ("fused", "f16", 0, 1, 64, 32, 20, 36, 3.0),           # register-staged filters: dcn3<f16,1,32,2>
     ("fused", "f16", 0x400, 1, 128, 128, 24, 40, 0.5),     # dcn3<f16,4,16,2>
 ]
@@ -193,6 +200,13 @@ def test_dcn_fused_variant_matches_oracle(case):
     frac_far = float((om[:, :18].abs() > 1.0).float().mean())
     assert err <= tol, "%s: max err %.3g > %.3g (scale %.2f, |offset|>1 for %.0f%%)" % (built.name, err, tol, scale, 100 * frac_far)
     assert torch.equal(got, built.run()), built.name
+
+
+def test_dcn_f16_stream_dispatches_to_the_dma_apron_kernel():
+    names = {c: _dcn_built(c)[5].name for c in DCN_CASES if c[0] == "stream" and c[1] == "f16"}
+    for c, n in names.items():
+        assert n.startswith("dcn3_kernel<f16_t" if c[2] & 0x3000 else "dcn5_kernel<"), (c, n)
+    assert {"dcn5_kernel<2, 2, 2, 256>", "dcn5_kernel<1, 2, 1, 256>", "dcn5_kernel<4, 4, 2, 256>"} <= set(names.values()), names
 
 
 def test_dcn_auto_selection_reaches_mt4():
