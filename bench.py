@@ -356,7 +356,7 @@ def workload_name(arch_name, size, batch, strong, n_global):
     return "ResNet-101-DCN ctdet -> decode; %dx%d, %s (BASELINE configs[4]: 256 over 8 GPUs = 32)" % (size, size, split)
 
 
-def make_step(det, images, nslot, world, n_global, dev):
+def make_step(det, images, nslot, world, n_global, dev, graph=False):
     """-> (step(), per-image dets shape).  step() issues one batch: consecutive calls alternate between `nslot` HIP streams, each
     with its own copy of the plan's buffers; for world > 1 the single collective (all-gather of dets) follows on the
     default stream, in step order."""
@@ -367,11 +367,12 @@ def make_step(det, images, nslot, world, n_global, dev):
     def step():
         k = counter[0] % nslot
         counter[0] += 1
+        kw = {"graph": True} if graph else {}
         if slot_streams[k] is None:
-            res = det.run(images, slot=0)
+            res = det.run(images, slot=0, **kw)
             return gather_detections(res["dets"], n_images=n_global) if world > 1 else res["dets"]
         with torch.cuda.stream(slot_streams[k]):
-            res = det.run(images, slot=k)
+            res = det.run(images, slot=k, **kw)
             if world == 1:
                 return res["dets"]
             done = torch.cuda.Event()
@@ -385,18 +386,20 @@ def make_step(det, images, nslot, world, n_global, dev):
     return step, dets_shape
 
 
-def time_steps(step, steps, warmup):
+def time_steps(step, steps, warmup, issued=None):
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if issued is not None:
+        issued.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
 
-def shard_sweep(det, images, nslot, dev, batches, steps=10):
+def shard_sweep(det, images, nslot, dev, batches, steps=30):
     """images/s of the SAME detector on the first B images of the batch, for the shard sizes a strong-scaling run of the
     headline batch would hand one GPU (64 over 8 / 4 / 2 GPUs).  Same step as the timed region (network + decode + SMPL,
     `nslot` steps in flight); measured after it, on one GPU."""
@@ -405,9 +408,11 @@ def shard_sweep(det, images, nslot, dev, batches, steps=10):
         if b >= images.shape[0]:
             continue
         sub = images[:b].contiguous()
-        step, _ = make_step(det, sub, nslot, 1, b, dev)
-        dt = time_steps(step, steps, 3)
-        out[str(b)] = {"images_per_s": round(b * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3)}
+        step, _ = make_step(det, sub, max(nslot, 3 if b <= 16 else nslot), 1, b, dev)      # small shards: three steps in flight
+        issued = []
+        dt = time_steps(step, steps, 3, issued)
+        out[str(b)] = {"images_per_s": round(b * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
+                       "host_issue_ms_per_step": round(1e3 * issued[0] / steps, 3), "steps_in_flight": max(nslot, 3 if b <= 16 else nslot)}
     return out
 
 
@@ -475,6 +480,10 @@ def main():
                     help="> 0: STRONG scaling -- one batch of this many images per step for the whole job, rank r takes the "
                          "contiguous slice detector.shard_batch(G, r, world) (the reference's DataParallel scatter of ONE batch, "
                          "trains/trainer.py:176; SURVEY 8e: batch 64 -> 8 per GPU on 8 GPUs); the line then says \"scaling\": \"strong\"")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: replay every step as one hipGraph (detector.run(graph=True)); 0 (default): issue every launch from Python. "
+                         "Measured: no gain -- batch 8, 1 / 2 / 3 steps in flight: 3792 / 5526 / 6373 images/s with graphs, 3760 / 5512 / "
+                         "6320 without; batch 64: 8180 vs 8320 (the host issues a step faster than the GPU runs it, even at 8 images)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the records measured after the timed region (shard_sweep, parity_mode, other_archs)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
@@ -543,7 +552,8 @@ def main():
     nslot = max(1, args.pipeline if args.pipeline is not None else (3 if args.arch == "hourglass" else 2))
     if args.streams > 1:
         nslot = 1              # sub-batch streams and plan slots are two uses of the same idea; not combined in the bench
-    step, dets_shape = make_step(det, images, nslot, world, n_global, dev)
+    use_graph = dla and args.graph == 1 and args.streams <= 1
+    step, dets_shape = make_step(det, images, nslot, world, n_global, dev, graph=use_graph)
 
     # one-time setup outside both warm-up and the timed region: weight packing + plan lowering (host work and uploads,
     # no network launches) and the SMPL model upload.  The first launch of every kernel still pays its code-object
@@ -570,6 +580,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    t_issued = time.perf_counter() - t0        # host time to ISSUE the K steps (launch-bound when it approaches dt)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -591,14 +602,15 @@ def main():
             "value": round(n_global * args.steps / dt, 2), "unit": "images/s",
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "host_issue_ms_per_step": round(1e3 * t_issued / args.steps, 3),
+            "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_name(args.arch, size, batch, strong, n_global),
                        "batch_per_gpu": batch, "global_batch": n_global, "K": 100,
                        "smpl_people_per_image": args.people if dla else 0, "conv_gflop_per_image": round(gflop_img, 2),
                        "parallelism": "dp%d (image shards, one all-gather of dets)" % world,
-                       "steps_in_flight": nslot,
+                       "steps_in_flight": nslot, "hip_graph": bool(use_graph),
                        "images": "%d distinct synthetic images (h3d_amd.synth.synth_image_batch, seed 317)" % n_global,
                        "weights": "synthetic (h3d_amd.synth, seed 0, gain %s, offset_scale %g)"
                                   % ("%g" % args.weight_gain if dla else "per arch", args.offset_scale)},

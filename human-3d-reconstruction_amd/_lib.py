@@ -56,6 +56,7 @@ SIGNATURES = {
     "h3d_dcn_fused_ck": [c_i, c_i],
     "h3d_smpl_coef_pack": [c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "h3d_smpl_verts3": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],
+    "h3d_smpl_verts3_exact": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],
     "h3d_preprocess": [c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "h3d_run_ops": [ctypes.POINTER(H3dOp), c_i, c_vp],
     "h3d_run_ops_timed": [ctypes.POINTER(H3dOp), c_i, c_vp, c_vp],

@@ -838,9 +838,11 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.G = op.wrows / 32;
     if (wdma && (size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
     if (op.dtype == H3D_BF16) return launch_dcn3_lowp<bf16_t>(op, a, wdma, st);
-    // fp16 plans: the apron needs no conversion, so it arrives by LDS-DMA like the filters (csrc/dcn5.hip); tuning overrides
-    // 0x1000 (no patch slots) and 0x2000 keep this file's register-staged apron (A/B, tests)
-    if (op.dtype == H3D_F16 && wdma && !(op.reserved & 0x3000)) return h3d_launch_dcn5(op, st);
+    // fp16 plans: the apron needs no conversion while it is staged.  csrc/dcn5.hip also moves it by LDS-DMA (double buffered, one
+    // barrier per phase-A stage): measured 5.7 % SLOWER on the ten <= 64-channel launches of the batch-64 plan (1.519 vs 1.437 ms,
+    // tools/ab_dcn5.py: an LDS-DMA piece costs its wave more issue cycles than two global loads + two ds_write_b128, and the
+    // kernel is bound by LDS reads and vector issue, not by the staging), so it runs only on request (tuning override 0x4000)
+    if (op.dtype == H3D_F16 && wdma && (op.reserved & 0x4000) && !(op.reserved & 0x3000)) return h3d_launch_dcn5(op, st);
     if (op.dtype == H3D_F16) return launch_dcn3_lowp<f16_t>(op, a, wdma, st);
     if (op.dtype == H3D_F32) {
         if (op.Cout <= 32) return launch_dcn3_cfg<float, 1, 16, 2>(a, st);

@@ -94,7 +94,9 @@ __device__ __forceinline__ u32x4 dcn5_corner(const char *img, int bytes, int vof
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
 
-template <int MT, int MARGIN, int EPI, int NP>      // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed
+// XP: experiment bits (h3d_op.reserved >> 16; tools/ab_dcn5.py).  1: next stage's DMA issued after the second barrier; 2 / 4 / 8
+// (timing only, wrong results): no patch pixels / no apron DMA after stage 0 / no filter DMA after stage 0; 16: tap-ahead gathers
+template <int MT, int MARGIN, int EPI, int NP, int XP = 0>      // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed
 __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
 {
     using C = Dcn5Cfg<MT, MARGIN, NP>;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
 #ifndef DCN5_TAPAHEAD
 #define DCN5_TAPAHEAD 4      // tap-ahead gathers from this many 32-channel output tiles per workgroup
 #endif
-    constexpr bool TAPAHEAD = MT >= DCN5_TAPAHEAD;
+    constexpr bool TAPAHEAD = MT >= DCN5_TAPAHEAD || (XP & 16);
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
     int *s_cnt = reinterpret_cast<int *>(smem + C::LDS - 16);
 
@@ -142,8 +144,9 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
     // stage s: apron chunk s % nchunks -> A[s & 1]; filters (offset conv for s < nchunks, else main) -> F[s & 1]
     auto issue = [&](int s) {
         const int c = s < nchunks ? s : s - nchunks;
-        dcn5_issue_a<C::APIECES>(img, img_bytes, smem + C::OFF_A + (s & 1) * C::ASLOT, avoff, c * CK * ES, wvu);
+        if (!((XP & 4) && s > 0)) dcn5_issue_a<C::APIECES>(img, img_bytes, smem + C::OFF_A + (s & 1) * C::ASLOT, avoff, c * CK * ES, wvu);
         char *dst = smem + C::OFF_F + (s & 1) * C::WSLOT;
+        if ((XP & 8) && s > 0) return;
         if (s < nchunks) dcn5_issue_w<C::OPIECES>(a.woff, off_bytes, dst, s * C::WGRP, l * 16, wvu);
         else dcn5_issue_w<C::WPIECES>(a.w, main_bytes, dst, (c * a.G + (int)blockIdx.y * MT) * C::WGRP, l * 16, wvu);
     };
@@ -373,14 +376,15 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
         }
     };
     for (int s = nchunks; s < 2 * nchunks; ++s) {
-        if (NP > 0 && anyp) {                     // workgroup-uniform
+        if (NP > 0 && anyp && !(XP & 2)) {        // workgroup-uniform
             patch_issue(s);
             __builtin_amdgcn_s_waitcnt(0x0f70 | 4);      // vmcnt(4): my DMA pieces of stage s (older than the four corner loads) have landed
             h3d_barrier_keep_vmcnt();             // everyone's have; stage s - 1 is no longer read (its slots and the patch area are free)
             __builtin_amdgcn_s_waitcnt(0x0f70);   // the corners (requested before the barrier wait) have arrived
             patch_commit();
-            if (s + 1 < 2 * nchunks) issue(s + 1);
+            if (!(XP & 1) && s + 1 < 2 * nchunks) issue(s + 1);
             h3d_barrier_keep_vmcnt();             // the patch pixels are visible (lgkmcnt(0) inside; the DMA stays in flight)
+            if ((XP & 1) && s + 1 < 2 * nchunks) issue(s + 1);
         } else {
             __builtin_amdgcn_s_waitcnt(0x0f70);
             h3d_barrier_keep_vmcnt();
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
     }
 }
 
-template <int MT, int MARGIN, int NP>
+template <int MT, int MARGIN, int NP, int XP = 0>
 static int launch_dcn5_cfg(const Dcn5Args &a0, hipStream_t st)
 {
     using C = Dcn5Cfg<MT, MARGIN, NP>;
@@ -512,14 +516,15 @@ static int launch_dcn5_cfg(const Dcn5Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, 32 * MT));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("dcn5_kernel<%d, %d, %d, %d>", MT, MARGIN, epi, NP)) return H3D_OK;
+    if (h3d_note_kernel(XP ? "dcn5_kernel<%d, %d, %d, %d, %d>" : "dcn5_kernel<%d, %d, %d, %d>", MT, MARGIN, epi, NP, XP)) return H3D_OK;
     if constexpr (MT >= 2) {
         if (epi == 2) {
-            hipLaunchKernelGGL((dcn5_kernel<MT, MARGIN, 2, NP>), grid, dim3(C::THREADS), 0, st, a);
+            hipLaunchKernelGGL((dcn5_kernel<MT, MARGIN, 2, NP, XP>), grid, dim3(C::THREADS), 0, st, a);
             H3D_CHECK_LAUNCH("dcn5_kernel");
             return H3D_OK;
         }
     }
+    if constexpr (XP != 0) H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn5: experiment variants exist for the LDS-transposed epilogue only");
     if (epi == 1) hipLaunchKernelGGL((dcn5_kernel<MT, MARGIN, 1, NP>), grid, dim3(C::THREADS), 0, st, a);
     else hipLaunchKernelGGL((dcn5_kernel<MT, MARGIN, 0, NP>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("dcn5_kernel");
@@ -536,6 +541,20 @@ int h3d_launch_dcn5(const h3d_op &op, hipStream_t st)
     a.tiles_x = a.tiles_y = 0;
     a.dbg = op.reserved;
     a.G = op.wrows / 32;
+    const int xp = (op.reserved >> 16) & 0xff;
+    if (xp && op.Cout > 32 && op.Cout <= 64) {
+        switch (xp) {
+        case 1: return launch_dcn5_cfg<2, 2, 256, 1>(a, st);
+        case 2: return launch_dcn5_cfg<2, 2, 256, 2>(a, st);
+        case 3: return launch_dcn5_cfg<2, 2, 256, 3>(a, st);
+        case 4: return launch_dcn5_cfg<2, 2, 256, 4>(a, st);
+        case 8: return launch_dcn5_cfg<2, 2, 256, 8>(a, st);
+        case 12: return launch_dcn5_cfg<2, 2, 256, 12>(a, st);
+        case 14: return launch_dcn5_cfg<2, 2, 256, 14>(a, st);
+        case 17: return launch_dcn5_cfg<2, 2, 256, 17>(a, st);
+        default: H3D_FAIL(H3D_ERR_ARG, "dcn5: unknown experiment %d", xp);
+        }
+    }
     if (op.Cout <= 32) return launch_dcn5_cfg<1, 2, 256>(a, st);
     if (op.Cout <= 64) return launch_dcn5_cfg<2, 2, 256>(a, st);
     // a layer whose 128-channel workgroups would leave CUs idle runs 64-channel workgroups instead (as csrc/dcn3.hip)

@@ -439,11 +439,9 @@ constexpr int S3_KP = 224, S3_NST = S3_KP / 16, S3_VT = 64, S3_NW = 8, S3_PB = 3
 constexpr int S3_PPAD = 128;                                  // the hosts pad the person count to this
 constexpr int S3_SPR = 7;                                     // 16-byte slots per row and stage: 6 data + 1 pad
 constexpr int S3_ROWB = S3_SPR * 16;                          // 112
-#ifdef H3D_SMPL_6
-constexpr int S3_DSLOTS = 6;                                  // slots of a row the DMA fetches: h, m, l
-#else
-constexpr int S3_DSLOTS = 4;                                  // h and m only: the lanes of the l slots carry an out-of-range offset (zeros, no traffic)
-#endif
+// slots of a row the DMA fetches: all six (h, m, l: SIX = true) or h and m only -- the lanes of the l slots then carry an out-of-range
+// offset (zeros, no traffic)
+template <bool SIX> constexpr int s3_dslots() { return SIX ? 6 : 4; }
 constexpr int S3_GROW = S3_NST * 96;                          // bytes of a row in global memory: 1344
 constexpr int S3_APIECES = 3 * S3_VT * S3_SPR / 64;           // 21 KiB pieces of direction rows
 constexpr int S3_BPIECES = S3_PB * S3_SPR / 64;               // 28 of coefficient rows
@@ -481,6 +479,7 @@ __device__ __forceinline__ void s3_issue(const char *dirsK, int dbytes, const ch
     for (int j = 0; j < S3_AJ + S3_BJ; ++j) s3_issue_piece(dirsK, dbytes, coefK, cbytes, slot, aoff, boff, wv, st, j);
 }
 
+template <bool SIX>      // SIX: all six products of the three-term split (2^-24 relative: the f32-mode detectors), else hh + hm + mh (2^-16)
 __global__ __launch_bounds__(64 * S3_NW) void smpl_verts3_kernel(const bf16_t *__restrict__ coefK3, const float *__restrict__ A,
                                                           const float *__restrict__ v_template,
                                                           const bf16_t *__restrict__ dirsK3, const int32_t *__restrict__ lbs_idx,
@@ -488,6 +487,7 @@ __global__ __launch_bounds__(64 * S3_NW) void smpl_verts3_kernel(const bf16_t *_
                                                           int Vpad, float *__restrict__ verts)
 {
     using E = ET<bf16_t>;
+    constexpr int S3_DSLOTS = s3_dslots<SIX>();
     __shared__ __attribute__((aligned(1024))) char smem[S3_LDS];
     const int tid = threadIdx.x, l = tid & 63, r = l & 31, h = l >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,12 +563,9 @@ __global__ __launch_bounds__(64 * S3_NW) void smpl_verts3_kernel(const bf16_t *_
             if (st + 1 < S3_NST && MODE != 3)
                 s3_issue((const char *)dirsK3, dbytes, (const char *)coefK3, cbytes, smem + ((st + 1) & 1) * S3_SLOT, aoff, boff, wv, st + 1);
             const char *sl = smem + (st & 1) * S3_SLOT;
-#ifdef H3D_SMPL_6
-            constexpr bool SIX = true;      // all six products down to 2^-24 relative (round 1)
-#else
-            constexpr bool SIX = false;     // hh + hm + mh: the three dropped products (mm, hl, lh) are 2^-16 relative each --
-#endif                                      // 2.2e-6 abs on the blend-shape displacement (fp64 emulation, |d| <= 0.34), 45x inside the
-                                            // 1e-4 tolerance -- for half the MFMAs and two thirds of the fragment reads
+            // SIX: all six products down to 2^-24 relative.  Otherwise hh + hm + mh: the three dropped products (mm, hl, lh) are
+            // 2^-16 relative each -- 2.2e-6 abs on the blend-shape displacement (fp64 emulation, |d| <= 0.34), 45x inside the
+            // 1e-4 tolerance -- for half the MFMAs and two thirds of the fragment reads
             const E::frag bh = E::lds_frag(sl + fb_off), bm = E::lds_frag(sl + fb_off + 32);
             E::frag bl = bh;
             if constexpr (SIX) bl = E::lds_frag(sl + fb_off + 64);
@@ -717,9 +714,9 @@ extern "C" int h3d_smpl_coef_pack(const float *betas, const float *pose_feat, in
     return H3D_OK;
 }
 
-extern "C" int h3d_smpl_verts3(const void *coefK3, const float *A, const float *v_template, const void *dirsK3,
-                               const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad,
-                               float *verts, void *stream)
+static int smpl_verts3_impl(bool six, const void *coefK3, const float *A, const float *v_template, const void *dirsK3,
+                            const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad,
+                            float *verts, void *stream)
 {
     if (!coefK3 || !A || !v_template || !dirsK3 || !lbs_idx || !lbs_w || !verts) H3D_FAIL(H3D_ERR_ARG, "smpl_verts3: null pointer");
 #ifdef H3D_ABLATE
@@ -734,8 +731,26 @@ extern "C" int h3d_smpl_verts3(const void *coefK3, const float *A, const float *
     if ((size_t)3 * Vpad * S3_GROW >= 0x7ffffff0ull || (size_t)Ppad * S3_GROW >= 0x7ffffff0ull)
         H3D_FAIL(H3D_ERR_SHAPE, "smpl_verts3: operand of 2 GiB or more");
     dim3 grid(Vpad / S3_VT, cdiv(Ppad, S3_PB));      // (coefficient rows past Ppad are outside the buffer: zeros)
-    hipLaunchKernelGGL(smpl_verts3_kernel, grid, dim3(64 * S3_NW), 0, (hipStream_t)stream, (const bf16_t *)coefK3, A, v_template,
-                       (const bf16_t *)dirsK3, lbs_idx, lbs_w, nnz | nnz_flags, P, Ppad, V, Vpad, verts);
+    if (six)
+        hipLaunchKernelGGL(smpl_verts3_kernel<true>, grid, dim3(64 * S3_NW), 0, (hipStream_t)stream, (const bf16_t *)coefK3, A, v_template,
+                           (const bf16_t *)dirsK3, lbs_idx, lbs_w, nnz | nnz_flags, P, Ppad, V, Vpad, verts);
+    else
+        hipLaunchKernelGGL(smpl_verts3_kernel<false>, grid, dim3(64 * S3_NW), 0, (hipStream_t)stream, (const bf16_t *)coefK3, A, v_template,
+                           (const bf16_t *)dirsK3, lbs_idx, lbs_w, nnz | nnz_flags, P, Ppad, V, Vpad, verts);
     H3D_CHECK_LAUNCH("smpl_verts3_kernel");
     return H3D_OK;
+}
+
+extern "C" int h3d_smpl_verts3(const void *coefK3, const float *A, const float *v_template, const void *dirsK3,
+                               const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad,
+                               float *verts, void *stream)
+{
+    return smpl_verts3_impl(false, coefK3, A, v_template, dirsK3, lbs_idx, lbs_w, nnz, P, Ppad, V, Vpad, verts, stream);
+}
+
+extern "C" int h3d_smpl_verts3_exact(const void *coefK3, const float *A, const float *v_template, const void *dirsK3,
+                                     const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad,
+                                     float *verts, void *stream)
+{
+    return smpl_verts3_impl(true, coefK3, A, v_template, dirsK3, lbs_idx, lbs_w, nnz, P, Ppad, V, Vpad, verts, stream);
 }

@@ -80,10 +80,16 @@ class MultiPoseDetector:
             self.smpl_model = _smpl.SMPLModel.synthetic()
 
     @torch.no_grad()
-    def run(self, images, meta=None, slot=0):
+    def run(self, images, meta=None, slot=0, graph=False):
         """images [B,3,H,W] fp32 on the device -> dict(dets [B,K,40], inds [B,K], optional
         verts [B,N,6890,3] / joints, optional results [B,K,39] in image px when meta={'c','s'}).
-        slot: plan-buffer copy (model.forward); consecutive batches issued on different HIP streams alternate slots."""
+        slot: plan-buffer copy (model.forward); consecutive batches issued on different HIP streams alternate slots.
+        graph: replay the whole step (network, decode, SMPL: ~75 launches and ~30 host-side allocations) as ONE hipGraph
+        captured at the first call of this (shape, slot) -- for small per-GPU shards, where issuing the launches from
+        Python takes longer than the GPU needs to run them.  Same kernels, same work; the returned tensors are the
+        graph's static outputs (overwritten by the next replay of the same slot: clone to keep)."""
+        if graph and meta is None:
+            return self._run_graph(images, slot)
         opt = self.opt
         if opt.flip_test:
             out = self._flip_test_heads(images, slot)
@@ -100,13 +106,42 @@ class MultiPoseDetector:
             B = inds.shape[0]
             thetas = _transpose_and_gather_feat(out["pose"], inds).view(B * n, 72)
             betas = _transpose_and_gather_feat(out["shape"], inds).view(B * n, 10)
-            verts, joints = _smpl.lbs(self.smpl_model, betas, thetas, return_joints=True)
+            # f32 (parity-mode) detectors keep all six products of the blend-shape split (fp32-level accuracy end to end)
+            verts, joints = _smpl.lbs(self.smpl_model, betas, thetas, return_joints=True,
+                                      kernel="auto_exact" if opt.dtype == "f32" else "auto")
             res["verts"] = verts.view(B, n, -1, 3)
             res["joints"] = joints.view(B, n, 24, 3)
         if meta is not None:
             res["results"] = multi_pose_post_process(dets, meta["c"], meta["s"], out["hm"].shape[2],
                                                      out["hm"].shape[3])
         return res
+
+
+def _run_graph(self, images, slot):
+    """hipGraph capture / replay of `run` (torch.cuda.CUDAGraph; the C ABI launches on torch's current stream, which is the
+    capture stream inside the context).  One graph per (shape, slot); the input lives in a static buffer the caller's
+    batch is copied into unless it already IS that buffer's address."""
+    _lib.require_cuda(images)
+    if not hasattr(self, "_graphs"):
+        self._graphs = {}
+    key = (tuple(images.shape), slot)
+    ent = self._graphs.get(key)
+    if ent is None:
+        static_in = images.detach().clone().float().contiguous()
+        self.run(static_in, slot=slot)                       # eager warm-up: plans, code objects, SMPL model upload
+        torch.cuda.current_stream().synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            res = self.run(static_in, slot=slot)
+        ent = self._graphs[key] = (g, static_in, res)
+    g, static_in, res = ent
+    if images.data_ptr() != static_in.data_ptr():
+        static_in.copy_(images)
+    g.replay()
+    return res
+
+
+MultiPoseDetector._run_graph = _run_graph
 
 
 class CtdetDetector:

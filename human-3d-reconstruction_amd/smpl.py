@@ -124,8 +124,9 @@ def _dirs_k3(model, Vpad, device, KP=224):
 
 def lbs(model, betas, thetas, return_joints=False, kernel="auto"):
     """betas [P,10], thetas [P,72] (CUDA fp32) -> vertices [P,V,3] (and posed joints [P,24,3]).
-    kernel: "gen3" = blend shapes on the matrix cores (3-term bf16 split, fp32-level accuracy), "gen2" = LDS-streamed vector kernel (both need
-    <= 4 skinning weights per vertex), "gen1" = register kernel, "auto" = gen3 when applicable and P >= 64."""
+    kernel: "gen3" = blend shapes on the matrix cores (3-term bf16 split; the three 2^-16 products dropped: 2e-6 abs on the displacement),
+    "gen3x" = the same with all six products (2^-24: what the f32 parity-mode detectors run), "gen2" = LDS-streamed vector kernel (all
+    need <= 4 skinning weights per vertex), "gen1" = register kernel, "auto" = gen3 when applicable and P >= 64, "auto_exact" = gen3x."""
     import torch
     from . import _lib
     _lib.require_cuda(betas, thetas)
@@ -141,7 +142,8 @@ def lbs(model, betas, thetas, return_joints=False, kernel="auto"):
     joints = torch.empty(P, NUM_JOINTS, 3, dtype=torch.float32, device=dev)
     verts = torch.empty(P, d["V"], 3, dtype=torch.float32, device=dev)
     L, st = _lib.lib(), _lib.stream_ptr()
-    gen3 = kernel == "gen3" or (kernel == "auto" and d["nnz"] <= 4 and P >= 64)
+    gen3 = kernel in ("gen3", "gen3x") or (kernel in ("auto", "auto_exact") and d["nnz"] <= 4 and P >= 64)
+    exact = kernel in ("gen3x", "auto_exact")
     gen2 = kernel == "gen2"
     Ppad = ((P + 127) // 128) * 128
     coefT = torch.zeros(NUM_BETAS + NUM_POSE_FEAT, Ppad, dtype=torch.float32, device=dev) if gen2 else None
@@ -152,9 +154,10 @@ def lbs(model, betas, thetas, return_joints=False, kernel="auto"):
         if gen3:
             coefK = torch.empty(Ppad, 14, 3, 16, dtype=torch.bfloat16, device=dev)
             _lib.check(L.h3d_smpl_coef_pack(_lib.ptr(betas), _lib.ptr(pf), P, Ppad, _lib.ptr(coefK), st), "smpl_coef_pack")
-            _lib.check(L.h3d_smpl_verts3(_lib.ptr(coefK), _lib.ptr(A), _lib.ptr(d["v_template"]), _lib.ptr(d["dirsK3"]),
-                                         _lib.ptr(d["lbs_idx"]), _lib.ptr(d["lbs_w"]), d["nnz"], P, Ppad, d["V"], d["Vpad"],
-                                         _lib.ptr(verts), st), "smpl_verts3")
+            fn = L.h3d_smpl_verts3_exact if exact else L.h3d_smpl_verts3
+            _lib.check(fn(_lib.ptr(coefK), _lib.ptr(A), _lib.ptr(d["v_template"]), _lib.ptr(d["dirsK3"]),
+                          _lib.ptr(d["lbs_idx"]), _lib.ptr(d["lbs_w"]), d["nnz"], P, Ppad, d["V"], d["Vpad"],
+                          _lib.ptr(verts), st), "smpl_verts3")
         elif gen2:
             _lib.check(L.h3d_smpl_verts2(_lib.ptr(coefT), _lib.ptr(A), _lib.ptr(d["v_template"]),
                                          _lib.ptr(d["shapedirsT"]), _lib.ptr(d["posedirsT"]), _lib.ptr(d["lbs_idx"]),

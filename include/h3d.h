@@ -282,6 +282,12 @@ int h3d_smpl_coef_pack(const float *betas, const float *pose_feat, int P, int Pp
 int h3d_smpl_verts3(const void *coefK3, const float *A, const float *v_template, const void *dirsK3,
                     const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad,
                     float *verts, void *stream);
+/* The same with all six products of the three-term split (h3d_smpl_verts3 keeps hh + hm + mh: 2^-16 relative per dropped
+ * product, 2e-6 abs on the blend-shape displacement): agrees with the fp32 vector kernels to 2e-6 -- what the f32
+ * (parity-mode) detectors run; 1.16x the time. */
+int h3d_smpl_verts3_exact(const void *coefK3, const float *A, const float *v_template, const void *dirsK3,
+                          const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad, int V, int Vpad,
+                          float *verts, void *stream);
 /* blend shapes + LBS: verts [P,V,3].  Model tensors struct-of-arrays with row stride Vpad:
  * v_template [3][Vpad], shapedirsT [10][3][Vpad], posedirsT [207][3][Vpad]. */
 int h3d_smpl_verts(const float *betas, const float *pose_feat, const float *A,

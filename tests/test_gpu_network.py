@@ -82,7 +82,8 @@ def test_f16_mode_within_stated_tolerance(use_dcn):
     eng = m.engine(torch.device(DEV))
     from gpu_helpers import kernel_name
     names = {kernel_name(op) for op in eng.plan(2, 128, 128).ops}
-    assert all("f16_t" in n for n in names), sorted(n for n in names if "f16_t" not in n)     # no bf16 kernel sneaks into an fp16 plan
+    # no bf16 kernel sneaks into an fp16 plan (csrc/dcn5.hip exists for fp16 only: no type in its name)
+    assert all("f16_t" in n or n.startswith("dcn5_kernel<") for n in names), sorted(n for n in names if "f16_t" not in n)
     with torch.no_grad():
         ref = odla.DLAOracle(sd, HEADS, use_dcn=use_dcn)(torch.from_numpy(xs))[0]
         emu = odla.DLAOracle(sd, HEADS, use_dcn=use_dcn, emulate="f16")(torch.from_numpy(xs))[0]

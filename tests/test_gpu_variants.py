@@ -142,18 +142,25 @@ DCN_CASES = [
     # selected the natural way by the workgroup count (>= 192 x 128-channel workgroups / >= 512 tiles)
     ("fused", "bf16", 0, 12, 128, 128, 64, 64, 0.5),       # 192 workgroups -> MT = 4 without an override
     # fp16 plans (H3D_F16): the apron needs no conversion while it is staged; everything else as in bf16 plans
-    ("stream", "f16", 0, 2, 128, 64, 24, 40, 0.5),         # dcn5<2,2,.,256>: apron AND filters by LDS-DMA (csrc/dcn5.hip)
+    ("stream", "f16", 0, 2, 128, 64, 24, 40, 0.5),         # dcn3<f16,2,16,2,WDMA,256>
     ("stream", "f16", 0, 1, 256, 64, 16, 32, 3.0),
     ("stream", "f16", 0, 2, 64, 64, 40, 24, 6.0),          #   ... patches AND pass 2
-    ("stream", "f16", 0, 1, 64, 32, 20, 20, 12.0),         # dcn5<1,2,.,256>
-    ("stream", "f16", 0x400, 1, 128, 128, 16, 32, 3.0),    # dcn5<4,4,.,256>: margin-4 apron
+    ("stream", "f16", 0, 1, 64, 32, 20, 20, 12.0),         # dcn3<f16,1,16,2,WDMA,256>
+    ("stream", "f16", 0x400, 1, 128, 128, 16, 32, 3.0),    # dcn3<f16,4,16,4,WDMA,256>: margin-4 apron
     ("stream", "f16", 0x400, 1, 256, 256, 24, 24, 8.0),    #   (ResNet-101-DCN's first up-sampling stage in miniature)
+    # 0x4000: csrc/dcn5.hip (apron AND filters by LDS-DMA; measured slower, kept selectable: DESIGN.md 2.2)
+    ("stream", "f16", 0x4000, 2, 128, 64, 24, 40, 0.5),    # dcn5<2,2,.,256>
+    ("stream", "f16", 0x4000, 1, 256, 64, 16, 32, 3.0),
+    ("stream", "f16", 0x4000, 2, 64, 64, 40, 24, 6.0),     #   ... patches AND pass 2
+    ("stream", "f16", 0x4000, 1, 64, 32, 20, 20, 12.0),    # dcn5<1,2,.,256>
+    ("stream", "f16", 0x4400, 1, 128, 128, 16, 32, 3.0),   # dcn5<4,4,.,256>
+    ("stream", "f16", 0x4400, 1, 256, 256, 24, 24, 8.0),
+    ("stream", "f16", 0x4000, 1, 48, 64, 20, 20, 3.0),     # three stages (no two-stage unrolling in dcn5)
+    ("stream", "f16", 0x4000, 1, 64, 64, 16, 16, 40.0),
     ("stream", "f16", 0, 1, 256, 256, 16, 16, 3.0),        # small grid: 64-channel workgroups
-    ("stream", "f16", 0, 1, 48, 64, 20, 20, 3.0),          # Cin = 16 (mod 32): three stages (csrc/dcn5.hip has no two-stage unrolling)
+    ("stream", "f16", 0, 1, 48, 64, 20, 20, 3.0),          # Cin = 16 (mod 32): no patches
     ("stream", "f16", 0, 1, 64, 64, 16, 16, 40.0),         #   ... nearly every sample outside the apron or the image
-    ("stream", "f16", 0, 12, 128, 128, 64, 64, 0.5),       # >= 192 workgroups: dcn5<4,4> without an override
-    ("stream", "f16", 0x2000, 2, 128, 64, 24, 40, 0.5),    # 0x2000: csrc/dcn3.hip's register-staged apron on an fp16 input (dcn3<f16,2,16,2,WDMA,256>)
-    ("stream", "f16", 0x2400, 1, 256, 256, 24, 24, 8.0),   #   ... dcn3<f16,4,16,4,WDMA,256>
+    ("stream", "f16", 0, 12, 128, 128, 64, 64, 0.5),       # >= 192 workgroups: the 128-channel variant without an override
     ("stream", "f16", 0x1000, 1, 64, 32, 20, 20, 12.0),    # 0x1000: no patch slots, dcn3<f16,1,16,1,WDMA,0>
     ("fused", "f16", 0, 1, 64, 32, 20, 36, 3.0),           # register-staged filters: dcn3<f16,1,32,2>
     ("fused", "f16", 0x400, 1, 128, 128, 24, 40, 0.5),     # dcn3<f16,4,16,2>
@@ -202,10 +209,10 @@ def test_dcn_fused_variant_matches_oracle(case):
     assert torch.equal(got, built.run()), built.name
 
 
-def test_dcn_f16_stream_dispatches_to_the_dma_apron_kernel():
+def test_dcn_f16_stream_dispatch():
     names = {c: _dcn_built(c)[5].name for c in DCN_CASES if c[0] == "stream" and c[1] == "f16"}
     for c, n in names.items():
-        assert n.startswith("dcn3_kernel<f16_t" if c[2] & 0x3000 else "dcn5_kernel<"), (c, n)
+        assert n.startswith("dcn5_kernel<" if c[2] & 0x4000 else "dcn3_kernel<f16_t"), (c, n)
     assert {"dcn5_kernel<2, 2, 2, 256>", "dcn5_kernel<1, 2, 1, 256>", "dcn5_kernel<4, 4, 2, 256>"} <= set(names.values()), names
 
 
@@ -232,7 +239,8 @@ def _plan_kernel_names(batch):
 
 def test_bench_plan_kernels_are_all_covered():
     """tested-kernel-set >= bench-kernel-set: every conv / DeformConv instantiation of the batch-64 (bench.py,
-    BASELINE configs[2]) and batch-32 (configs[1]) plans has a per-op parity case above or in test_gpu_conv.py;
+    BASELINE configs[2]), batch-32 (configs[1]) and batch-8 (the 8-GPU shard of configs[2]) plans has a per-op parity case
+    above or in test_gpu_conv.py;
     the remaining kernels (stem3, heads, max-pool, up-sample) have exactly one instantiation per dtype and are
     compared at full size in test_gpu_fullsize.py."""
     import test_gpu_conv
@@ -240,7 +248,7 @@ def test_bench_plan_kernels_are_all_covered():
     tested = {_conv2_built(c)[4].name for c in CONV2_CASES} | {_dcn_built(c)[5].name for c in DCN_CASES}
     tested |= test_gpu_conv.conv_case_kernel_names("bf16") | test_gpu_conv.gemm1_case_kernel_names()
     single = ("stem3_kernel", "heads_kernel<", "maxpool_kernel<", "upadd_kernel<", "copy_kernel<")
-    for batch in (64, 32):
+    for batch in (64, 32, 8):       # 8: the shard one GPU of eight gets from the headline batch (bench.py --global-batch 64)
         names = _plan_kernel_names(batch)
         missing = sorted(n for n in names if n not in tested and not n.startswith(single))
         assert not missing, "batch %d: no per-op parity case dispatches to %s" % (batch, missing)
