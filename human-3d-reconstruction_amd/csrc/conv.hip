@@ -622,6 +622,8 @@ int h3d_launch_elementwise(const h3d_op &op, hipStream_t st)
     // segments) 0.029 -> 0.041: stays in global memory.  Tuning override: reserved 1 = never, 2 = whenever it fits 64 KiB
     const size_t up_wbytes = (size_t)op.ksize * op.ksize * op.Cin * sizeof(float);
     const bool up_wlds = op.reserved == 1 ? false : op.reserved == 2 ? up_wbytes <= 64 * 1024 : (up_wbytes <= 8192 || (up_wbytes <= 16384 && op.Cin <= 64));
+    // (measured and dropped in round 3: f = 2 tap weights in registers, rows in pairs with ten loads in flight -- 0.341 vs 0.325 ms
+    //  over the six f = 2 launches of the batch-64 plan: the kernel sits at the 4.4-4.9 TB/s these mixed read / write streams reach)
     if (h3d_note_kernel("%s<%s%s%s>", op.kind == H3D_OP_MAXPOOL ? "maxpool_kernel" : op.kind == H3D_OP_UPADD ? "upadd_kernel" : "copy_kernel",
                         f16 ? "f16_t" : es == 2 ? "unsigned short" : "float", op.kind == H3D_OP_UPADD ? (f16out ? ", true" : ", false") : "",
                         op.kind == H3D_OP_UPADD ? (up_wlds ? ", true" : ", false") : ""))

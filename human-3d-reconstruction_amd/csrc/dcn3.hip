@@ -76,7 +76,7 @@ struct Dcn3Cfg {
     static constexpr int PB = NP ? (NP * PSLOT + 255) / 256 * 256 : 0;
     static constexpr int STAGE = PB + LDS_H + WSLOT;                   // one stage buffer (non-WDMA)
     static constexpr int LDS_MAIN = WDMA ? PB + LDS_H + 2 * WSLOT : 2 * STAGE;
-    static constexpr int LDS_DESC = NP ? NP * 16 + 16 : 0;             // sample list (16 B each) + the slot counter
+    static constexpr int LDS_DESC = NP ? NP * 16 + 32 : 0;             // sample list (16 B each) + the eight per-wave sample counts
     static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // epilogue.h tile_epilogue_lds regions
     static constexpr int LDS = LDS_MAIN + LDS_DESC > LDS_EPI ? LDS_MAIN + LDS_DESC : LDS_EPI;
     static_assert(NP == 0 || (WDMA && sizeof(T) == 2), "patches: bf16 plans with DMA'd filters");
@@ -245,7 +245,6 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         // the patch area and the apron are cleared once (pad slots and row tails are never written afterwards; the filter
         // slots only ever hold finite fp16); the barriers of phase A order this before any use
         for (int i = tid * 16; i < C::PB + C::LDS_H; i += C::THREADS * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
-        if (tid == 0) *reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16) = 0;
         __syncthreads();                       // ... and before stage 0's apron is stored
     }
     H3D_STAMP(blockIdx.x, 0);
@@ -345,16 +344,22 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             my_geo[u] = g;
         }
         if constexpr (NP > 0) {
-            // patch slots: ONE LDS atomic per wave for all five taps (the slots of tap u follow those of taps < u)
+            // patch slots, in a DETERMINISTIC order (wave, tap, lane): every wave publishes its sample count, and after a barrier
+            // takes the slots behind those of the lower-numbered waves.  (Round 2 used one LDS atomic per wave: the order in which
+            // the waves arrived decided WHICH samples of a tile with more than NP of them went to pass 2 instead of a patch --
+            // two accumulation orders, so such tiles differed in the last bit from run to run: found by the batch-8 full-size
+            // test, where the 256-channel 32 x 32 layer runs this variant.)
             unsigned long long m[5];
             int cnt = 0;
 #pragma unroll
             for (int u = 0; u < 5; ++u) { m[u] = __ballot(my_want[u]); cnt += __popcll(m[u]); }
+            int *s_cnt = reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16);
+            if (l == 0) s_cnt[wv] = cnt;
+            __syncthreads();
+            int base = 0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) base += (w8 < wv) ? s_cnt[w8] : 0;
             if (cnt) {                                               // wave-uniform
-                int base = 0;
-                if (l == 0) base = __hip_atomic_fetch_add(reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16), cnt,
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
                 for (int u = 0; u < 5; ++u) {
                     const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
@@ -400,7 +405,12 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     [[maybe_unused]] bool overflow = false;
     if constexpr (NP > 0) {
         __syncthreads();                                                 // the list is complete
-        const int nwant = *reinterpret_cast<const int *>(smem + C::LDS_MAIN + NP * 16);
+        int nwant = 0;
+        {
+            const int *s_cnt = reinterpret_cast<const int *>(smem + C::LDS_MAIN + NP * 16);
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) nwant += s_cnt[w8];
+        }
         overflow = nwant > NP;                                           // workgroup-uniform: some sample found no slot
         const int nsl = min(nwant, NP);
         const int ps = tid / C::VPP, pv = tid - ps * C::VPP;

@@ -56,7 +56,7 @@ struct Dcn5Cfg {
     static constexpr int OFF_A = PB, OFF_F = PB + 2 * ASLOT;
     static constexpr int LDS_MAIN = OFF_F + 2 * WSLOT;
     static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);
-    static constexpr int LDS = (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) + 16;      // + the slot counter
+    static constexpr int LDS = (LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI) + 32;      // + the eight per-wave sample counts
     static constexpr int THREADS = 512;
     static constexpr int AP = (APIECES + 7) / 8;                // apron pieces per wave
     static_assert((ROWB / 16) % 2 == 0 && (ROWB & 16) == 0, "row-parity swizzle: rows of an even number of 16-byte slots");
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
 #endif
     constexpr bool TAPAHEAD = MT >= DCN5_TAPAHEAD || (XP & 16);
     __shared__ __attribute__((aligned(1024))) char smem[C::LDS];
-    int *s_cnt = reinterpret_cast<int *>(smem + C::LDS - 16);
+    int *s_cnt = reinterpret_cast<int *>(smem + C::LDS - 32);
 
     const int tid = threadIdx.x;
     const int l = tid & 63, r = l & 31, h = l >> 5;
@@ -156,7 +156,6 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
         // every byte a zero-weighted corner read of a patched sample can touch must hold a finite number: the patch area is
         // cleared once (the apron slots are written whole by the DMA, the filter slots only ever hold finite fp16)
         for (int i = tid * 16; i < C::PB; i += C::THREADS * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
-        if (tid == 0) *s_cnt = 0;
     }
 
     // ================= phase A: offsets/mask = conv3x3(x; 27 filters), one barrier per stage ========================
@@ -234,15 +233,17 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
             my_geo[u] = g;
         }
         if constexpr (NP > 0) {
-            __syncthreads();                                         // the counter and the cleared patch area are visible
+            // patch slots in a deterministic order (wave, tap, lane): see csrc/dcn3.hip
             unsigned long long m[5];
             int cnt = 0;
 #pragma unroll
             for (int u = 0; u < 5; ++u) { m[u] = __ballot(my_want[u]); cnt += __popcll(m[u]); }
+            if (l == 0) s_cnt[wvu] = cnt;
+            __syncthreads();                                         // the counts (and the cleared patch area) are visible
+            int base = 0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) base += (w8 < wvu) ? s_cnt[w8] : 0;
             if (cnt) {                                               // wave-uniform
-                int base = 0;
-                if (l == 0) base = __hip_atomic_fetch_add(s_cnt, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
                 for (int u = 0; u < 5; ++u) {
                     const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[u], 0u));
@@ -286,7 +287,9 @@ __global__ __launch_bounds__(512, MT <= 2 ? 4 : 2) void dcn5_kernel(Dcn5Args a)
     [[maybe_unused]] bool phas = false, overflow = false, anyp = false;
     if constexpr (NP > 0) {
         __syncthreads();                                                 // the list is complete
-        const int nwant = *s_cnt;
+        int nwant = 0;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) nwant += s_cnt[w8];
         overflow = nwant > NP;                                           // workgroup-uniform: some sample found no slot
         anyp = nwant > 0;                                                // workgroup-uniform: the tile has patch pixels
         const int nsl = min(nwant, NP);
