@@ -550,8 +550,8 @@ def main():
     images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317, first=lo)).to(dev)
 
     nslot = max(1, args.pipeline if args.pipeline is not None else (3 if args.arch == "hourglass" else 2))
-    if args.streams > 1:
-        nslot = 1              # sub-batch streams and plan slots are two uses of the same idea; not combined in the bench
+    if args.streams > 1 and args.pipeline is None:
+        nslot = 1              # sub-batch streams and plan slots are two uses of the same idea: combined only on request
     use_graph = dla and args.graph == 1 and args.streams <= 1
     step, dets_shape = make_step(det, images, nslot, world, n_global, dev, graph=use_graph)
 

@@ -133,21 +133,30 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     if (H3D_DBG(a) == 1) return;
     if (ti + 1 < t_first + S3K_TPB) load_patch(ti + 1);      // (zeros past the last tile)
 
-    // ---- P1: stem -> S --------------------------------------------------------------------------------------
+    // ---- P1: stem -> S.  The 19 x 35 region is walked as a FLAT list of 665 pixels in groups of 16 (42 groups; round 2 walked
+    //      3 groups of 16 per 35-pixel row: 57 groups, a quarter of their lanes idle): lane p of group g owns flat pixel
+    //      16 g + p, a wave advances by 128 pixels = 3 rows + 23 columns per iteration -------------------------------------
+    {
+        constexpr int NG = (S3K_SH * S3K_SW + 15) / 16;
+        int sy = (wv * 16 + p) / S3K_SW, sx = (wv * 16 + p) - sy * S3K_SW;
 #pragma unroll 1
-    for (int gi = wv; gi < S3K_SH * 3; gi += 8) {
-        const int sy = gi / 3, sx = (gi - sy * 3) * 16 + p;
-        f32x4_s3 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int gi = wv; gi < NG; gi += 8) {
+            f32x4_s3 acc = {0.f, 0.f, 0.f, 0.f};
+            const uint2 *src = s_i + sy * S3K_IW + sx + 2 * q;          // (lanes past the last pixel read rows below the patch: LDS, unused)
 #pragma unroll
-        for (int dy = 0; dy < 7; ++dy) {
-            const uint2 lo = s_i[(sy + dy) * S3K_IW + sx + 2 * q], hi = s_i[(sy + dy) * S3K_IW + sx + 2 * q + 1];
-            const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
-            acc = stem3_mfma16<T>(fa0[dy], fb, acc);
-        }
-        if (sx < S3K_SW) {
-            const int gy = sy0 + sy, gx = sx0 + sx;
-            const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = stem3_epi<T>(acc, b0, in);
+            for (int dy = 0; dy < 7; ++dy) {
+                const uint2 lo = src[dy * S3K_IW], hi = src[dy * S3K_IW + 1];
+                const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
+                acc = stem3_mfma16<T>(fa0[dy], fb, acc);
+            }
+            if (sy < S3K_SH) {                                           // (flat index < 665)
+                const int gy = sy0 + sy, gx = sx0 + sx;
+                const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = stem3_epi<T>(acc, b0, in);
+            }
+            sx += 128 % S3K_SW;
+            sy += 128 / S3K_SW;
+            if (sx >= S3K_SW) { sx -= S3K_SW; sy += 1; }
         }
     }
     __syncthreads();
@@ -160,34 +169,40 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
         const int tap = min(2 * ks + (q >> 1), 8);          // the 10th "tap" has zero weights: read tap 8 again
         toff[ks] = (tap / 3) * S3K_ROWB + (tap % 3) * S3K_PXB + (q & 1) * 16;
     }
-    // two groups per iteration: two independent MFMA chains and their loads in flight
+    // two groups per iteration: two independent MFMA chains and their loads in flight.  Flat pixel list as in P1: 17 x 33 = 561
+    // pixels = 36 groups (round 2: 51); group g and group g + 8 per iteration, a wave advances by 256 pixels
+    {
+        constexpr int NG = (S3K_LH * S3K_LW + 15) / 16;
+        int ly0v = (wv * 16 + p) / S3K_LW, lx0v = (wv * 16 + p) - ly0v * S3K_LW;
 #pragma unroll 1
-    for (int g0i = wv; g0i < S3K_LH * 3; g0i += 16) {
-        f32x4_s3 acc[2];
-        int lyv[2], lxv[2];
+        for (int g0i = wv; g0i < NG; g0i += 16) {
+            f32x4_s3 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            int lyv[2], lxv[2];                                          // group g0i and group g0i + 8 (128 pixels on)
+            lyv[0] = ly0v; lxv[0] = lx0v;
+            lxv[1] = lx0v + 128 % S3K_LW; lyv[1] = ly0v + 128 / S3K_LW;
+            if (lxv[1] >= S3K_LW) { lxv[1] -= S3K_LW; lyv[1] += 1; }
+            const char *src[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int gi = min(g0i + 8 * u, S3K_LH * 3 - 1);      // (a duplicate of the last group when there is no second one)
-            lyv[u] = gi / 3;
-            lxv[u] = (gi - lyv[u] * 3) * 16 + p;
-            acc[u] = f32x4_s3{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int u = 0; u < 2; ++u) src[u] = s_s + lyv[u] * S3K_ROWB + lxv[u] * S3K_PXB;      // (pixels past the end: reads inside the LDS slack)
 #pragma unroll
-        for (int ks = 0; ks < 5; ++ks)
+            for (int ks = 0; ks < 5; ++ks)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const u32x4 fb = *reinterpret_cast<const u32x4 *>(src[u] + toff[ks]);
+                    acc[u] = stem3_mfma16<T>(fa1[ks], fb, acc[u]);
+                }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const u32x4 fb = *reinterpret_cast<const u32x4 *>(s_s + lyv[u] * S3K_ROWB + lxv[u] * S3K_PXB + toff[ks]);
-                acc[u] = stem3_mfma16<T>(fa1[ks], fb, acc[u]);
+                if (lyv[u] < S3K_LH) {                                   // (flat index < 561)
+                    const int ly = lyv[u], lx = lxv[u];
+                    const int gy = ly0 + ly, gx = lx0 + lx;
+                    const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                    *reinterpret_cast<u32x2 *>(s_l + ly * S3K_ROWB + lx * S3K_PXB + q * 8) = stem3_epi<T>(acc[u], b1, in);
+                }
             }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u == 1 && g0i + 8 >= S3K_LH * 3) break;
-            const int ly = lyv[u], lx = lxv[u];
-            if (lx < S3K_LW) {
-                const int gy = ly0 + ly, gx = lx0 + lx;
-                const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                *reinterpret_cast<u32x2 *>(s_l + ly * S3K_ROWB + lx * S3K_PXB + q * 8) = stem3_epi<T>(acc[u], b1, in);
-            }
+            lx0v += 256 % S3K_LW;
+            ly0v += 256 / S3K_LW;
+            if (lx0v >= S3K_LW) { lx0v -= S3K_LW; ly0v += 1; }
         }
     }
     __syncthreads();
