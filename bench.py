@@ -224,13 +224,29 @@ def dcn_apron_stats(det, images2, dev):
 
 
 def boundary_op_times(batch, dev):
-    """The literal drop-in operator (`_ext.dcn_v2_forward`, DCNv2/src/dcn_v2.h:9-23 -> h3d_dcn_v2_forward_ws) on the 16
-    DeformConv shapes of the network at this batch: NCHW fp32 operands in, NCHW fp32 out, HIP events on the
-    current stream around the call (layout conversion inside the workspace included).  Not part of the timed step: the
-    engine path never materialises offsets or NCHW tensors."""
+    """The literal drop-in operator (`_ext.dcn_v2_forward`, DCNv2/src/dcn_v2.h:9-23) on the 16 DeformConv shapes of the network
+     at this batch, HIP events on the current stream around the call, in three forms of the SAME Python function:
+      reference  NCHW fp32 operands in, NCHW fp32 out (input relayout + offset/mask pack inside a workspace; since round 3 the
+                 packed filters are cached per parameter version, as any caller running a layer repeatedly gets them);
+      nhwc       the input in torch.channels_last memory format: read in place, channels-last fp32 out;
+      bf16       a bfloat16 channels-last input: the network's bf16 DeformConv path (fp16 filters and blend, f16 MFMA).
+    Not part of the timed step: the engine path never materialises offsets or NCHW tensors."""
     from h3d_amd import dcn_v2
     res = {}
     g = torch.Generator(device="cpu").manual_seed(0)
+    tot = {"reference": 0.0, "nhwc": 0.0, "bf16": 0.0}
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 3
+
     for prefix, o, ins, ups in arch.ida_specs():
         lvl = {"dla_up.ida_0": 32, "dla_up.ida_1": 64, "dla_up.ida_2": 128, "ida_up": 128}[prefix]     # output side at 512 x 512
         for k, (ci, f) in enumerate(zip(ins, ups), start=1):
@@ -244,20 +260,23 @@ def boundary_op_times(batch, dev):
                 b = torch.zeros(o, device=dev)
                 off = (torch.randn(batch, 18, hw, hw, generator=g) * 1.5).to(dev)
                 m = torch.rand(batch, 9, hw, hw, generator=g).to(dev)
-                for _ in range(2):
-                    dcn_v2.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(3):
-                    dcn_v2.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
-                e1.record()
-                torch.cuda.synchronize()
-                ms = e0.elapsed_time(e1) / 3
-                res[key] = {"n": 1, "ms": round(ms, 3), "tflops": round(2.0 * batch * hw * hw * o * cin * 9 / ms / 1e9, 1)}
-                del x, w, off, m
-    tot = sum(v["ms"] * v["n"] for v in res.values())
-    return {"dtype": "f32 (v_mfma_f32_32x32x2_f32, peak 157 TFLOP/s)", "batch": batch, "layers": sum(v["n"] for v in res.values()),
-            "total_ms": round(tot, 3), "shapes": res}
+                xcl = x.contiguous(memory_format=torch.channels_last)
+                xbf = xcl.to(torch.bfloat16)
+                flop = 2.0 * batch * hw * hw * o * cin * 9
+                ms = {"reference": timed(lambda: dcn_v2.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)),
+                      "nhwc": timed(lambda: dcn_v2.dcn_v2_forward(xcl, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)),
+                      "bf16": timed(lambda: dcn_v2.dcn_v2_forward(xbf, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1))}
+                res[key] = {"n": 1, "ms": round(ms["reference"], 3), "tflops": round(flop / ms["reference"] / 1e9, 1),
+                            "ms_nhwc": round(ms["nhwc"], 3), "ms_bf16": round(ms["bf16"], 3), "tflops_bf16": round(flop / ms["bf16"] / 1e9, 1)}
+                del x, w, off, m, xcl, xbf
+    for v in res.values():
+        tot["reference"] += v["ms"] * v["n"]
+        tot["nhwc"] += v["ms_nhwc"] * v["n"]
+        tot["bf16"] += v["ms_bf16"] * v["n"]
+    return {"dtype": "reference / nhwc: f32 (v_mfma_f32_32x32x2_f32, peak 157 TFLOP/s); bf16: fp16 blend + v_mfma_f32_32x32x16_f16",
+            "batch": batch, "layers": sum(v["n"] for v in res.values()),
+            "total_ms": round(tot["reference"], 3), "total_ms_nhwc": round(tot["nhwc"], 3), "total_ms_bf16": round(tot["bf16"], 3),
+            "shapes": res}
 
 
 def _free_port():

@@ -16,6 +16,7 @@ OP_CONV_STREAM, OP_DCN_FUSED_F16, OP_DCN_FUSED_STREAM, OP_STEM3, OP_UPDCN_F16 = 
 OP_IM2COL, OP_MAXPOOL3, OP_DEPTH2SPACE, OP_UPDCN_STREAM = 15, 16, 17, 18
 HEADS_MAX = 16
 OUT_NHWC, OUT_NCHW_F32, OUT_NHWC_F32, OUT_NHWC_F16 = 0, 1, 2, 3
+DCN_INPUT_NHWC, DCN_OUTPUT_NHWC = 1, 2
 ABI_VERSION = 1
 
 c_vp, c_i, c_fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
@@ -53,6 +54,8 @@ class H3dUpdcnDesc(ctypes.Structure):
 SIGNATURES = {
     "h3d_dcn_v2_forward": [c_vp] * 6 + [c_i] * 14 + [c_vp],
     "h3d_dcn_v2_forward_ws": [c_vp] * 6 + [c_i] * 14 + [c_vp, ctypes.c_size_t, c_vp],
+    "h3d_dcn_v2_pack_weights": [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp],
+    "h3d_dcn_v2_forward_packed": [c_vp] * 5 + [c_i] * 7 + [c_vp, ctypes.c_size_t, c_vp],
     "h3d_dcn_fused_ck": [c_i, c_i],
     "h3d_smpl_coef_pack": [c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "h3d_smpl_verts3": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],
@@ -106,6 +109,10 @@ def lib():
             fn.restype = c_i
         L.h3d_dcn_v2_workspace_bytes.argtypes = [c_i] * 5
         L.h3d_dcn_v2_workspace_bytes.restype = ctypes.c_size_t
+        L.h3d_dcn_v2_packed_weight_bytes.argtypes = [c_i] * 3
+        L.h3d_dcn_v2_packed_weight_bytes.restype = ctypes.c_size_t
+        L.h3d_dcn_v2_packed_workspace_bytes.argtypes = [c_i] * 5
+        L.h3d_dcn_v2_packed_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

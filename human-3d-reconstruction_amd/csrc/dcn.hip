@@ -391,6 +391,20 @@ __global__ void dcn_w_pack_kernel(const float *__restrict__ w, const float *__re
 
 static size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// fp16 twin of dcn_w_pack_kernel: the filter format of the bf16 DeformConv kernels (csrc/dcn2.hip)
+__global__ void dcn_w_pack_f16_kernel(const float *__restrict__ w, const float *__restrict__ bias, _Float16 *__restrict__ wp, float *__restrict__ bp,
+                                      int Cout, int C, int rows)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)rows * 9 * C;
+    if (i < (size_t)rows) bp[i] = i < (size_t)Cout ? bias[i] : 0.f;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int tap = (int)((i / C) % 9);
+    const int o = (int)(i / ((size_t)9 * C));
+    wp[i] = (_Float16)(o < Cout ? __builtin_amdgcn_fmed3f(w[((size_t)o * C + c) * 9 + tap], -65504.f, 65504.f) : 0.f);
+}
+
 extern "C" size_t h3d_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout)
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
@@ -431,5 +445,78 @@ extern "C" int h3d_dcn_v2_forward_ws(const float *input, const float *weight, co
     op.B = B; op.H = H; op.W = W; op.Cin = C; op.in_cs = C; op.in2_cs = 32; op.Ho = H; op.Wo = W; op.Cout = Cout; op.out_cs = Cout;
     op.ksize = 3; op.stride = 1; op.relu = 0; op.out_mode = H3D_OUT_NCHW_F32; op.wrows = rows;
     op.reserved = 0x800;                        // the mask operand is final (the reference applies the sigmoid in DCN.forward, dcn_v2.py:124)
+    return h3d_launch_dcn2(op, st);
+}
+
+// ---- the operator's THROUGHPUT form (round 3): what a caller that runs the same layer on every batch wants ----------------------
+// h3d_dcn_v2_forward / _ws keep the reference's contract literally (dcn_v2.h:9-23: OIHW fp32 weights and NCHW fp32 input on every
+// call), so every call re-packs the filters and re-lays the input: on the 16 DeformConv shapes of the network at batch 16 that is 35
+// launches each of dcn_w_pack_kernel / dcn_om_pack_kernel / nchw_to_nhwc_kernel and 6.5 ms.  Here the filters are packed ONCE
+// (h3d_dcn_v2_pack_weights; the Python shim caches the result per parameter version), the input may be channels-last (torch's
+// channels_last memory format IS this library's NHWC: no relayout) and may be bf16 (the network kernels' bf16 path: fp16 filters,
+// fp16 blend, f16 MFMA), and the output may be channels-last too.  offset / mask stay the reference's NCHW fp32 tensors.
+extern "C" size_t h3d_dcn_v2_packed_weight_bytes(int Cout, int C, int dtype)
+{
+    if (Cout <= 0 || C <= 0 || (dtype != H3D_F32 && dtype != H3D_BF16)) return 0;
+    const size_t rows = ((size_t)Cout + 127) / 128 * 128;
+    return ws_align(rows * 9 * C * (dtype == H3D_F32 ? 4 : 2)) + ws_align(rows * 4);
+}
+
+extern "C" int h3d_dcn_v2_pack_weights(const float *weight, const float *bias, int Cout, int C, int dtype, void *packed, void *stream)
+{
+    if (!weight || !bias || !packed) H3D_FAIL(H3D_ERR_ARG, "dcn_v2_pack_weights: null pointer");
+    if (Cout <= 0 || C <= 0 || C % 16) H3D_FAIL(H3D_ERR_SHAPE, "dcn_v2_pack_weights: C=%d must be a positive multiple of 16", C);
+    if (dtype != H3D_F32 && dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "dcn_v2_pack_weights: dtype %d (f32 | bf16)", dtype);
+    const int rows = (Cout + 127) / 128 * 128;
+    const size_t wtotal = (size_t)rows * 9 * C;
+    float *bp = (float *)((char *)packed + ws_align(wtotal * (dtype == H3D_F32 ? 4 : 2)));
+    if (dtype == H3D_F32)
+        hipLaunchKernelGGL(dcn_w_pack_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, bias, (float *)packed, bp, Cout, C, rows);
+    else
+        hipLaunchKernelGGL(dcn_w_pack_f16_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, bias, (_Float16 *)packed, bp, Cout, C, rows);
+    H3D_CHECK_LAUNCH("dcn_w_pack_kernel");
+    return H3D_OK;
+}
+
+extern "C" size_t h3d_dcn_v2_packed_workspace_bytes(int B, int C, int H, int W, int flags)
+{
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t px = (size_t)B * H * W;
+    return ws_align(px * 32 * 4) + ((flags & H3D_DCN_INPUT_NHWC) ? 0 : ws_align(px * C * 4));
+}
+
+extern "C" int h3d_dcn_v2_forward_packed(const void *input, const void *packed, const float *offset, const float *mask, void *output, int B,
+                                         int C, int H, int W, int Cout, int dtype, int flags, void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    if (!input || !packed || !offset || !mask || !output || !workspace) H3D_FAIL(H3D_ERR_ARG, "dcn_v2_forward_packed: null pointer");
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C <= 0 || C % 16 || H > 32767 || W > 32767)
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn_v2_forward_packed: B=%d C=%d (multiple of 16) H=%d W=%d Cout=%d", B, C, H, W, Cout);
+    if (dtype != H3D_F32 && dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "dcn_v2_forward_packed: dtype %d (f32 | bf16)", dtype);
+    if (dtype == H3D_BF16 && !(flags & H3D_DCN_INPUT_NHWC)) H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_v2_forward_packed: bf16 input must be channels-last");
+    if ((flags & H3D_DCN_OUTPUT_NHWC) && Cout % 4) H3D_FAIL(H3D_ERR_SHAPE, "dcn_v2_forward_packed: channels-last output needs Cout %% 4 == 0");
+    if (workspace_bytes < h3d_dcn_v2_packed_workspace_bytes(B, C, H, W, flags))
+        H3D_FAIL(H3D_ERR_ARG, "dcn_v2_forward_packed: workspace of %zu bytes, %zu needed", workspace_bytes, h3d_dcn_v2_packed_workspace_bytes(B, C, H, W, flags));
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = (Cout + 127) / 128 * 128;
+    const size_t px = (size_t)B * H * W;
+    char *ws = (char *)workspace;
+    float *om = (float *)ws;                    ws += ws_align(px * 32 * 4);
+    const void *x = input;
+    if (!(flags & H3D_DCN_INPUT_NHWC)) {
+        int rc = h3d_nchw_f32_to_nhwc((const float *)input, ws, H3D_F32, B, C, H, W, C, stream);
+        if (rc != H3D_OK) return rc;
+        x = ws;
+    }
+    hipLaunchKernelGGL(dcn_om_pack_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, offset, mask, om, H * W, px);
+    H3D_CHECK_LAUNCH("dcn_om_pack_kernel");
+    h3d_op op = {};
+    op.kind = H3D_OP_DCN; op.dtype = dtype;
+    op.in = x; op.in2 = om; op.w = packed;
+    op.bias = (const float *)((const char *)packed + ws_align((size_t)rows * 9 * C * (dtype == H3D_F32 ? 4 : 2)));
+    op.out = output;
+    op.B = B; op.H = H; op.W = W; op.Cin = C; op.in_cs = C; op.in2_cs = 32; op.Ho = H; op.Wo = W; op.Cout = Cout; op.out_cs = Cout;
+    op.ksize = 3; op.stride = 1; op.relu = 0; op.out_mode = (flags & H3D_DCN_OUTPUT_NHWC) ? H3D_OUT_NHWC : H3D_OUT_NCHW_F32; op.wrows = rows;
+    op.reserved = 0x800;                        // the mask operand is final
     return h3d_launch_dcn2(op, st);
 }

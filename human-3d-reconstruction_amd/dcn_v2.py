@@ -14,15 +14,52 @@ from torch.nn.modules.utils import _pair
 from . import _lib
 
 
+_PACKED = {}          # (weight ptr, version, bias ptr, version, dtype, device) -> packed filter image (h3d_dcn_v2_pack_weights)
+_PACKED_MAX = 64
+
+
+def _packed_weights(weight, bias, dtype):
+    """The operator's filters in the kernels' layout, packed ONCE per parameter version (the reference re-reads OIHW weights
+    on every call; re-packing them per call was 35 launches and a third of the operator's time on the network's 16 layers)."""
+    key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, dtype, str(weight.device))
+    ent = _PACKED.get(key)
+    if ent is None:
+        Cout, C = weight.shape[0], weight.shape[1]
+        L = _lib.lib()
+        n = int(L.h3d_dcn_v2_packed_weight_bytes(Cout, C, dtype))
+        buf = torch.empty(n, dtype=torch.uint8, device=weight.device)
+        _lib.check(L.h3d_dcn_v2_pack_weights(_lib.ptr(weight), _lib.ptr(bias), Cout, C, dtype, _lib.ptr(buf), _lib.stream_ptr()),
+                   "dcn_v2_pack_weights")
+        if len(_PACKED) >= _PACKED_MAX:
+            _PACKED.pop(next(iter(_PACKED)))
+        # (the key holds the parameters' addresses: keep them alive as long as the entry, so an address cannot be reused)
+        ent = _PACKED[key] = (buf, weight, bias)
+    return ent[0]
+
+
 def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w,
                    pad_h, pad_w, dilation_h, dilation_w, deformable_group):
-    """Positional twin of `_ext.dcn_v2_forward` (dcn_v2.py:25-31 call site). fp32 contiguous
-    NCHW CUDA tensors; returns a new [B,Cout,Ho,Wo] tensor."""
+    """Positional twin of `_ext.dcn_v2_forward` (dcn_v2.py:25-31 call site): fp32 contiguous NCHW CUDA tensors in, a new
+    [B,Cout,Ho,Wo] fp32 tensor out.
+
+    Throughput form (same function, nothing to opt into): in the model's configuration (3x3 s1 p1 d1 dg1, C % 16 == 0)
+      * the packed filters are cached per (weight, bias) version -- a layer that runs every batch packs once;
+      * an `input` in torch.channels_last memory format is read in place (no relayout) and the output comes back
+        channels-last as well (torch's convention: the output follows the input's memory format);
+      * a bfloat16 channels-last `input` runs the network's bf16 DeformConv path (fp16 filters and blend, f16 MFMA, fp32
+        accumulation) and returns bfloat16; offset / mask stay fp32 NCHW as in the reference."""
     _lib.require_cuda(input, weight, bias, offset, mask)
-    for t in (input, weight, bias, offset, mask):
+    lowp = input.dtype == torch.bfloat16
+    for t in (weight, bias, offset, mask) + (() if lowp else (input,)):
         if t.dtype != torch.float32:
             raise RuntimeError("dcn_v2_forward: expected float32 tensors (reference uses .data<float>())")
-    input, weight, bias, offset, mask = [t.contiguous() for t in (input, weight, bias, offset, mask)]
+    nhwc = input.dim() == 4 and input.is_contiguous(memory_format=torch.channels_last) and not input.is_contiguous()
+    if lowp and not (input.dim() == 4 and input.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("dcn_v2_forward: a bfloat16 input must be in torch.channels_last memory format")
+    nhwc = nhwc or lowp
+    if not nhwc:
+        input = input.contiguous()
+    weight, bias, offset, mask = [t.contiguous() for t in (weight, bias, offset, mask)]
     B, C, H, W = input.shape
     Cout, Ck, kh_, kw_ = weight.shape
     if kh_ != kernel_h or kw_ != kernel_w:
@@ -39,19 +76,36 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
         raise RuntimeError("mask shape %s does not match [B, dg*kh*kw, Ho, Wo]" % (tuple(mask.shape),))
     if bias.numel() != Cout:
         raise RuntimeError("bias has %d elements, expected %d" % (bias.numel(), Cout))
-    out = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=input.device)
+    fast = ((kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, deformable_group)
+            == (3, 3, 1, 1, 1, 1, 1, 1, 1) and C % 16 == 0 and H <= 32767 and W <= 32767)
+    L = _lib.lib()
     with torch.cuda.device(input.device):
-        # the model's configuration (3x3 s1 p1 d1 dg1, C % 16 == 0) runs on the LDS-apron + MFMA kernel, which wants a
-        # workspace (the reference allocates `columns` / `ones` itself, dcn_v2_cuda.cu:90-103; here torch's caching
-        # allocator does, stream-ordered); everything else takes the general kernel and needs none
-        fast = ((kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, deformable_group)
-                == (3, 3, 1, 1, 1, 1, 1, 1, 1) and C % 16 == 0)
-        nws = int(_lib.lib().h3d_dcn_v2_workspace_bytes(B, C, H, W, Cout)) if fast else 0
-        ws = torch.empty(nws, dtype=torch.uint8, device=input.device) if nws else None
-        rc = _lib.lib().h3d_dcn_v2_forward_ws(
-            _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(out),
-            B, C, H, W, Cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
-            deformable_group, _lib.ptr(ws), nws, _lib.stream_ptr())
+        if fast:
+            # LDS-apron + MFMA kernel on packed filters (cached); the workspace holds the [B,H,W,32] offset/mask rows and, for an
+            # NCHW input, its channels-last copy (the reference allocates `columns` / `ones` itself, dcn_v2_cuda.cu:90-103;
+            # here torch's caching allocator does, stream-ordered)
+            out_nhwc = nhwc and Cout % 4 == 0
+            dtype = _lib.H3D_BF16 if lowp else _lib.H3D_F32
+            if lowp and not out_nhwc:
+                raise RuntimeError("dcn_v2_forward: bfloat16 needs Cout % 4 == 0")
+            flags = (_lib.DCN_INPUT_NHWC if nhwc else 0) | (_lib.DCN_OUTPUT_NHWC if out_nhwc else 0)
+            packed = _packed_weights(weight, bias, dtype)
+            out = torch.empty(B, Cout, Ho, Wo, dtype=input.dtype if lowp else torch.float32, device=input.device,
+                              memory_format=torch.channels_last if out_nhwc else torch.contiguous_format)
+            nws = int(L.h3d_dcn_v2_packed_workspace_bytes(B, C, H, W, flags))
+            ws = torch.empty(nws, dtype=torch.uint8, device=input.device)
+            rc = L.h3d_dcn_v2_forward_packed(_lib.ptr(input), _lib.ptr(packed), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(out),
+                                             B, C, H, W, Cout, dtype, flags, _lib.ptr(ws), nws, _lib.stream_ptr())
+        else:
+            if lowp:
+                raise RuntimeError("dcn_v2_forward: bfloat16 is implemented for the model's configuration only (3x3 s1 p1 d1 dg1)")
+            if nhwc:
+                input = input.contiguous()
+            out = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=input.device)
+            rc = L.h3d_dcn_v2_forward_ws(
+                _lib.ptr(input), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(offset), _lib.ptr(mask), _lib.ptr(out),
+                B, C, H, W, Cout, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                deformable_group, None, 0, _lib.stream_ptr())
     _lib.check(rc, "dcn_v2_forward")
     return out
 

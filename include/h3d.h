@@ -72,6 +72,22 @@ int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *
                           int pad_h, int pad_w, int dilation_h, int dilation_w,
                           int deformable_group, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The operator's THROUGHPUT form: the same contraction with the per-call work of the reference contract taken out.  The filters
+ * are packed once (h3d_dcn_v2_pack_weights into h3d_dcn_v2_packed_weight_bytes(...) bytes; `dtype` H3D_F32 = exact fmaf chains on
+ * the fp32 matrix instruction, H3D_BF16 = fp16 filters + fp16 blend + f16 MFMA on a bf16 input); `input` is NCHW fp32 as in the
+ * reference or, with H3D_DCN_INPUT_NHWC, channels-last [B,H,W,C] of `dtype` (torch.channels_last: no relayout); the output is
+ * NCHW fp32 or, with H3D_DCN_OUTPUT_NHWC, channels-last of `dtype`.  offset [B,18,H,W] and mask [B,9,H,W] stay the reference's
+ * NCHW fp32 operands.  3x3, stride 1, pad 1, dilation 1, deformable_group 1 (model.py:355), C % 16 == 0.
+ * workspace: h3d_dcn_v2_packed_workspace_bytes(B, C, H, W, flags) bytes. */
+#define H3D_DCN_INPUT_NHWC 1
+#define H3D_DCN_OUTPUT_NHWC 2
+size_t h3d_dcn_v2_packed_weight_bytes(int Cout, int C, int dtype);
+int h3d_dcn_v2_pack_weights(const float *weight, const float *bias, int Cout, int C, int dtype, void *packed, void *stream);
+size_t h3d_dcn_v2_packed_workspace_bytes(int B, int C, int H, int W, int flags);
+int h3d_dcn_v2_forward_packed(const void *input, const void *packed, const float *offset, const float *mask, void *output,
+                              int B, int C, int H, int W, int Cout, int dtype, int flags,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
 /* =====================================================================================
  * 2. Network ops (DLA-34 + DLAUp/IDAUp + heads, model.py:32-61,148-222,286-292,346-415,475-489)
  *    on the internal layout: activations NHWC (channels-last) of element type f32 or bf16,

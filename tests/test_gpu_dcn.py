@@ -151,6 +151,50 @@ def test_dcn_module_model_configuration_is_one_fused_launch_and_matches_oracle()
     assert mod._fused_ok(x.to(DEV)) and not dcn_v2.DCN(16, 8, (3, 3), 2, 1).to(DEV)._fused_ok(x.to(DEV))
 
 
+def test_operator_throughput_form_cached_weights_channels_last_and_bf16():
+    """The drop-in operator without the per-call work of the reference contract (h3d_dcn_v2_forward_packed): packed filters
+    cached per parameter version, channels-last input read in place, bf16 input on the network's bf16 DeformConv path.  Every
+    form against the oracle; the fp32 forms bit-identical to each other (same kernel, same operands)."""
+    from h3d_amd import dcn_v2 as dv
+    torch.manual_seed(0)
+    B, C, Co, H, W = 2, 64, 48, 20, 28
+    x = rnd("x", (B, C, H, W))
+    w = rnd("w", (Co, C, 3, 3)) * (1.5 / np.sqrt(C * 9))
+    b = rnd("b", (Co,))
+    off = rnd("off", (B, 18, H, W), -3.0, 3.0)
+    m = torch.sigmoid(rnd("m", (B, 9, H, W), -2.0, 2.0))
+    ref = odcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
+    xd, wd, bd, od, md = [t.to(DEV) for t in (x, w, b, off, m)]
+    dv._PACKED.clear()
+    with torch.no_grad():
+        y0 = dv.dcn_v2_forward(xd, wd, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+        assert len(dv._PACKED) == 1
+        y1 = dv.dcn_v2_forward(xd, wd, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)          # second call: the cached pack
+        assert len(dv._PACKED) == 1 and torch.equal(y0, y1)
+        np.testing.assert_allclose(y0.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4)
+        # channels-last input: no relayout, channels-last output, same numbers
+        xcl = xd.contiguous(memory_format=torch.channels_last)
+        y2 = dv.dcn_v2_forward(xcl, wd, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+        assert y2.is_contiguous(memory_format=torch.channels_last) and y2.shape == y0.shape and torch.equal(y2, y0)
+        # a parameter update invalidates the cache entry (new version -> new pack)
+        wd.mul_(2.0)
+        y3 = dv.dcn_v2_forward(xd, wd, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+        assert len(dv._PACKED) == 2
+        ref3 = odcn.dcn_v2_forward(x, 2.0 * w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
+        np.testing.assert_allclose(y3.cpu().numpy(), ref3.numpy(), rtol=0, atol=4e-4)
+        # bf16 channels-last input: the network's bf16 path (fp16 filters and blend), bf16 channels-last output
+        xb = bf16_round(x)
+        wh = (2.0 * w).half().float()
+        refb = odcn.dcn_v2_forward(xb, wh, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
+        yb = dv.dcn_v2_forward(xb.to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last), wd, bd, od, md,
+                               3, 3, 1, 1, 1, 1, 1, 1, 1)
+        assert yb.dtype == torch.bfloat16 and yb.is_contiguous(memory_format=torch.channels_last)
+        scale = max(1.0, float(refb.abs().max()))
+        assert float((yb.float().cpu() - refb).abs().max()) <= 1.2e-2 * scale
+        with pytest.raises(RuntimeError, match="channels_last"):
+            dv.dcn_v2_forward(xd.to(torch.bfloat16), wd, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
 def test_dcn_module_runs_outside_no_grad_like_the_reference_module():
     # ADVICE r2: nn.Parameter requires grad by default, so `model.eval(); dcn(x)` outside torch.no_grad() used to raise.
     # The reference module runs there; ours computes without a graph and returns a detached tensor.  An input that itself
