@@ -68,6 +68,7 @@ SIGNATURES = {
     "h3d_nhwc_to_nchw_f32": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "h3d_nms_topk": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp],
     "h3d_nms_topk2": [c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "h3d_nms_topk_large": [c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp],
     "h3d_nms": [c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "h3d_topk_merge": [c_vp] * 4 + [c_i] * 3 + [c_vp] * 5 + [c_vp],
     "h3d_gather_feat": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
@@ -113,6 +114,8 @@ def lib():
         L.h3d_dcn_v2_packed_weight_bytes.restype = ctypes.c_size_t
         L.h3d_dcn_v2_packed_workspace_bytes.argtypes = [c_i] * 5
         L.h3d_dcn_v2_packed_workspace_bytes.restype = ctypes.c_size_t
+        L.h3d_nms_topk_large_workspace_bytes.argtypes = [c_i] * 5
+        L.h3d_nms_topk_large_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
 

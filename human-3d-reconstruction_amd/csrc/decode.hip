@@ -90,11 +90,22 @@ struct NmsJob {
     int nblk;       // B * C maps
 };
 
-__global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob j1, int H, int W, int K, int ncand, int flags)
+// Maps larger than the LDS (H * W > 36864, e.g. the 320 x 184 output of a --keep_res 1280 x 736 frame, datasets/coco.py:160-163)
+// are cut into `nbands` bands of `band_rows` rows: workgroup (map, band) loads its rows plus one halo row on either side (the
+// 3x3 max needs them), only the band's own rows are candidates, and the band's top K go to a [maps][nbands][K] scratch that
+// topk_merge_kernel reduces (same order: score descending, lowest flat index first).  nbands = 1 is the plain case.
+__global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob j1, int H_img, int W, int K, int ncand, int flags,
+                                                               int band_rows, int nbands)
 {
-    int blk = blockIdx.x;
+    int blk = blockIdx.x / nbands;
+    const int band = blockIdx.x - blk * nbands;
     NmsJob jb = j0;
     if (blk >= j0.nblk) { blk -= j0.nblk; jb = j1; }     // (workgroup-uniform)
+    const int out_blk = blk * nbands + band;             // output row: [map][band]
+    const int cy0 = band * band_rows, cy1 = min(H_img, cy0 + band_rows);      // candidate rows
+    const int ly0 = max(cy0 - 1, 0), ly1 = min(cy1 + 1, H_img);              // rows held in LDS
+    const int H = ly1 - ly0;                                                 // (from here on H, HW and i are LOCAL)
+    const int c_lo = (cy0 - ly0) * W, c_hi = (cy1 - ly0) * W;                // local pixel range of the candidates
     const float *__restrict__ heat = jb.heat;
     float *__restrict__ o_score = jb.o_score;
     int64_t *__restrict__ o_ind = jb.o_ind;
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob
     __shared__ uint32_t s_cnt;
     const int tid = threadIdx.x;
     const int HW = H * W;
-    const float *map = heat + (size_t)blk * HW;
+    const float *map = heat + (size_t)blk * H_img * W + (size_t)ly0 * W;
     u64 *s_cand = reinterpret_cast<u64 *>(s_key + ((HW + 1) & ~1));
     u64 *s_mask = s_cand + ncand;             // keep bits, one word per 64 pixels
 
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob
             const float sv = s_val[i];
             const bool keep = (s_mask[i >> 6] >> (i & 63)) & 1ull;
             const float val = (keep ? sv : sv * 0.0f) + 0.0f;
-            s_key[i] = fkey(val);
+            s_key[i] = (i >= c_lo && i < c_hi) ? fkey(val) : 0u;     // halo rows of a band: below every real key, never selected
         }
     }
     __syncthreads();
@@ -241,8 +252,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob
 
     for (int j = tid; j < K; j += NMS_THREADS) {
         const u64 c = s_cand[j];
-        const uint32_t idx = 0xffffffffu - (uint32_t)(c & 0xffffffffull);
-        const size_t o = (size_t)blk * K + j;
+        const uint32_t idx = 0xffffffffu - (uint32_t)(c & 0xffffffffull) + (uint32_t)(ly0 * W);     // global flat index
+        const size_t o = (size_t)out_blk * K + j;
         o_score[o] = fkey_inv((uint32_t)(c >> 32));
         o_ind[o] = (int64_t)idx;
         o_y[o] = (float)(int)(idx / (uint32_t)W);
@@ -250,12 +261,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_topk_kernel(NmsJob j0, NmsJob
     }
 }
 
-static int nms_topk_launch(const NmsJob &j0, const NmsJob &j1, int H, int W, int K, int flags, void *stream)
+constexpr long NMS_MAXHW = 36864;      // pixels of a map (or of a band + its halo rows) the LDS holds
+
+static int nms_topk_launch(const NmsJob &j0, const NmsJob &j1, int H_img, int W, int K, int flags, void *stream, int band_rows = 0, int nbands = 1)
 {
+    if (band_rows <= 0) band_rows = H_img;
+    const int H = min(H_img, band_rows + 2);             // rows in LDS (band + halo)
     const long HW = (long)H * W;
-    if (K <= 0 || K > HW) H3D_FAIL(H3D_ERR_SHAPE, "nms_topk: selected index k out of range (K=%d, H*W=%ld)", K, HW);
-    if (K > NMS_MAXK || HW > 36864)
-        H3D_FAIL(H3D_ERR_UNSUPPORTED, "nms_topk: K=%d (max %d), H*W=%ld (max 36864)", K, NMS_MAXK, HW);
+    if (K <= 0 || K > (long)min(band_rows, H_img - (nbands - 1) * band_rows) * W)
+        H3D_FAIL(H3D_ERR_SHAPE, "nms_topk: selected index k out of range (K=%d, %d x %d pixels per band)", K, band_rows, W);
+    if (K > NMS_MAXK || HW > NMS_MAXHW)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "nms_topk: K=%d (max %d), H*W=%ld (max %ld: larger maps through h3d_nms_topk_large)", K, NMS_MAXK, HW, NMS_MAXHW);
     int N = 1;
     while (N < K) N <<= 1;
     const size_t lds = (size_t)((HW + 1) & ~1L) * 4 + (size_t)N * 8 + (size_t)((HW + 63) / 64) * 8;
@@ -265,7 +281,8 @@ static int nms_topk_launch(const NmsJob &j0, const NmsJob &j1, int H, int W, int
             H3D_FAIL(H3D_ERR_LAUNCH, "nms_topk: cannot reserve %zu bytes of LDS", lds);
         max_set = lds;
     }
-    hipLaunchKernelGGL(nms_topk_kernel, dim3(j0.nblk + j1.nblk), dim3(NMS_THREADS), lds, (hipStream_t)stream, j0, j1, H, W, K, N, flags);
+    hipLaunchKernelGGL(nms_topk_kernel, dim3((j0.nblk + j1.nblk) * nbands), dim3(NMS_THREADS), lds, (hipStream_t)stream, j0, j1, H_img, W, K, N, flags,
+                       band_rows, nbands);
     H3D_CHECK_LAUNCH("nms_topk_kernel");
     return H3D_OK;
 }
@@ -289,6 +306,54 @@ extern "C" int h3d_nms_topk2(const float *heat_a, int Ca, float *scores_a, int64
     // the many-map tensor first: its workgroups fill the CUs while the few maps of the other ride along
     const NmsJob ja = {heat_a, scores_a, inds_a, ys_a, xs_a, B * Ca}, jb = {heat_b, scores_b, inds_b, ys_b, xs_b, B * Cb};
     return Ca >= Cb ? nms_topk_launch(ja, jb, H, W, K, flags, stream) : nms_topk_launch(jb, ja, H, W, K, flags, stream);
+}
+
+// Maps of any size: bands through nms_topk_kernel, then topk_merge_kernel over the bands of every map.  Scratch (caller-provided,
+// h3d_nms_topk_large_workspace_bytes): per map and band K (score, index, y, x) candidates + one int32 per output for the band id.
+static int nms_bands(int H, int W, int K, int *band_rows, int *nbands)
+{
+    const long maxrows = NMS_MAXHW / W - 2;              // a band + two halo rows must fit the LDS
+    if (maxrows < 1) return H3D_ERR_UNSUPPORTED;
+    const int nb = (int)((H + maxrows - 1) / maxrows);
+    const int br = (H + nb - 1) / nb;                   // even split: the last band is at most nb - 1 rows shorter
+    if ((long)(H - (nb - 1) * br) * W < K) return H3D_ERR_UNSUPPORTED;      // every band must hold K candidates
+    *band_rows = br;
+    *nbands = nb;
+    return H3D_OK;
+}
+
+extern "C" size_t h3d_nms_topk_large_workspace_bytes(int B, int C, int H, int W, int K)
+{
+    int br = 0, nb = 0;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || W > NMS_MAXHW / 3 || nms_bands(H, W, K, &br, &nb) != H3D_OK) return 0;
+    const size_t n = (size_t)B * C * nb * K;
+    return n * (4 + 8 + 4 + 4) + (size_t)B * C * K * 4 + 256;
+}
+
+extern "C" int h3d_nms_topk_large(const float *heat, int B, int C, int H, int W, int K, int flags, float *scores, int64_t *inds,
+                                  float *ys, float *xs, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!heat || !scores || !inds || !ys || !xs) H3D_FAIL(H3D_ERR_ARG, "nms_topk_large: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) H3D_FAIL(H3D_ERR_SHAPE, "nms_topk_large: bad shape");
+    if ((long)H * W <= NMS_MAXHW) return h3d_nms_topk(heat, B, C, H, W, K, flags, scores, inds, ys, xs, stream);
+    int br = 0, nb = 0;
+    if (W > NMS_MAXHW / 3 || nms_bands(H, W, K, &br, &nb) != H3D_OK)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "nms_topk_large: rows of %d pixels (a band of rows + two halo rows must fit %ld pixels)", W, NMS_MAXHW);
+    if ((long)nb * K > 8192) H3D_FAIL(H3D_ERR_UNSUPPORTED, "nms_topk_large: %d bands x K=%d candidates per map (max 8192)", nb, K);
+    if (!workspace || workspace_bytes < h3d_nms_topk_large_workspace_bytes(B, C, H, W, K))
+        H3D_FAIL(H3D_ERR_ARG, "nms_topk_large: workspace of %zu bytes, %zu needed", workspace_bytes, h3d_nms_topk_large_workspace_bytes(B, C, H, W, K));
+    const size_t n = (size_t)B * C * nb * K;
+    char *ws = (char *)workspace;
+    int64_t *t_ind = (int64_t *)ws;         ws += n * 8;        // (8-byte items first: alignment)
+    float *t_score = (float *)ws;           ws += n * 4;
+    float *t_y = (float *)ws;               ws += n * 4;
+    float *t_x = (float *)ws;               ws += n * 4;
+    int32_t *t_band = (int32_t *)ws;
+    const NmsJob j0 = {heat, t_score, t_ind, t_y, t_x, B * C}, j1 = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    int rc = nms_topk_launch(j0, j1, H, W, K, flags, stream, br, nb);
+    if (rc != H3D_OK) return rc;
+    // the bands of a map are "classes" of the merge: positions are band-major, i.e. ascending flat index among equal scores
+    return h3d_topk_merge(t_score, t_ind, t_y, t_x, B * C, nb, K, scores, inds, t_band, ys, xs, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

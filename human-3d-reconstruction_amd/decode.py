@@ -22,6 +22,9 @@ def _nms(heat, kernel=3):
     return out
 
 
+MAX_LDS_MAP = 36864      # pixels of a map the one-workgroup kernel holds in LDS; larger maps go through h3d_nms_topk_large
+
+
 def _map_topk(scores, K, flags):
     scores = _f32c(scores)
     B, C, H, W = scores.shape
@@ -30,6 +33,17 @@ def _map_topk(scores, K, flags):
     i = torch.empty(B, C, K, dtype=torch.int64, device=dev)
     y = torch.empty(B, C, K, dtype=torch.float32, device=dev)
     x = torch.empty(B, C, K, dtype=torch.float32, device=dev)
+    if H * W > MAX_LDS_MAP:
+        # e.g. the 320 x 184 output map of a --keep_res 1280 x 736 frame (datasets/coco.py:160-163): bands of rows + a merge
+        L = _lib.lib()
+        nws = int(L.h3d_nms_topk_large_workspace_bytes(B, C, H, W, K))
+        if nws == 0:
+            raise RuntimeError("top-k: a %d x %d map with K = %d is not supported (a band of rows and its two halo rows must fit "
+                               "%d pixels)" % (H, W, K, MAX_LDS_MAP))
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        _lib.check(L.h3d_nms_topk_large(_lib.ptr(scores), B, C, H, W, K, flags, _lib.ptr(s), _lib.ptr(i), _lib.ptr(y), _lib.ptr(x),
+                                        _lib.ptr(ws), nws, _lib.stream_ptr()), "topk")
+        return s, i, y, x
     _lib.check(_lib.lib().h3d_nms_topk(_lib.ptr(scores), B, C, H, W, K, flags, _lib.ptr(s), _lib.ptr(i),
                                        _lib.ptr(y), _lib.ptr(x), _lib.stream_ptr()), "topk")
     return s, i, y, x
@@ -97,7 +111,7 @@ def _multi_pose(heat, wh, kps, reg, hm_hp, hp_offset, K, logits, return_aux=Fals
     B, C, H, W = heat.shape
     J = kps.shape[1] // 2
     flags = NMS_SIGMOID if logits else 0
-    if hm_hp is not None and hm_hp.shape[0] == B and hm_hp.shape[2:] == heat.shape[2:]:
+    if hm_hp is not None and hm_hp.shape[0] == B and hm_hp.shape[2:] == heat.shape[2:] and H * W <= MAX_LDS_MAP:
         (s1, i1, y1, x1), (hs, hi, hy, hx) = _map_topk2(heat, hm_hp, K, flags)      # one launch for both tensors
         s, i, c, y, x = _merge(s1, i1, y1, x1, K)
     else:

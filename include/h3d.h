@@ -213,7 +213,7 @@ int h3d_nhwc_to_nchw_f32(const void *src, int dtype, float *dst, int B, int C, i
 /* _sigmoid (utils.py:8-10) optionally, then _nms (decode.py:6-13) and the per-channel top-K of
  * _topk_channel / stage 1 of _topk (decode.py:15-24, 26-33) in one pass per (b, c) map.
  *   heat [B,C,H,W]; with H3D_NMS_SIGMOID heat holds logits and scores are
- *   clamp(sigmoid(x), 1e-4, 1-1e-4).  Requires K <= min(H*W, 1024), H*W <= 36864.
+ *   clamp(sigmoid(x), 1e-4, 1-1e-4).  Requires K <= min(H*W, 1024), H*W <= 36864 (larger maps: h3d_nms_topk_large).
  *   out: scores [B,C,K] f32 (descending), inds [B,C,K] i64 (flat y*W+x), ys/xs [B,C,K] f32. */
 #define H3D_NMS_SIGMOID 1 /* heat holds logits: apply _sigmoid first            */
 #define H3D_NMS_SKIP 2    /* heat is already NMS-ed (plain _topk/_topk_channel) */
@@ -224,6 +224,15 @@ int h3d_nms_topk(const float *heat, int B, int C, int H, int W, int K, int flags
 int h3d_nms_topk2(const float *heat_a, int Ca, float *scores_a, int64_t *inds_a, float *ys_a, float *xs_a,
                   const float *heat_b, int Cb, float *scores_b, int64_t *inds_b, float *ys_b, float *xs_b,
                   int B, int H, int W, int K, int flags, void *stream);
+
+/* h3d_nms_topk for maps of any size (H * W > 36864: e.g. the 320 x 184 output of a --keep_res 1280 x 736 frame,
+ * datasets/coco.py:160-163): the map is cut into bands of rows (each with one halo row on either side for the 3x3 max), the bands'
+ * top K are merged; same results and the same tie rule as h3d_nms_topk.  workspace: h3d_nms_topk_large_workspace_bytes(...) bytes
+ * (0 = the shape is not supported: a band of rows + two halo rows must fit 36864 pixels, bands x K <= 8192). */
+size_t h3d_nms_topk_large_workspace_bytes(int B, int C, int H, int W, int K);
+int h3d_nms_topk_large(const float *heat, int B, int C, int H, int W, int K, int flags,
+                       float *scores, int64_t *inds, float *ys, float *xs,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* stand-alone _nms (decode.py:6-13): out = heat * (maxpool3x3(heat) == heat), [B,C,H,W] */
 int h3d_nms(const float *heat, int B, int C, int H, int W, float *out, void *stream);

@@ -24,7 +24,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(L, name), name
-    size_t_fns = {"h3d_dcn_v2_workspace_bytes", "h3d_dcn_v2_packed_weight_bytes", "h3d_dcn_v2_packed_workspace_bytes"}     # (size_t results: bound separately)
+    size_t_fns = {"h3d_dcn_v2_workspace_bytes", "h3d_dcn_v2_packed_weight_bytes", "h3d_dcn_v2_packed_workspace_bytes",
+                  "h3d_nms_topk_large_workspace_bytes"}     # (size_t results: bound separately)
     assert declared - {"h3d_last_error", "h3d_abi_version"} - size_t_fns == set(_lib.SIGNATURES)
     assert L.h3d_dcn_v2_workspace_bytes(2, 64, 10, 12, 64) >= 2 * 10 * 12 * (64 + 32) * 4 + 128 * 9 * 64 * 4
     assert L.h3d_dcn_v2_workspace_bytes(0, 64, 10, 12, 64) == 0

@@ -109,6 +109,29 @@ def test_f16_plan_saturates_instead_of_overflowing():
         assert bool(torch.isfinite(out[k]).all()), k
 
 
+def test_keep_res_frame_larger_than_the_lds_map_end_to_end():
+    # `--keep_res` pads a frame to (h | 31) + 1 (datasets/coco.py:160-163): 1280 x 720 -> 1280 x 736 -> a 320 x 184 output map,
+    # 58880 pixels > the 36864 the one-workgroup top-k holds in LDS.  Network (f32 plan) vs the oracle, and the detector's decode
+    # (banded top-k + merge) bit-exact against the oracle's decode of the GPU's own heads.
+    from h3d_amd import utils
+    opt = Opt(input_h=736, input_w=1280, dtype="f32", K=100)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=1.25)
+    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    xs = synth.synth_images(1, 736, 1280, seed=11)
+    res = det.run(torch.from_numpy(xs).to(DEV))
+    assert res["heads"]["hm"].shape == (1, 1, 184, 320) and res["dets"].shape == (1, 100, 40)
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, opt.heads, use_dcn=True)(torch.from_numpy(xs))[0]
+    for k in opt.heads:
+        e = float(np.abs(res["heads"][k].cpu().numpy() - ref[k].numpy()).max())
+        assert e <= 2e-3, (k, e)
+    h = {k: v.cpu().numpy() for k, v in res["heads"].items()}
+    dref, aux = odec.multi_pose_decode(utils._sigmoid(res["heads"]["hm"].clone()).cpu().numpy(), h["wh"], h["hps"], h["reg"],
+                                       utils._sigmoid(res["heads"]["hm_hp"].clone()).cpu().numpy(), h["hp_offset"], K=100, return_aux=True)
+    np.testing.assert_array_equal(res["inds"].cpu().numpy(), aux["inds"])
+    np.testing.assert_array_equal(res["dets"].cpu().numpy(), dref)
+
+
 def test_batch_position_invariance_and_determinism():
     m, _ = _net(True, "bf16")
     xs = torch.from_numpy(synth.synth_images(3, 64, 64, seed=3)).to(DEV)
