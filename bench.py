@@ -31,6 +31,11 @@ import subprocess
 import sys
 import time
 
+# more hardware queues than HIP's default of 4: with three or four steps in flight (small per-GPU shards) two of the streams
+# otherwise share a queue and serialise (batch 8, four steps in flight: 5530 images/s with 4 queues, 7090 with 8).  A process
+# setting read by the HIP runtime at start-up; must be in the environment before torch initialises HIP.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -375,11 +380,29 @@ def workload_name(arch_name, size, batch, strong, n_global):
     return "ResNet-101-DCN ctdet -> decode; %dx%d, %s (BASELINE configs[4]: 256 over 8 GPUs = 32)" % (size, size, split)
 
 
+_STREAM_POOL = []
+
+
+def _streams(n, dev):
+    """The first n streams of one pool per process (stream -> hardware queue is decided at creation: re-creating streams for
+    every measurement would change which of them share a queue)."""
+    while len(_STREAM_POOL) < n:
+        _STREAM_POOL.append(torch.cuda.Stream(device=dev))
+    return _STREAM_POOL[:n]
+
+
+def steps_in_flight_default(arch_name, batch):
+    """3 (batch 64: 8420 / 8539 / 8537 images/s at 2 / 3 / 4 steps in flight, same box); small per-GPU shards (<= 16 images: grids
+    of a few hundred workgroups) keep 4 so that the launches of different steps fill the CUs (batch 8: 3792 / 5525 / 6577 / 7090
+    images/s at 1 / 2 / 3 / 4)."""
+    return 4 if (batch <= 16 and arch_name == "dla_34") else 3
+
+
 def make_step(det, images, nslot, world, n_global, dev, graph=False):
     """-> (step(), per-image dets shape).  step() issues one batch: consecutive calls alternate between `nslot` HIP streams, each
     with its own copy of the plan's buffers; for world > 1 the single collective (all-gather of dets) follows on the
     default stream, in step order."""
-    slot_streams = [torch.cuda.Stream(device=dev) for _ in range(nslot)] if nslot > 1 else [None]
+    slot_streams = _streams(nslot, dev) if nslot > 1 else [None]
     counter = [0]
     dets_shape = (det.opt.K, 6 if det.opt.task == "ctdet" else 40)
 
@@ -427,11 +450,12 @@ def shard_sweep(det, images, nslot, dev, batches, steps=30):
         if b >= images.shape[0]:
             continue
         sub = images[:b].contiguous()
-        step, _ = make_step(det, sub, max(nslot, 3 if b <= 16 else nslot), 1, b, dev)      # small shards: three steps in flight
+        ns = steps_in_flight_default("dla_34", b)
+        step, _ = make_step(det, sub, ns, 1, b, dev)
         issued = []
-        dt = time_steps(step, steps, 3, issued)
+        dt = time_steps(step, steps, ns + 2, issued)          # (the first call of every slot lowers its plan: all inside the warm-up)
         out[str(b)] = {"images_per_s": round(b * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
-                       "host_issue_ms_per_step": round(1e3 * issued[0] / steps, 3), "steps_in_flight": max(nslot, 3 if b <= 16 else nslot)}
+                       "host_issue_ms_per_step": round(1e3 * issued[0] / steps, 3), "steps_in_flight": ns}
     return out
 
 
@@ -509,8 +533,7 @@ def main():
     ap.add_argument("--people", type=int, default=100, help="SMPL meshes per image (<= K)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batches run concurrently on their own HIP streams")
     ap.add_argument("--pipeline", type=int, default=None,
-                    help="steps in flight (default 2; 3 for --arch hourglass, whose deep levels are many small launches: 1335 -> "
-                         "1425 images/s, 4: 1344): consecutive batches alternate between this many HIP streams, each with its own copy "
+                    help="steps in flight (default 3; 4 for per-GPU batches of at most 16 images): consecutive batches alternate between this many HIP streams, each with its own copy "
                          "of the plan's buffers, so the decode / SMPL tail of one batch (small grids) overlaps the network of "
                          "the next.  Same launches, same work per step; 1 = strictly one batch at a time")
     ap.add_argument("--offset-scale", type=float, default=0.5,
@@ -568,7 +591,7 @@ def main():
     # every image of the job is a different synthetic image (image i of the global batch is a pure function of i)
     images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317, first=lo)).to(dev)
 
-    nslot = max(1, args.pipeline if args.pipeline is not None else (3 if args.arch == "hourglass" else 2))
+    nslot = max(1, args.pipeline if args.pipeline is not None else steps_in_flight_default(args.arch, batch))
     if args.streams > 1 and args.pipeline is None:
         nslot = 1              # sub-batch streams and plan slots are two uses of the same idea: combined only on request
     use_graph = dla and args.graph == 1 and args.streams <= 1

@@ -226,6 +226,29 @@ def test_dcn_tiles_with_more_far_samples_than_patch_slots_are_deterministic(dtyp
         assert torch.equal(first, built.run()), built.name
 
 
+def test_dcn_bf16_input_beyond_the_fp16_range_is_clamped_not_overflowed():
+    # bf16 plans sample from an fp16 apron: a bf16 activation beyond +-65504 is CLAMPED while it is staged (v_med3_f32 in
+    # SE<bf16_t>::cvt) -- in the LDS apron, in the patch pixels and in pass 2.  Driven past the range here: the
+    # result must equal the oracle's on the clipped input (no inf / nan), for samples inside and outside the apron.
+    B, Ci, Co, H, W = 1, 64, 64, 24, 24
+    x = bf16_round(rnd("x", (B, Ci, H, W)) * 1.0e5)                   # ~35 % of the values beyond 65504
+    assert float((x.abs() > 65504).float().mean()) > 0.2
+    a = float(np.sqrt(3.0 / (Ci * 9)))
+    w = (rnd("w", (Co, Ci, 3, 3)) * (1.5 / np.sqrt(Ci * 9))).half().float()
+    b = rnd("b", (Co,))
+    wo = (rnd("wo", (27, Ci, 3, 3)) * (a * 6.0e-5)).half().float()      # offsets of a few pixels on inputs of 1e5
+    bo = rnd("bo", (27,), -0.1, 0.1)
+    for kind in ("stream", "fused"):
+        built = dcn_fused_op(kind, x, w, b, wo, bo, "bf16", 0)
+        got = built.run()
+        assert bool(torch.isfinite(got).all()), built.name
+        # the offset convolution sees the clamped input too (it reads the same apron)
+        ref, om = dcn_fused_reference(x.clamp(-65504.0, 65504.0), w, b, wo, bo)
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 1.2e-2 * scale, (built.name, float((got - ref).abs().max()), scale)
+        assert float((om[:, :18].abs() > 1.0).float().mean()) > 0.05      # (some samples do leave their pixel)
+
+
 def test_dcn_f16_stream_dispatch():
     names = {c: _dcn_built(c)[5].name for c in DCN_CASES if c[0] == "stream" and c[1] == "f16"}
     for c, n in names.items():
