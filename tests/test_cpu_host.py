@@ -117,6 +117,20 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     assert line["config"]["global_batch"] == 10 and line["dry_run"] is True and line["scaling"] == "weak"
 
 
+def test_bench_strong_scaling_mode_splits_one_batch_gloo_dry_run():
+    # `--global-batch G`: ONE batch of G images per step for the whole job, rank r takes shard_batch(G, r, world) -- the
+    # reference's DataParallel scatter (trains/trainer.py:176; SURVEY 8e: 64 -> 8 per GPU).  Uneven split (9 over 2 ranks: 5 + 4):
+    # the padded fixed-size all-gather and the pad-row removal are the real code; the line says "strong".
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run", "--global-batch", "9"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert line["config"]["global_batch"] == 9 and line["config"]["batch_per_gpu"] == 5       # rank 0's share
+
+
 def test_flip_helpers_match_the_reference_semantics():
     # models/utils.py:29-51 (flip test): host helpers (torch, device-resident) vs the numpy restatement
     import numpy as np
