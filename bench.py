@@ -395,7 +395,9 @@ def steps_in_flight_default(arch_name, batch):
     """3 (batch 64: 8420 / 8539 / 8537 images/s at 2 / 3 / 4 steps in flight, same box); small per-GPU shards (<= 16 images: grids
     of a few hundred workgroups) keep 4 so that the launches of different steps fill the CUs (batch 8: 3792 / 5525 / 6577 / 7090
     images/s at 1 / 2 / 3 / 4)."""
-    return 4 if (batch <= 16 and arch_name == "dla_34") else 3
+    if arch_name != "dla_34":
+        return 4                 # Hourglass-104 16 x 512^2: 1476 / 1516 / 1495 images/s at 3 / 4 / 6; ResNet-101-DCN 32 x 768^2: 2672 / 2750 / 2772 at 2 / 3 / 4
+    return 4 if batch <= 16 else 3
 
 
 def make_step(det, images, nslot, world, n_global, dev, graph=False):
@@ -494,7 +496,7 @@ def other_archs(args, dev, steps=5):
     """The per-GPU shards of BASELINE configs[3] / [4] (what `--arch hourglass` / `--arch resdcn_101` time), a few steps each
     after the headline measurement, so that the driver's one command observes them too: network + decode, no SMPL stage."""
     out = {}
-    for name, batch, size, dtype, nslot in (("hourglass", 16, 512, "bf16", 3), ("resdcn_101", 32, 768, "f16", 2)):
+    for name, batch, size, dtype, nslot in (("hourglass", 16, 512, "bf16", 4), ("resdcn_101", 32, 768, "f16", 4)):
         try:
             det, opt, _, gflop = build_detector(name, dtype, size, args, dev)
             images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317)).to(dev)

@@ -288,7 +288,7 @@ def test_bench_plan_kernels_are_all_covered():
     tested = {_conv2_built(c)[4].name for c in CONV2_CASES} | {_dcn_built(c)[5].name for c in DCN_CASES}
     tested |= test_gpu_conv.conv_case_kernel_names("bf16") | test_gpu_conv.gemm1_case_kernel_names()
     single = ("stem3_kernel", "heads_kernel<", "maxpool_kernel<", "upadd_kernel<", "copy_kernel<")
-    for batch in (64, 32, 8):       # 8: the shard one GPU of eight gets from the headline batch (bench.py --global-batch 64)
+    for batch in (64, 32, 16, 8):   # 16 / 8: the shards one GPU of four / eight gets from the headline batch (bench.py --global-batch 64)
         names = _plan_kernel_names(batch)
         missing = sorted(n for n in names if n not in tested and not n.startswith(single))
         assert not missing, "batch %d: no per-op parity case dispatches to %s" % (batch, missing)
