@@ -180,14 +180,14 @@ def dcn_apron_stats(det, images2, dev):
     cfgs = []                      # (margin, patch slots) per DeformConv launch
     for op in fused.ops:
         name = kernel_name(op)
-        if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_STREAM, _lib.OP_UPDCN_STREAM):
+        if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_STREAM):
             m = re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+), \d+, \w+, (\d+)", name) or re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+)", name)
             if m is None:
                 return {"error": "unrecognised DeformConv kernel name %r" % name}
             cfgs.append((int(m.group(1)), int(m.group(2)) if m.lastindex >= 2 else 0))
         elif op.kind in (_lib.OP_DCN_FUSED_F16, _lib.OP_UPDCN_F16):
             cfgs.append((1 if re.match(r"dcn4_kernel<\d+, \d+, 1,", name) else 2, 0))
-    twin = Plan(eng.pw, B, H, W, **dict(eng._flags(), fuse_offsets=False, fuse_updcn3=False))
+    twin = Plan(eng.pw, B, H, W, **dict(eng._flags(), fuse_offsets=False))
     twin.op_array[0].in_ = images2.data_ptr()
     twin.run()
     torch.cuda.synchronize()
@@ -501,7 +501,7 @@ def other_archs(args, dev, steps=5):
             det, opt, _, gflop = build_detector(name, dtype, size, args, dev)
             images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317)).to(dev)
             step, _ = make_step(det, images, nslot, 1, batch, dev)
-            dt = time_steps(step, steps, 2)
+            dt = time_steps(step, steps, nslot + 1)          # (every slot's plan is lowered inside the warm-up)
             out[name] = {"images_per_s": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "batch_per_gpu": batch,
                          "size": size, "dtype": dtype, "steps": steps, "steps_in_flight": nslot,
                          "model_tflops": round(gflop * batch * steps / dt / 1e3, 1)}
@@ -529,6 +529,11 @@ def main():
                     help="1: replay every step as one hipGraph (detector.run(graph=True)); 0 (default): issue every launch from Python. "
                          "Measured: no gain -- batch 8, 1 / 2 / 3 steps in flight: 3792 / 5526 / 6373 images/s with graphs, 3760 / 5512 / "
                          "6320 without; batch 64: 8180 vs 8320 (the host issues a step faster than the GPU runs it, even at 8 images)")
+    ap.add_argument("--dcn-margin", default="auto", choices=["narrow", "wide", "auto"],
+                    help="DeformConv apron: narrow = margin 2 (fastest while offsets are small), wide = margin 4 on the packed apron for "
+                         "every layer, auto (default; bf16 DLA-34 plans) = per layer from a calibration pass on the first two images, outside "
+                         "the timed region (DLAEngine.calibrate_dcn_margins).  Same box, images/s at --offset-scale 0.5 / 1.0 / 2.0: narrow "
+                         "8310 / 6831 / 5768, wide 7880 / 7143 / 6095, auto 8301 / 7340 / 6082")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the records measured after the timed region (shard_sweep, parity_mode, other_archs)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
@@ -592,6 +597,12 @@ def main():
         setattr(eng, name, int(val))
     # every image of the job is a different synthetic image (image i of the global batch is a pure function of i)
     images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317, first=lo)).to(dev)
+    dcn_wide_layers = None
+    if args.dcn_margin == "wide":
+        eng.dcn_wide_margin = 1
+    elif args.dcn_margin == "auto" and args.dtype == "bf16" and dla:
+        shares = eng.calibrate_dcn_margins(images[:2].contiguous())        # (setup, outside the timed region: two images through the unfused twin)
+        dcn_wide_layers = sorted(eng.pw.dcn_wide)
 
     nslot = max(1, args.pipeline if args.pipeline is not None else steps_in_flight_default(args.arch, batch))
     if args.streams > 1 and args.pipeline is None:
@@ -654,7 +665,8 @@ def main():
                        "batch_per_gpu": batch, "global_batch": n_global, "K": 100,
                        "smpl_people_per_image": args.people if dla else 0, "conv_gflop_per_image": round(gflop_img, 2),
                        "parallelism": "dp%d (image shards, one all-gather of dets)" % world,
-                       "steps_in_flight": nslot, "hip_graph": bool(use_graph),
+                       "steps_in_flight": nslot, "hip_graph": bool(use_graph), "dcn_margin": args.dcn_margin,
+                       "dcn_wide_layers": dcn_wide_layers,
                        "images": "%d distinct synthetic images (h3d_amd.synth.synth_image_batch, seed 317)" % n_global,
                        "weights": "synthetic (h3d_amd.synth, seed 0, gain %s, offset_scale %g)"
                                   % ("%g" % args.weight_gain if dla else "per arch", args.offset_scale)},

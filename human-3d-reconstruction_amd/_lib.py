@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libh3d_hip.so")
 H3D_F32, H3D_BF16, H3D_F16 = 0, 1, 2
 OP_STEM, OP_CONV, OP_DCN, OP_MAXPOOL, OP_UPADD, OP_COPY, OP_HEADS, OP_DCN_V1, OP_DCN_FUSED = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OP_CONV_STREAM, OP_DCN_FUSED_F16, OP_DCN_FUSED_STREAM, OP_STEM3, OP_UPDCN_F16 = 10, 11, 12, 13, 14
-OP_IM2COL, OP_MAXPOOL3, OP_DEPTH2SPACE, OP_UPDCN_STREAM = 15, 16, 17, 18
+OP_IM2COL, OP_MAXPOOL3, OP_DEPTH2SPACE = 15, 16, 17
 HEADS_MAX = 16
 OUT_NHWC, OUT_NCHW_F32, OUT_NHWC_F32, OUT_NHWC_F16 = 0, 1, 2, 3
 DCN_INPUT_NHWC, DCN_OUTPUT_NHWC = 1, 2

@@ -51,14 +51,20 @@ struct Dcn3Args {
 #define H3D_STAMP_B(s, k) do { } while (0)
 #endif
 
-template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0>
+// PK ("packed" apron, round 3: the wide-margin variants): 32 B per pixel, no pad bytes, rows of HH * 32 B; the 16-byte half a
+// lane-half reads is selected by the ROW parity (half' = half ^ (row & 1)), which keeps the 16-lane ds_read_b128 groups of the
+// offset convolution on 16 distinct bank slots (rows are an even number of 16-byte slots) -- a margin-4 apron (26 x 26 pixels)
+// then takes 21.6 KB where the padded margin-2 one takes 28 KB, so the wide margin still fits two workgroups per CU.  Corner
+// (y+1, x) of a sample at byte offset o is (o ^ 16) + RBH.
+template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0, bool PK = false>
 struct Dcn3Cfg {
     static constexpr int ES = sizeof(T);
     static constexpr int SS = SE<T>::SS;
     static constexpr int HH = 16 + 2 + 2 * MARGIN;
-    static constexpr int SBH = CK * SS + 16;
-    static constexpr int RBH = ((HH * SBH + 255) / 256) * 256;   // 256 B-aligned rows: the 2-row x 16-px gather of a
+    static constexpr int SBH = PK ? CK * SS : CK * SS + 16;
+    static constexpr int RBH = PK ? HH * SBH : ((HH * SBH + 255) / 256) * 256;   // 256 B-aligned rows: the 2-row x 16-px gather of a
                                                                  // 16-lane ds_read_b128 group then covers 16 distinct 16-B slots
+    static_assert(!PK || (CK == 16 && SS == 2 && WDMA && NP > 0 && (RBH / 16) % 2 == 0 && (RBH & 16) == 0), "packed apron: fp16 samples, 16-channel stages");
     static constexpr int WB = 9 * CK * SS + 16;
     static constexpr int BN = 32 * MT;
     static constexpr int THREADS = 512;
@@ -105,13 +111,13 @@ __device__ __forceinline__ u32x4 dcn3_patch_corner(const char *img, int bytes, i
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
 
-template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false, int NP = 0>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
+template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false, int NP = 0, bool PK = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
 __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dcn3Args a)
 {
-    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP>;
+    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP, PK>;
     using X = SE<T>;
     constexpr int ES = C::ES, SS = C::SS;
-    __shared__ __attribute__((aligned(16))) char smem[C::LDS];
+    __shared__ __attribute__((aligned(256))) char smem[C::LDS];
     char *s_w = smem + C::PB + C::LDS_H;       // filters of stage buffer 0 (pass 2) / of the WDMA ring
 
     const int tid = threadIdx.x;
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             if (i < NH) {
                 const int v = i % C::VPP, pix = i / C::VPP;
                 const int iy = pix / C::HH, ix = pix - iy * C::HH;
-                *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + v * 16) = X::convert16(stg[j]);
+                *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + ((PK ? (v ^ (iy & 1)) : v) * 16)) = X::convert16(stg[j]);
             } else if (i < NH + NW) {
                 const int q0 = i - NH;
                 const int row = q0 / WV, q = q0 - row * WV;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             const int iy = pix / C::HH, ix = pix - iy * C::HH;
             const int gy = hy0 + iy, gx = hx0 + ix;
             avoff[j] = (i < NH && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? ((gy * a.W + gx) * a.in_cs) * ES + v * 16 : 0x7ffffff0;
-            adst[j] = i < NH ? iy * C::RBH + ix * C::SBH + v * 16 : -1;
+            adst[j] = i < NH ? iy * C::RBH + ix * C::SBH + ((PK ? (v ^ (iy & 1)) : v) * 16) : -1;
         }
     }
     [[maybe_unused]] const int img_bytes = (int)((size_t)a.H * a.W * a.in_cs * ES);
@@ -252,7 +258,10 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     f32x16 aoffs;   // rows (i&3)+8(i>>2)+4h of the permuted offset conv for this lane's pixel
 #pragma unroll
     for (int i = 0; i < 16; ++i) aoffs[i] = 0.f;
-    const int bconv = (MARGIN + py) * C::RBH + (MARGIN + px) * C::SBH + 8 * h * SS;   // tap (0,0) of the plain conv
+    // tap (0,0) of the plain conv (PK: rows dy = 0, 2 share the lane half's position, dy = 1 has the other one)
+    const int bconv = PK ? (MARGIN + py) * C::RBH + (MARGIN + px) * C::SBH + ((h ^ ((MARGIN + py) & 1)) << 4)
+                         : (MARGIN + py) * C::RBH + (MARGIN + px) * C::SBH + 8 * h * SS;
+    [[maybe_unused]] const int bconv1 = (bconv ^ 16) + C::RBH;
     auto computeA = [&](int s) {
         const char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
                 const typename X::frag fa = X::lds(s_w + aoff + (tap * CK + kk * 16) * SS);
-                const typename X::frag fb = X::lds(s_h + bconv + dy * C::RBH + dx * C::SBH + kk * 16 * SS);
+                const typename X::frag fb = X::lds(s_h + ((PK && dy == 1) ? bconv1 : bconv + dy * C::RBH) + dx * C::SBH + kk * 16 * SS);
                 if (H3D_DBG(a) & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, fb);
             }
         }
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                 const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
                 g = X::make_geo(w4, dcn2_sigmoid(aoffs[3 * u + 2]));
                 if (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH) {
-                    off = ry * C::RBH + rx * C::SBH;
+                    off = ry * C::RBH + rx * C::SBH + (PK ? ((ry & 1) << 4) : 0);      // (PK: half 0's bytes; half 1 reads off ^ 16)
                 } else {
                     want = true;
                 }
@@ -389,10 +398,10 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             const int o_off = __shfl_xor(my_off[u], 32);
             const typename X::geo o_geo = X::shfl_xor32(my_geo[u]);
             // tap u (u < 5) belongs to half 0, tap 5 + u (u < 4) to half 1
-            boff[u] = (h == 0 ? my_off[u] : o_off) + 8 * h * SS;
+            boff[u] = PK ? ((h == 0 ? my_off[u] : o_off) ^ (h << 4)) : (h == 0 ? my_off[u] : o_off) + 8 * h * SS;
             geo[u] = (h == 0) ? my_geo[u] : o_geo;
             if (u < 4) {
-                boff[5 + u] = (h == 1 ? my_off[u] : o_off) + 8 * h * SS;
+                boff[5 + u] = PK ? ((h == 1 ? my_off[u] : o_off) ^ (h << 4)) : (h == 1 ? my_off[u] : o_off) + 8 * h * SS;
                 geo[5 + u] = (h == 1) ? my_geo[u] : o_geo;
             }
         }
@@ -476,10 +485,11 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             typename X::frag v[2][4];
             auto gather = [&](int tap, int q) {
                 const char *p00 = s_h + boff[tap];
+                const char *p10 = PK ? s_h + ((boff[tap] ^ 16) + C::RBH) : p00 + C::RBH;
                 v[q][0] = X::lds(p00);
                 v[q][1] = X::lds(p00 + C::SBH);
-                v[q][2] = X::lds(p00 + C::RBH);
-                v[q][3] = X::lds(p00 + C::RBH + C::SBH);
+                v[q][2] = X::lds(p10);
+                v[q][3] = X::lds(p10 + C::SBH);
             };
             gather(0, 0);
 #pragma unroll
@@ -501,14 +511,15 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         for (int tap = 0; tap < 9; ++tap) {
             typename X::frag fb[CK / 16];
             const char *p00 = s_h + boff[tap];
+            const char *p10 = PK ? s_h + ((boff[tap] ^ 16) + C::RBH) : p00 + C::RBH;
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
                 if (H3D_DBG(a) & 2) { fb[kk] = X::lds(p00 + kk * 16 * SS); continue; }
                 typename X::frag v[4];
                 v[0] = X::lds(p00 + kk * 16 * SS);
                 v[1] = X::lds(p00 + C::SBH + kk * 16 * SS);
-                v[2] = X::lds(p00 + C::RBH + kk * 16 * SS);
-                v[3] = X::lds(p00 + C::RBH + C::SBH + kk * 16 * SS);
+                v[2] = X::lds(p10 + kk * 16 * SS);
+                v[3] = X::lds(p10 + C::SBH + kk * 16 * SS);
                 fb[kk] = X::blend(v, geo[tap]);
             }
 #pragma unroll
@@ -744,10 +755,11 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     H3D_STAMP(blockIdx.x, 5);
 }
 
-template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0>
+template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0, bool PK = false>
 static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
 {
-    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP>;
+    using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP, PK>;
+    static_assert(!(WDMA && MT <= 2) || C::LDS * 2 <= 160 * 1024, "two workgroups per CU");
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     Dcn3Args a = a0;
     a.tiles_x = cdiv(a.W, 16);
@@ -761,20 +773,20 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (sizeof(T) == 2 && MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel("dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", h3d_tname<T>(), MT, CK, MARGIN, epi,
+    if (h3d_note_kernel(PK ? "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d, true>" : "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", h3d_tname<T>(), MT, CK, MARGIN, epi,
                         WDMA ? "true" : "false", NP))
         return H3D_OK;
     if constexpr (sizeof(T) == 2 && MT >= 2) {
         if (epi == 2) {
-            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2, WDMA, NP>), grid, dim3(C::THREADS), 0, st, a);
+            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2, WDMA, NP, PK>), grid, dim3(C::THREADS), 0, st, a);
             H3D_CHECK_LAUNCH("dcn3_kernel");
             return H3D_OK;
         }
     }
     if (epi == 1)
-        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1, WDMA, NP>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1, WDMA, NP, PK>), grid, dim3(C::THREADS), 0, st, a);
     else
-        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0, WDMA, NP>), grid, dim3(C::THREADS), 0, st, a);
+        hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0, WDMA, NP, PK>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("dcn3_kernel");
     return H3D_OK;
 }
@@ -793,6 +805,15 @@ static int launch_dcn3_lowp(const h3d_op &op, const Dcn3Args &a, bool wdma, hipS
             if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 1, true>(a, st);
             if (op.Cout <= 64) return launch_dcn3_cfg<T, 2, 16, 1, true>(a, st);
             return launch_dcn3_cfg<T, 4, 16, 2, true>(a, st);
+        }
+        const long wgs4w = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
+        if (op.reserved & 0x8000) {
+            // wide margin on the packed apron (engine.dcn_wide_margin / DLAEngine.calibrate_dcn_margins: layers whose offsets send
+            // many samples outside a margin-2 apron): margin 4 at two workgroups per CU (73 KB).  The 128-channel variant has
+            // margin 4 anyway (a margin-6 packed apron needs a fourth staging register set: 14 spilled registers)
+            if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 4, true, 256, true>(a, st);
+            if (op.Cout <= 64 || ((wgs4w < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400))) return launch_dcn3_cfg<T, 2, 16, 4, true, 256, true>(a, st);
+            return launch_dcn3_cfg<T, 4, 16, 4, true, 256>(a, st);
         }
         // <= 64 output channels: margin-2 apron, 16-channel stages, <= 128 VGPRs and 78 KB of LDS -> two workgroups
         // (16 waves) per CU, one computing while the other waits at its stage barriers; 256 patch slots per tile.

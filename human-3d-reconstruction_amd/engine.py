@@ -65,6 +65,7 @@ class PackedWeights:
         if missing:
             raise KeyError("state_dict is missing %d keys, e.g. %s" % (len(missing), missing[:3]))
         self.t = {}
+        self.dcn_wide = set()       # DeformConv layers (state_dict prefixes) that run the wide-margin variant (calibrate_dcn_margins)
         if arch_name == "resdcn101":
             # the DCN of up-sampling stage i is `deconv_layers.{6i}` (weight, bias, conv_offset_mask.*) followed by the
             # BatchNorm `deconv_layers.{6i+1}`: alias them to the key pattern the DeformConv lowering reads
@@ -87,6 +88,7 @@ class PackedWeights:
         self.head_conv, self.arch = 0, "bare"
         self.sd = {k: _t(v) for k, v in tensors.items()}
         self.t = {}
+        self.dcn_wide = set()
         return self
 
     def _fold(self, w, b, bn):
@@ -331,7 +333,9 @@ class Plan:
         fuse_upnode=True,      # False: up-sample + add always as its own launch in front of the 64-channel node DeformConvs
         fuse_upnode_min_f=2,   # ... from this up-sampling factor.  Same box, batch 64, up-sampling + node over the five layers:
                                # 1.234 ms as two launches each, 1.194 with the 4x layer folded, 1.156 with all five
-        fuse_updcn3=False,     # True: IDAUp's up-sample + add folded into the apron staging of the node DeformConv (csrc/dcn3.hip UP)
+        dcn_wide_margin=0,     # 1: every fused DeformConv (<= 64-channel workgroups) on the margin-4 packed apron (csrc/dcn3.hip PK): slower
+                               # while the offsets stay small (more apron to stage), far faster once many samples of a tile leave a
+                               # margin-2 apron; per-layer choices from a calibration batch: DLAEngine.calibrate_dcn_margins
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
@@ -356,6 +360,7 @@ class Plan:
         self.dtype = pw.dtype
         self.es = 2 if pw.dtype in LOWP else 4
         self.ops = []
+        self.dcn_layers = []    # (state_dict prefix, op index) of the fused DeformConvs
         self.keep = []          # tensors the ops point into
         self.images = torch.empty(B, 3, H, W, dtype=torch.float32, device=pw.device)
         self.outputs = {}
@@ -520,9 +525,12 @@ class Plan:
             wimg, woimg, bias, cout, cin, rows = self.pw.dcn_stream(p, ck)
             if out is None:
                 out = self._alloc(x.H, x.W, cout)
+            wide = self.dcn_patches and cin % 32 == 0 and (self.dcn_wide_margin or p in self.pw.dcn_wide)
             self._op(_lib.OP_DCN_FUSED_STREAM, in_=x.ptr, in2=woimg.data_ptr(), w=wimg.data_ptr(), bias=bias.data_ptr(),
                      out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
-                     stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows, reserved=0 if self.dcn_patches else 0x1000)
+                     stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows,
+                     reserved=(0x8000 if wide else 0) if self.dcn_patches else 0x1000)
+            self.dcn_layers.append((p, len(self.ops) - 1))
             return out
         if self.pw.use_dcn and self.fuse_offsets:
             wp, bp, cout, cin, k, rows = self.pw.conv(p + ".conv.weight", p + ".conv.bias", p + ".actf.0", as_half=True)
@@ -838,4 +846,55 @@ class DLAEngine:
             self._keepalive[slot] = images
             return full
 
+    def calibrate_dcn_margins(self, images, max_over_frac=0.05):
+        """Choose per DeformConv layer between the margin-2 apron (default) and the wide-margin variant from a calibration batch:
+        the unfused twin of the plan is run on `images` (its conv_offset_mask outputs are the offsets the fused kernels compute
+        internally), and a layer whose share of 16x16 tiles with more far samples than patch slots exceeds `max_over_frac`
+        is switched to the wide margin (those tiles otherwise run the slow pass 2).  bf16 / f32 plans (the unfused path has no
+        fp16 kernels).  Returns {layer: share}.  Plans built before the call are dropped."""
+        _lib.require_cuda(images)
+        if self.pw.dtype == "f16":
+            raise RuntimeError("calibrate_dcn_margins: run it on a bf16 engine (same weights) and copy `pw.dcn_wide`")
+        B, _, H, W = images.shape
+        with torch.cuda.device(self.device):
+            twin = Plan(self.pw, B, H, W, **dict(self._flags(), fuse_offsets=False))
+            twin.op_array[0].in_ = images.float().contiguous().data_ptr()
+            twin.run()
+            torch.cuda.synchronize()
+            probe = Plan(self.pw, B, H, W, **self._flags())
+            names = [p for p, _ in probe.dcn_layers]
+            dcn_ops = [op for op in twin.ops if op.kind == _lib.OP_DCN]
+            assert len(dcn_ops) == len(names), (len(dcn_ops), len(names))
+            shares = {}
+            for p, op in zip(names, dcn_ops):
+                om = [t for t in twin.keep if torch.is_tensor(t) and t.data_ptr() == op.in2][0]      # [B,h,w,32] fp32
+                shares[p] = float(_tiles_over_slots(om, margin=2, slots=256))
+            self.pw.dcn_wide = {p for p, v in shares.items() if v > max_over_frac}
+        self.plans.clear()
+        return shares
+
     __call__ = forward
+
+
+def _tiles_over_slots(om, margin, slots):
+    """Share of 16x16 tiles of an offset/mask map [B,h,w,>=18] (channel 2t = dh, 2t+1 = dw of tap t) with more than `slots`
+    samples whose bilinear corners leave the tile's apron of the given margin -- the test of csrc/dcn3.hip, on the device."""
+    Bn, h, w = om.shape[0], om.shape[1], om.shape[2]
+    dev = om.device
+    ys = torch.arange(h, device=dev, dtype=torch.float32).view(1, h, 1)
+    xs = torch.arange(w, device=dev, dtype=torch.float32).view(1, 1, w)
+    y0, x0 = ys - ys % 16 - 1 - margin, xs - xs % 16 - 1 - margin
+    HH = 18 + 2 * margin
+    miss = torch.zeros(Bn, h, w, device=dev)
+    for t in range(9):
+        ti, tj = divmod(t, 3)
+        h_im, w_im = ys - 1 + ti + om[..., 2 * t], xs - 1 + tj + om[..., 2 * t + 1]
+        inside = (h_im > -1) & (w_im > -1) & (h_im < h) & (w_im < w)
+        ry, rx = torch.floor(h_im) - y0, torch.floor(w_im) - x0
+        ok = (ry >= 0) & (ry + 1 < HH) & (rx >= 0) & (rx + 1 < HH)
+        miss += (inside & ~ok).float()
+    th, tw = -(-h // 16), -(-w // 16)
+    pad = torch.zeros(Bn, th * 16, tw * 16, device=dev)
+    pad[:, :h, :w] = miss
+    per_tile = pad.view(Bn, th, 16, tw, 16).sum(dim=(2, 4))
+    return (per_tile > slots).float().mean()

@@ -109,6 +109,41 @@ def test_f16_plan_saturates_instead_of_overflowing():
         assert bool(torch.isfinite(out[k]).all()), k
 
 
+def test_dcn_wide_margin_flag_and_calibration():
+    # engine.dcn_wide_margin = 1: every <= 64-channel-workgroup DeformConv on the margin-4 packed apron -- bit-identical heads while
+    # no tile overflows its patch slots (small offsets).  calibrate_dcn_margins: weights with LARGE offsets (offset_scale 2:
+    # mean |offset| 6 px) make it pick the wide margin for the layers whose tiles overflow; the network then still matches
+    # the oracle within the bf16 tolerance, and the plan runs the packed-apron kernels for exactly those layers.
+    from gpu_helpers import kernel_name
+    m, _ = _net(True, "bf16")
+    xs = torch.from_numpy(synth.synth_images(2, 128, 128, seed=7)).to(DEV)
+    on, off = _ab(m, xs, "dcn_wide_margin")
+    m.engine(xs.device).dcn_wide_margin = 0
+    m.engine(xs.device).plans.clear()
+    for k in HEADS:
+        assert torch.equal(on[k], off[k]), k
+    sd = synth.synth_state_dict(arch.state_dict_shapes(HEADS, True), seed=0, offset_scale=2.0, gain=1.25)
+    m2 = model.dla_net(HEADS, dtype="bf16")
+    m2.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m2.to(DEV).eval()
+    x2 = synth.synth_images(2, 256, 256, seed=7)
+    eng = m2.engine(torch.device(DEV))
+    before = {k: v.clone() for k, v in m2(torch.from_numpy(x2).to(DEV))[0].items()}
+    shares = eng.calibrate_dcn_margins(torch.from_numpy(x2).to(DEV))
+    assert len(shares) == 16 and eng.pw.dcn_wide and max(shares.values()) > 0.05, shares
+    after = m2(torch.from_numpy(x2).to(DEV))[0]
+    names = [kernel_name(op) for op in eng.plan(2, 256, 256).ops if op.kind == 12]
+    assert sum(n.endswith(", true>") for n in names) == len([p for p in eng.pw.dcn_wide]), (names, eng.pw.dcn_wide)
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(torch.from_numpy(x2))[0]
+        emu = odla.DLAOracle(sd, HEADS, use_dcn=True, emulate_bf16=True)(torch.from_numpy(x2))[0]
+    for k in HEADS:
+        e_b = float((before[k].cpu() - ref[k]).abs().max())
+        e_a = float((after[k].cpu() - ref[k]).abs().max())
+        t = float((emu[k] - ref[k]).abs().max())
+        assert e_a <= 1.5 * t + 1e-3 and e_b <= 1.5 * t + 1e-3, (k, e_b, e_a, t)
+
+
 def test_keep_res_frame_larger_than_the_lds_map_end_to_end():
     # `--keep_res` pads a frame to (h | 31) + 1 (datasets/coco.py:160-163): 1280 x 720 -> 1280 x 736 -> a 320 x 184 output map,
     # 58880 pixels > the 36864 the one-workgroup top-k holds in LDS.  Network (f32 plan) vs the oracle, and the detector's decode

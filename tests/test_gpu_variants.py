@@ -148,6 +148,16 @@ DCN_CASES = [
     ("stream", "f16", 0, 1, 64, 32, 20, 20, 12.0),         # dcn3<f16,1,16,2,WDMA,256>
     ("stream", "f16", 0x400, 1, 128, 128, 16, 32, 3.0),    # dcn3<f16,4,16,4,WDMA,256>: margin-4 apron
     ("stream", "f16", 0x400, 1, 256, 256, 24, 24, 8.0),    #   (ResNet-101-DCN's first up-sampling stage in miniature)
+    # 0x8000: the wide-margin variants on the packed apron (margin 4 at two workgroups per CU; engine.dcn_wide_margin / calibration)
+    ("stream", "bf16", 0x8000, 2, 128, 64, 24, 40, 0.5),   # dcn3<bf16,2,16,4,WDMA,256,PK>
+    ("stream", "bf16", 0x8000, 1, 256, 64, 16, 32, 3.0),
+    ("stream", "bf16", 0x8000, 2, 64, 64, 40, 24, 6.0),    #   ... patches AND pass 2
+    ("stream", "bf16", 0x8000, 1, 64, 64, 16, 16, 40.0),
+    ("stream", "bf16", 0x8000, 1, 64, 32, 20, 20, 12.0),   # dcn3<bf16,1,16,4,WDMA,256,PK>
+    ("stream", "bf16", 0x8000, 1, 256, 256, 16, 16, 3.0),  # small grid: 64-channel workgroups, wide margin
+    ("stream", "bf16", 0x8400, 1, 128, 128, 16, 32, 3.0),  # the 128-channel variant has margin 4 anyway
+    ("stream", "f16", 0x8000, 2, 128, 64, 24, 40, 3.0),    # dcn3<f16,2,16,4,WDMA,256,PK>
+    ("stream", "f16", 0x8000, 1, 64, 32, 20, 20, 12.0),
     # 0x4000: csrc/dcn5.hip (apron AND filters by LDS-DMA; measured slower, kept selectable: DESIGN.md 2.2)
     ("stream", "f16", 0x4000, 2, 128, 64, 24, 40, 0.5),    # dcn5<2,2,.,256>
     ("stream", "f16", 0x4000, 1, 256, 64, 16, 32, 3.0),
@@ -249,10 +259,23 @@ def test_dcn_bf16_input_beyond_the_fp16_range_is_clamped_not_overflowed():
         assert float((om[:, :18].abs() > 1.0).float().mean()) > 0.05      # (some samples do leave their pixel)
 
 
+def test_dcn_wide_margin_variant_is_bit_identical_while_no_tile_overflows():
+    # A sample inside the apron is blended from LDS in phase B; the same sample outside a narrower apron is blended by the same
+    # fp16 chain when its patch pixel is filled and then read back with weights (1, 0, 0, 0): the same value.  So the margin-2 and the
+    # margin-4 (packed apron) variants agree bit for bit as long as neither has a tile with more far samples than patch slots.
+    for dtype in ("bf16", "f16"):
+        for shape in ((2, 128, 64, 40, 56, 1.5), (1, 64, 64, 48, 48, 2.5), (1, 64, 32, 24, 40, 1.5)):
+            narrow = _dcn_built(("stream", dtype, 0) + shape)[5]
+            wide = _dcn_built(("stream", dtype, 0x8000) + shape)[5]
+            assert ", 4, " in wide.name and wide.name.endswith(", true>") and not narrow.name.endswith(", true>"), (narrow.name, wide.name)
+            assert torch.equal(narrow.run(), wide.run()), (dtype, shape)
+
+
 def test_dcn_f16_stream_dispatch():
     names = {c: _dcn_built(c)[5].name for c in DCN_CASES if c[0] == "stream" and c[1] == "f16"}
     for c, n in names.items():
         assert n.startswith("dcn5_kernel<" if c[2] & 0x4000 else "dcn3_kernel<f16_t"), (c, n)
+        assert n.endswith(", true>") == bool(c[2] & 0x8000 and not c[2] & 0x400), (c, n)
     assert {"dcn5_kernel<2, 2, 2, 256>", "dcn5_kernel<1, 2, 1, 256>", "dcn5_kernel<4, 4, 2, 256>"} <= set(names.values()), names
 
 
