@@ -529,10 +529,11 @@ def main():
                     help="1: replay every step as one hipGraph (detector.run(graph=True)); 0 (default): issue every launch from Python. "
                          "Measured: no gain -- batch 8, 1 / 2 / 3 steps in flight: 3792 / 5526 / 6373 images/s with graphs, 3760 / 5512 / "
                          "6320 without; batch 64: 8180 vs 8320 (the host issues a step faster than the GPU runs it, even at 8 images)")
-    ap.add_argument("--dcn-margin", default="auto", choices=["narrow", "wide", "auto"],
-                    help="DeformConv apron: narrow = margin 2 (fastest while offsets are small), wide = margin 4 on the packed apron for "
-                         "every layer, auto (default; bf16 DLA-34 plans) = per layer from a calibration pass on the first two images, outside "
-                         "the timed region (DLAEngine.calibrate_dcn_margins).  Same box, images/s at --offset-scale 0.5 / 1.0 / 2.0: narrow "
+    ap.add_argument("--dcn-margin", default="auto", choices=["narrow", "slots512", "wide", "auto"],
+                    help="DeformConv tile variant: narrow = margin 2, 256 patch slots (fastest while offsets are small), slots512 = margin 2 "
+                         "with 512 slots in two rounds, wide = margin 4 on the packed apron, each for every layer; auto (default; bf16 / f16 "
+                         "DLA-34 plans) = per layer, by timing the three on the job's own batch outside the timed region "
+                         "(DLAEngine.calibrate_dcn_margins).  Same box, images/s at --offset-scale 0.5 / 1.0 / 2.0: narrow "
                          "8310 / 6831 / 5768, wide 7880 / 7143 / 6095, auto 8301 / 7340 / 6082")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the records measured after the timed region (shard_sweep, parity_mode, other_archs)")
@@ -597,12 +598,15 @@ def main():
         setattr(eng, name, int(val))
     # every image of the job is a different synthetic image (image i of the global batch is a pure function of i)
     images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317, first=lo)).to(dev)
-    dcn_wide_layers = None
+    dcn_variants = None
     if args.dcn_margin == "wide":
         eng.dcn_wide_margin = 1
-    elif args.dcn_margin == "auto" and args.dtype == "bf16" and dla:
-        shares = eng.calibrate_dcn_margins(images[:2].contiguous())        # (setup, outside the timed region: two images through the unfused twin)
-        dcn_wide_layers = sorted(eng.pw.dcn_wide)
+    elif args.dcn_margin == "slots512":
+        eng.dcn_slots512 = 1
+    elif args.dcn_margin == "auto" and args.dtype in ("bf16", "f16") and dla:
+        eng.calibrate_dcn_margins(images)       # (setup, outside the timed region: every DeformConv op timed per variant on this batch)
+        names = {v: k for k, v in eng.DCN_VARIANTS.items()}
+        dcn_variants = {p: names[v] for p, v in sorted(eng.pw.dcn_variant.items())}
 
     nslot = max(1, args.pipeline if args.pipeline is not None else steps_in_flight_default(args.arch, batch))
     if args.streams > 1 and args.pipeline is None:
@@ -666,7 +670,7 @@ def main():
                        "smpl_people_per_image": args.people if dla else 0, "conv_gflop_per_image": round(gflop_img, 2),
                        "parallelism": "dp%d (image shards, one all-gather of dets)" % world,
                        "steps_in_flight": nslot, "hip_graph": bool(use_graph), "dcn_margin": args.dcn_margin,
-                       "dcn_wide_layers": dcn_wide_layers,
+                       "dcn_variants": dcn_variants,
                        "images": "%d distinct synthetic images (h3d_amd.synth.synth_image_batch, seed 317)" % n_global,
                        "weights": "synthetic (h3d_amd.synth, seed 0, gain %s, offset_scale %g)"
                                   % ("%g" % args.weight_gain if dla else "per arch", args.offset_scale)},

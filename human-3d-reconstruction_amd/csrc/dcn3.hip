@@ -86,7 +86,7 @@ struct Dcn3Cfg {
     static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // epilogue.h tile_epilogue_lds regions
     static constexpr int LDS = LDS_MAIN + LDS_DESC > LDS_EPI ? LDS_MAIN + LDS_DESC : LDS_EPI;
     static_assert(NP == 0 || (WDMA && sizeof(T) == 2), "patches: bf16 plans with DMA'd filters");
-    static_assert(NP * (CK * SS / 16) <= 512, "one 16-byte patch entry per thread");
+    static_assert(NP * (CK * SS / 16) <= 1024, "at most two 16-byte patch units per thread (the second one in a second fill round)");
 };
 
 // WDMA (bf16 plans): the filters are stage-major fp16 LDS images (H3D_OP_DCN_FUSED_STREAM) copied by LDS-DMA into a
@@ -412,6 +412,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     [[maybe_unused]] typename X::geo pgeo = X::zero_geo();
     [[maybe_unused]] bool phas = false;
     [[maybe_unused]] bool overflow = false;
+    [[maybe_unused]] int nsl2 = 0;                 // slots in use (workgroup-uniform); entries >= 512 / VPP are filled in a second round
     if constexpr (NP > 0) {
         __syncthreads();                                                 // the list is complete
         int nwant = 0;
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         }
         overflow = nwant > NP;                                           // workgroup-uniform: some sample found no slot
         const int nsl = min(nwant, NP);
+        nsl2 = nsl;
         const int ps = tid / C::VPP, pv = tid - ps * C::VPP;
         phas = ps < nsl;
         if (phas) {
@@ -458,6 +460,35 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             for (int k = 0; k < 4; ++k) v[k].v = __builtin_bit_cast(half8_t, X::convert16(pst[k]));
             const typename X::frag o = X::blend(v, pgeo);
             *reinterpret_cast<half8_t *>(s_h - C::PB + tid * 16) = o.v;      // entry tid/VPP, unit tid%VPP: PSLOT = VPP * 16
+        }
+    };
+
+    // NP > 256 (the packed-apron variants): a tile with more far samples than one round of 512 / VPP entries fills the rest in a
+    // SECOND round per stage -- entry 256 + tid / VPP, its constants re-read from the list (rare path: no registers kept for
+    // it), its four corner loads exposed (they are issued behind the barrier, ~2k cycles per stage) -- instead of sending
+    // those samples through pass 2, which costs the tile 3x its time
+    auto patch_round2 = [&](int s, char *s_h) {
+        if constexpr (NP * C::VPP > 512 && sizeof(T) == 2) {
+            constexpr int R = 512 / C::VPP;
+            if (nsl2 <= R) return;                                       // workgroup-uniform
+            const int ps = R + tid / C::VPP, pv = tid % C::VPP;
+            if (ps >= nsl2) return;
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(smem + C::LDS_MAIN + ps * 16);
+            const int hl = (int)d[0] >> 16, wl = (int)(short)(d[0] & 0xffffu);
+            typename X::geo g2;
+            g2.w01 = d[1]; g2.w23 = d[2];
+            const int base2 = ((hl * a.W + wl) * a.in_cs) * ES + pv * 16;
+            const int c0 = (s - nchunks) * CK;
+            typename X::frag v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = hl + (k >> 1), xx = wl + (k & 1);
+                const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                const int voff = base2 + ((k & 1) + (k >> 1) * a.W) * a.in_cs * ES;
+                v[k].v = __builtin_bit_cast(half8_t, X::convert16(dcn3_patch_corner(img, img_bytes, ok ? voff : 0x7ffffff0, c0 * ES)));
+            }
+            const typename X::frag o = X::blend(v, g2);
+            *reinterpret_cast<half8_t *>(s_h - C::PB + (R * C::VPP + tid) * 16) = o.v;
         }
     };
 
@@ -546,6 +577,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             H3D_STAMP_B(s, 1);
             store2(P);
             patch_commit(smem + C::PB);
+            patch_round2(s, smem + C::PB);
             __builtin_amdgcn_s_waitcnt(0x0f70);  // (the patch loads were the youngest: nothing older is pending either)
             H3D_STAMP_B(s, 2);
             __syncthreads();
@@ -818,11 +850,18 @@ static int launch_dcn3_lowp(const h3d_op &op, const Dcn3Args &a, bool wdma, hipS
         // <= 64 output channels: margin-2 apron, 16-channel stages, <= 128 VGPRs and 78 KB of LDS -> two workgroups
         // (16 waves) per CU, one computing while the other waits at its stage barriers; 256 patch slots per tile.
         // > 64: one workgroup per CU has the LDS for a margin-4 apron (26 x 26 pixels)
+        const long wgs4 = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
+        if (op.reserved & 0x10000) {
+            // experiment / candidate default: margin 2 on the PACKED apron (15 KB instead of 28) with 512 patch slots per tile, the second
+            // 256 filled in a second round per stage
+            if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 2, true, 512, true>(a, st);
+            if (op.Cout <= 64 || ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400))) return launch_dcn3_cfg<T, 2, 16, 2, true, 512, true>(a, st);
+            return launch_dcn3_cfg<T, 4, 16, 4, true, 512>(a, st);
+        }
         if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 2, true, 256>(a, st);
         if (op.Cout <= 64) return launch_dcn3_cfg<T, 2, 16, 2, true, 256>(a, st);
         // a layer whose 128-channel workgroups would leave CUs idle (16 x 16 maps at batch 64: 128 workgroups on 256 CUs)
         // runs 64-channel workgroups instead: twice the gather / blend work, on CUs that had nothing to do
-        const long wgs4 = (long)op.B * cdiv(op.H, 16) * cdiv(op.W, 16) * cdiv(op.Cout, 128);
         if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) return launch_dcn3_cfg<T, 2, 16, 2, true, 256>(a, st);
         return launch_dcn3_cfg<T, 4, 16, 4, true, 256>(a, st);
     }

@@ -65,7 +65,7 @@ class PackedWeights:
         if missing:
             raise KeyError("state_dict is missing %d keys, e.g. %s" % (len(missing), missing[:3]))
         self.t = {}
-        self.dcn_wide = set()       # DeformConv layers (state_dict prefixes) that run the wide-margin variant (calibrate_dcn_margins)
+        self.dcn_variant = {}       # DeformConv layer (state_dict prefix) -> csrc/dcn3.hip variant bits (DLAEngine.calibrate_dcn_margins)
         if arch_name == "resdcn101":
             # the DCN of up-sampling stage i is `deconv_layers.{6i}` (weight, bias, conv_offset_mask.*) followed by the
             # BatchNorm `deconv_layers.{6i+1}`: alias them to the key pattern the DeformConv lowering reads
@@ -88,8 +88,12 @@ class PackedWeights:
         self.head_conv, self.arch = 0, "bare"
         self.sd = {k: _t(v) for k, v in tensors.items()}
         self.t = {}
-        self.dcn_wide = set()
+        self.dcn_variant = {}
         return self
+
+    @property
+    def dcn_wide(self):
+        return {p for p, v in self.dcn_variant.items() if v == 0x8000}
 
     def _fold(self, w, b, bn):
         """conv(+bias) followed by eval BatchNorm `bn` -> (w', b')."""
@@ -333,6 +337,7 @@ class Plan:
         fuse_upnode=True,      # False: up-sample + add always as its own launch in front of the 64-channel node DeformConvs
         fuse_upnode_min_f=2,   # ... from this up-sampling factor.  Same box, batch 64, up-sampling + node over the five layers:
                                # 1.234 ms as two launches each, 1.194 with the 4x layer folded, 1.156 with all five
+        dcn_slots512=0,        # 1: margin 2 on the PACKED apron with 512 patch slots per tile (second 256 filled in a second round per stage)
         dcn_wide_margin=0,     # 1: every fused DeformConv (<= 64-channel workgroups) on the margin-4 packed apron (csrc/dcn3.hip PK): slower
                                # while the offsets stay small (more apron to stage), far faster once many samples of a tile leave a
                                # margin-2 apron; per-layer choices from a calibration batch: DLAEngine.calibrate_dcn_margins
@@ -525,11 +530,13 @@ class Plan:
             wimg, woimg, bias, cout, cin, rows = self.pw.dcn_stream(p, ck)
             if out is None:
                 out = self._alloc(x.H, x.W, cout)
-            wide = self.dcn_patches and cin % 32 == 0 and (self.dcn_wide_margin or p in self.pw.dcn_wide)
+            var = 0
+            if self.dcn_patches and cin % 32 == 0:
+                var = 0x8000 if self.dcn_wide_margin else 0x10000 if self.dcn_slots512 else self.pw.dcn_variant.get(p, 0)
             self._op(_lib.OP_DCN_FUSED_STREAM, in_=x.ptr, in2=woimg.data_ptr(), w=wimg.data_ptr(), bias=bias.data_ptr(),
                      out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
                      stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows,
-                     reserved=(0x8000 if wide else 0) if self.dcn_patches else 0x1000)
+                     reserved=var if self.dcn_patches else 0x1000)
             self.dcn_layers.append((p, len(self.ops) - 1))
             return out
         if self.pw.use_dcn and self.fuse_offsets:
@@ -846,32 +853,51 @@ class DLAEngine:
             self._keepalive[slot] = images
             return full
 
-    def calibrate_dcn_margins(self, images, max_over_frac=0.05):
-        """Choose per DeformConv layer between the margin-2 apron (default) and the wide-margin variant from a calibration batch:
-        the unfused twin of the plan is run on `images` (its conv_offset_mask outputs are the offsets the fused kernels compute
-        internally), and a layer whose share of 16x16 tiles with more far samples than patch slots exceeds `max_over_frac`
-        is switched to the wide margin (those tiles otherwise run the slow pass 2).  bf16 / f32 plans (the unfused path has no
-        fp16 kernels).  Returns {layer: share}.  Plans built before the call are dropped."""
+    DCN_VARIANTS = {"narrow": 0, "slots512": 0x10000, "wide": 0x8000}      # h3d_op.reserved bits read by csrc/dcn3.hip's launcher
+
+    def calibrate_dcn_margins(self, images, reps=3, min_gain=0.03):
+        """Choose per fused DeformConv layer among the three tile variants of csrc/dcn3.hip, by TIMING them on a calibration
+        batch (data-dependent: what matters is how many bilinear samples leave a tile's apron, i.e. the offsets the
+        conv_offset_mask layers produce on real images):
+          narrow    margin-2 apron, 256 patch slots per tile   (default; fastest while almost no tile overflows)
+          slots512  margin-2 packed apron, 512 slots in two rounds per stage
+          wide      margin-4 (64-channel workgroups: 6) packed apron, 256 slots
+        A tile with more far samples than slots re-runs them in the slow pass 2, which is what the other two avoid.  The plan
+        for `images`' shape is run once (so every layer sees real inputs), then every DeformConv op is timed `reps` times per
+        variant with HIP events (`h3d_run_ops_timed`); a layer leaves `narrow` only for a variant at least `min_gain` faster.
+        All dtypes of the fused path (bf16 / f16).  Returns {layer: {variant: ms}}; the choice lands in `pw.dcn_variant`
+        (`pw.dcn_wide` = the layers on `wide`) and plans built before the call are dropped."""
         _lib.require_cuda(images)
-        if self.pw.dtype == "f16":
-            raise RuntimeError("calibrate_dcn_margins: run it on a bf16 engine (same weights) and copy `pw.dcn_wide`")
+        if self.pw.dtype not in LOWP:
+            raise RuntimeError("calibrate_dcn_margins: the fused DeformConv variants exist for bf16 / f16 plans")
+        import ctypes
         B, _, H, W = images.shape
         with torch.cuda.device(self.device):
-            twin = Plan(self.pw, B, H, W, **dict(self._flags(), fuse_offsets=False))
-            twin.op_array[0].in_ = images.float().contiguous().data_ptr()
-            twin.run()
+            self.pw.dcn_variant = {}
+            self.plans.clear()
+            self.forward(images)
+            plan = self.plan(B, H, W)
+            n = len(plan.ops)
+            ms = (ctypes.c_float * n)()
+            layers = [(p, i) for p, i in plan.dcn_layers if plan.ops[i].Cin % 32 == 0 and not plan.ops[i].reserved & 0x1000]
+            times = {p: {} for p, _ in layers}
+            for name, bits in self.DCN_VARIANTS.items():
+                for _, i in layers:
+                    plan.op_array[i].reserved = bits
+                runs = []
+                for _ in range(reps + 1):                       # (first run of a variant: code-object load, dropped)
+                    _lib.check(_lib.lib().h3d_run_ops_timed(plan.op_array, n, _lib.stream_ptr(), ms), "h3d_run_ops_timed")
+                    runs.append([ms[i] for _, i in layers])
+                runs = list(zip(*runs[1:]))                    # per layer: its `reps` durations
+                for (p, _), r in zip(layers, runs):
+                    times[p][name] = float(sorted(r)[len(r) // 2])
             torch.cuda.synchronize()
-            probe = Plan(self.pw, B, H, W, **self._flags())
-            names = [p for p, _ in probe.dcn_layers]
-            dcn_ops = [op for op in twin.ops if op.kind == _lib.OP_DCN]
-            assert len(dcn_ops) == len(names), (len(dcn_ops), len(names))
-            shares = {}
-            for p, op in zip(names, dcn_ops):
-                om = [t for t in twin.keep if torch.is_tensor(t) and t.data_ptr() == op.in2][0]      # [B,h,w,32] fp32
-                shares[p] = float(_tiles_over_slots(om, margin=2, slots=256))
-            self.pw.dcn_wide = {p for p, v in shares.items() if v > max_over_frac}
+            for p, t in times.items():
+                best = min(t, key=t.get)
+                if best != "narrow" and t[best] < (1.0 - min_gain) * t["narrow"]:
+                    self.pw.dcn_variant[p] = self.DCN_VARIANTS[best]
         self.plans.clear()
-        return shares
+        return times
 
     __call__ = forward
 

@@ -111,8 +111,8 @@ def test_f16_plan_saturates_instead_of_overflowing():
 
 def test_dcn_wide_margin_flag_and_calibration():
     # engine.dcn_wide_margin = 1: every <= 64-channel-workgroup DeformConv on the margin-4 packed apron -- bit-identical heads while
-    # no tile overflows its patch slots (small offsets).  calibrate_dcn_margins: weights with LARGE offsets (offset_scale 2:
-    # mean |offset| 6 px) make it pick the wide margin for the layers whose tiles overflow; the network then still matches
+    # no tile overflows its patch slots (small offsets).  calibrate_dcn_margins: with weights of LARGE offsets (offset_scale 2:
+    # mean |offset| 6 px) the timed calibration moves the layers whose tiles overflow to the 512-slot or the wide-margin variant; the network then still matches
     # the oracle within the bf16 tolerance, and the plan runs the packed-apron kernels for exactly those layers.
     from gpu_helpers import kernel_name
     m, _ = _net(True, "bf16")
@@ -129,11 +129,18 @@ def test_dcn_wide_margin_flag_and_calibration():
     x2 = synth.synth_images(2, 256, 256, seed=7)
     eng = m2.engine(torch.device(DEV))
     before = {k: v.clone() for k, v in m2(torch.from_numpy(x2).to(DEV))[0].items()}
-    shares = eng.calibrate_dcn_margins(torch.from_numpy(x2).to(DEV))
-    assert len(shares) == 16 and eng.pw.dcn_wide and max(shares.values()) > 0.05, shares
+    times = eng.calibrate_dcn_margins(torch.from_numpy(x2).to(DEV))
+    assert len(times) == 16 and all(set(t) == {"narrow", "slots512", "wide"} and min(t.values()) > 0 for t in times.values()), times
+    assert eng.pw.dcn_variant and set(eng.pw.dcn_variant.values()) <= {0x8000, 0x10000}, (eng.pw.dcn_variant, times)
+    for p_, bits in eng.pw.dcn_variant.items():          # a layer leaves the default only for a variant measured >= 3 % faster
+        name = {0x8000: "wide", 0x10000: "slots512"}[bits]
+        assert times[p_][name] < 0.97 * times[p_]["narrow"], (p_, times[p_])
     after = m2(torch.from_numpy(x2).to(DEV))[0]
-    names = [kernel_name(op) for op in eng.plan(2, 256, 256).ops if op.kind == 12]
-    assert sum(n.endswith(", true>") for n in names) == len([p for p in eng.pw.dcn_wide]), (names, eng.pw.dcn_wide)
+    plan = eng.plan(2, 256, 256)
+    assert {p_: plan.ops[i].reserved for p_, i in plan.dcn_layers if plan.ops[i].reserved} == eng.pw.dcn_variant
+    names = {p_: kernel_name(plan.ops[i]) for p_, i in plan.dcn_layers}
+    for p_, bits in eng.pw.dcn_variant.items():
+        assert ("512" in names[p_].split("<")[1]) == (bits == 0x10000) and (names[p_].endswith(", true>") or ", 4, 16, 4," in names[p_]), names[p_]
     with torch.no_grad():
         ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(torch.from_numpy(x2))[0]
         emu = odla.DLAOracle(sd, HEADS, use_dcn=True, emulate_bf16=True)(torch.from_numpy(x2))[0]

@@ -158,6 +158,13 @@ DCN_CASES = [
     ("stream", "bf16", 0x8400, 1, 128, 128, 16, 32, 3.0),  # the 128-channel variant has margin 4 anyway
     ("stream", "f16", 0x8000, 2, 128, 64, 24, 40, 3.0),    # dcn3<f16,2,16,4,WDMA,256,PK>
     ("stream", "f16", 0x8000, 1, 64, 32, 20, 20, 12.0),
+    # 0x10000: margin 2 on the packed apron with 512 patch slots, the second 256 filled in a second round per stage
+    ("stream", "bf16", 0x10000, 2, 128, 64, 24, 40, 0.5),  # dcn3<bf16,2,16,2,WDMA,512,PK>: one round
+    ("stream", "bf16", 0x10000, 2, 64, 64, 40, 24, 4.0),   #   ... tiles with 256-512 far samples: two rounds, no pass 2
+    ("stream", "bf16", 0x10000, 2, 64, 64, 40, 24, 9.0),   #   ... more than 512: two rounds AND pass 2
+    ("stream", "bf16", 0x10000, 1, 64, 32, 20, 20, 12.0),  # dcn3<bf16,1,16,2,WDMA,512,PK>
+    ("stream", "bf16", 0x10400, 1, 256, 256, 24, 24, 8.0), # dcn3<bf16,4,16,4,WDMA,512>
+    ("stream", "f16", 0x10000, 2, 64, 64, 40, 24, 4.0),
     # 0x4000: csrc/dcn5.hip (apron AND filters by LDS-DMA; measured slower, kept selectable: DESIGN.md 2.2)
     ("stream", "f16", 0x4000, 2, 128, 64, 24, 40, 0.5),    # dcn5<2,2,.,256>
     ("stream", "f16", 0x4000, 1, 256, 64, 16, 32, 3.0),
@@ -219,7 +226,7 @@ def test_dcn_fused_variant_matches_oracle(case):
     assert torch.equal(got, built.run()), built.name
 
 
-@pytest.mark.parametrize("dtype,ov", [("bf16", 0), ("f16", 0), ("f16", 0x4000)])
+@pytest.mark.parametrize("dtype,ov", [("bf16", 0), ("f16", 0), ("f16", 0x4000), ("bf16", 0x8000), ("bf16", 0x10000)])
 def test_dcn_tiles_with_more_far_samples_than_patch_slots_are_deterministic(dtype, ov):
     # A tile with more than NP samples outside its apron sends the surplus through pass 2 (another accumulation order).  Round 2
     # handed out the slots with an LDS atomic per wave, so WHICH samples were the surplus depended on the order the waves arrived
@@ -275,7 +282,7 @@ def test_dcn_f16_stream_dispatch():
     names = {c: _dcn_built(c)[5].name for c in DCN_CASES if c[0] == "stream" and c[1] == "f16"}
     for c, n in names.items():
         assert n.startswith("dcn5_kernel<" if c[2] & 0x4000 else "dcn3_kernel<f16_t"), (c, n)
-        assert n.endswith(", true>") == bool(c[2] & 0x8000 and not c[2] & 0x400), (c, n)
+        assert n.endswith(", true>") == bool(c[2] & 0x18000 and not c[2] & 0x400), (c, n)
     assert {"dcn5_kernel<2, 2, 2, 256>", "dcn5_kernel<1, 2, 1, 256>", "dcn5_kernel<4, 4, 2, 256>"} <= set(names.values()), names
 
 
