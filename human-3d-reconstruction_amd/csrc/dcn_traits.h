@@ -85,13 +85,18 @@ template <> struct SE<bf16_t> {
     }
     static __device__ __forceinline__ u32x4 convert16(u32x4 raw)        // 8 bf16 -> 8 fp16
     {
-        half8_t o;
+        // v_cvt_pkrtz_f16_f32: three instructions per pair (shift, and, convert + pack).  A bf16 value inside fp16's normal range
+        // converts exactly under any rounding (8 significand bits into 11); round-toward-zero differs from nearest-even only
+        // (a) beyond +-65504, where it SATURATES to the largest finite fp16 instead of producing an infinity -- the clamp this
+        // conversion used to spend a v_med3_f32 per element on -- and (b) below 2^-14 (fp16 subnormals: at most 6e-8 off)
+        typedef __fp16 pk2_t __attribute__((ext_vector_type(2)));
+        u32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            o[2 * e] = cvt(raw[e] << 16);
-            o[2 * e + 1] = cvt(raw[e] & 0xffff0000u);
+            const pk2_t q = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(raw[e] << 16), __uint_as_float(raw[e] & 0xffff0000u));
+            o[e] = __builtin_bit_cast(uint32_t, q);
         }
-        return __builtin_bit_cast(u32x4, o);
+        return o;
     }
     static __device__ __forceinline__ frag global8(const char *p)       // 8 bf16 from global -> fp16
     {
