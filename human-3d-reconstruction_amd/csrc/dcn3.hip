@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             constexpr int q = decltype(P)::value;
 #pragma unroll
             for (int j = 0; j < NV; ++j)
-                if (adst[j] >= 0) *reinterpret_cast<u32x4 *>(smem + C::PB + adst[j]) = X::convert16(stg2[q][j]);
+                if (adst[j] >= 0) *reinterpret_cast<u32x4 *>(smem + C::PB + adst[j]) = X::convert16(stg2[q][j]);      // (converting in front of the barrier instead, in place: +0.5 %, tools/ab_lib.py)
         }
     };
     [[maybe_unused]] constexpr std::integral_constant<int, 0> I0{};
@@ -321,32 +321,25 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         bool my_want[5];
         uint32_t my_hw[5];
         int my_pm = 0;
-        const int tb = h ? 5 : 0;
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
-            const int tap = tb + u;
-            const int ti = tap / 3, tj = tap - ti * 3;
+            // tap = tb + u: row / column of the tap as a select between the two halves' compile-time values (no per-lane division)
+            const int ti = h ? (5 + u) / 3 : u / 3, tj = h ? (5 + u) % 3 : u % 3;
             const float h_im = (float)(oy - 1 + ti) + aoffs[3 * u];
             const float w_im = (float)(ox - 1 + tj) + aoffs[3 * u + 1];
-            const bool inside = live && tap < 9 && (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W);
-            typename X::geo g = X::zero_geo();
-            int off = 0;
-            bool want = false;               // inside the image, corners outside the apron
-            int hl = 0, wl = 0;
-            if (inside) {
-                hl = (int)floorf(h_im);
-                wl = (int)floorf(w_im);
-                const int ry = hl - hy0, rx = wl - hx0;
-                const float lh = h_im - (float)hl, lw = w_im - (float)wl;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-                g = X::make_geo(w4, dcn2_sigmoid(aoffs[3 * u + 2]));
-                if (ry >= 0 && ry + 1 < C::HH && rx >= 0 && rx + 1 < C::HH) {
-                    off = ry * C::RBH + rx * C::SBH + (PK ? ((ry & 1) << 4) : 0);      // (PK: half 0's bytes; half 1 reads off ^ 16)
-                } else {
-                    want = true;
-                }
-            }
+            const bool inside = live & (u < 4 || h == 0) & (h_im > -1.f) & (w_im > -1.f) & (h_im < (float)a.H) & (w_im < (float)a.W);
+            // branch free (the divergent `if (inside)` cost five exec-mask regions and ~150 register moves per wave and tile):
+            // everything is computed for every lane and SELECTED -- a sample outside the image keeps offset 0 with zero weights
+            const float fh = floorf(h_im), fw = floorf(w_im);
+            const int hl = (int)fh, wl = (int)fw;
+            const int ry = hl - hy0, rx = wl - hx0;
+            const float lh = h_im - fh, lw = w_im - fw;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+            typename X::geo g = X::select_geo(inside, X::make_geo(w4, dcn2_sigmoid(aoffs[3 * u + 2])));
+            const bool inap = (unsigned)ry < (unsigned)(C::HH - 1) && (unsigned)rx < (unsigned)(C::HH - 1);   // all four corners in the apron
+            const int off = (inside && inap) ? ry * C::RBH + rx * C::SBH + (PK ? ((ry & 1) << 4) : 0) : 0;    // (PK: half 0's bytes; half 1 reads off ^ 16)
+            const bool want = inside && !inap;               // inside the image, corners outside the apron
             my_want[u] = want;
             my_hw[u] = ((uint32_t)hl << 16) | ((uint32_t)wl & 0xffffu);
             my_off[u] = off;

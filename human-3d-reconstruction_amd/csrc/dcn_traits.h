@@ -36,6 +36,14 @@ template <> struct SE<float> {
         return g;
     }
     static __device__ __forceinline__ geo zero_geo() { geo g; g.w[0] = g.w[1] = g.w[2] = g.w[3] = 0.f; g.mask = 0.f; return g; }
+    static __device__ __forceinline__ geo select_geo(bool keep, const geo &g)      // keep ? g : zero_geo(), as selects
+    {
+        geo o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.w[i] = keep ? g.w[i] : 0.f;
+        o.mask = keep ? g.mask : 0.f;
+        return o;
+    }
     static __device__ __forceinline__ geo shfl_xor32(const geo &g)
     {
         geo o;
@@ -117,6 +125,7 @@ template <> struct SE<bf16_t> {
         return g;
     }
     static __device__ __forceinline__ geo zero_geo() { geo g; g.w01 = 0u; g.w23 = 0u; return g; }
+    static __device__ __forceinline__ geo select_geo(bool keep, const geo &g) { geo o; o.w01 = keep ? g.w01 : 0u; o.w23 = keep ? g.w23 : 0u; return o; }
     static __device__ __forceinline__ geo shfl_xor32(const geo &g)
     {
         geo o;
