@@ -34,7 +34,7 @@ struct Stem3Args {
 constexpr int S3K_TPB = 8;                           // consecutive tiles per workgroup (image patch prefetched one tile ahead)
 constexpr int S3K_IW = 56, S3K_IH = 25;              // image patch (uint2 per pixel)
 constexpr int S3K_ROWB = 1792, S3K_PXB = 48;         // S and L0 tiles: 48 B per pixel, rows 0 mod 256 B
-constexpr int S3K_SH = 19, S3K_SW = 35, S3K_LH = 17, S3K_LW = 33;
+constexpr int S3K_SH = 19, S3K_LH = 17, S3K_LW = 33;    // (the stem region is 19 x 35)
 constexpr int S3K_LDS_I = S3K_IH * S3K_IW * 8, S3K_LDS_S = S3K_SH * S3K_ROWB, S3K_LDS_L = S3K_LH * S3K_ROWB;
 constexpr int S3K_LDS = S3K_LDS_I + S3K_LDS_S + S3K_LDS_L + 4096;     // + slack: masked lanes of the last groups read past a row
 
@@ -133,30 +133,51 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     if (H3D_DBG(a) == 1) return;
     if (ti + 1 < t_first + S3K_TPB) load_patch(ti + 1);      // (zeros past the last tile)
 
-    // ---- P1: stem -> S.  The 19 x 35 region is walked as a FLAT list of 665 pixels in groups of 16 (42 groups; round 2 walked
-    //      3 groups of 16 per 35-pixel row: 57 groups, a quarter of their lanes idle): lane p of group g owns flat pixel
-    //      16 g + p, a wave advances by 128 pixels = 3 rows + 23 columns per iteration -------------------------------------
+    // ---- P1: stem -> S.  The kernel is bound by the LDS array (SQ_LDS_IDX_ACTIVE 0.75 per CU cycle, profiles/r03_pmc_sq_summary):
+    //      a flat pixel list (rounds 2-3: 42 groups of 16 pixels, one 1-KB patch read per MFMA) re-reads every patch row for each
+    //      of the 7 tap rows.  Now a wave owns a 16-column STRIP of up to 5 output rows: each of the 11 patch rows under it is
+    //      read ONCE and feeds the (up to) 5 accumulators whose tap row it is -- 11 reads for 35 MFMAs.  Waves 0-3 / 4-7 take
+    //      columns 0-15 / 16-31, rows 5 (wv & 3) ..; the last three columns (57 pixels) stay a flat list on waves 4-7.
+    //      Same MFMAs in the same order per output pixel (tap rows ascending): bit-identical. ------------------------------
     {
-        constexpr int NG = (S3K_SH * S3K_SW + 15) / 16;
-        int sy = (wv * 16 + p) / S3K_SW, sx = (wv * 16 + p) - sy * S3K_SW;
-#pragma unroll 1
-        for (int gi = wv; gi < NG; gi += 8) {
-            f32x4_s3 acc = {0.f, 0.f, 0.f, 0.f};
-            const uint2 *src = s_i + sy * S3K_IW + sx + 2 * q;          // (lanes past the last pixel read rows below the patch: LDS, unused)
+        const int r0 = 5 * (wv & 3), c0 = 16 * (wv >> 2);
+        f32x4_s3 acc[5];
 #pragma unroll
-            for (int dy = 0; dy < 7; ++dy) {
-                const uint2 lo = src[dy * S3K_IW], hi = src[dy * S3K_IW + 1];
-                const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
-                acc = stem3_mfma16<T>(fa0[dy], fb, acc);
-            }
-            if (sy < S3K_SH) {                                           // (flat index < 665)
+        for (int o = 0; o < 5; ++o) acc[o] = f32x4_s3{0.f, 0.f, 0.f, 0.f};
+        const uint2 *src = s_i + r0 * S3K_IW + c0 + p + 2 * q;          // (rows past the patch: LDS of the S tile, results unused)
+#pragma unroll
+        for (int pr = 0; pr < 11; ++pr) {
+            const uint2 lo = src[pr * S3K_IW], hi = src[pr * S3K_IW + 1];
+            const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int o = 0; o < 5; ++o)
+                if (pr - o >= 0 && pr - o < 7) acc[o] = stem3_mfma16<T>(fa0[pr - o], fb, acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 5; ++o) {
+            const int sy = r0 + o, sx = c0 + p;
+            if (sy < S3K_SH) {
                 const int gy = sy0 + sy, gx = sx0 + sx;
                 const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = stem3_epi<T>(acc, b0, in);
+                *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = stem3_epi<T>(acc[o], b0, in);
             }
-            sx += 128 % S3K_SW;
-            sy += 128 / S3K_SW;
-            if (sx >= S3K_SW) { sx -= S3K_SW; sy += 1; }
+        }
+        if (wv >= 4) {                                                   // columns 32..34: flat pixel 16 (wv - 4) + p of 19 x 3
+            const int fi = 16 * (wv - 4) + p;
+            const int sy = fi / 3, sx = 32 + fi - 3 * sy;
+            f32x4_s3 accr = {0.f, 0.f, 0.f, 0.f};
+            const uint2 *srcr = s_i + sy * S3K_IW + sx + 2 * q;           // (fi >= 57: rows below the patch, unused)
+#pragma unroll
+            for (int dy = 0; dy < 7; ++dy) {
+                const uint2 lo = srcr[dy * S3K_IW], hi = srcr[dy * S3K_IW + 1];
+                const u32x4 fb = {lo.x, lo.y, hi.x, hi.y};
+                accr = stem3_mfma16<T>(fa0[dy], fb, accr);
+            }
+            if (sy < S3K_SH) {
+                const int gy = sy0 + sy, gx = sx0 + sx;
+                const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                *reinterpret_cast<u32x2 *>(s_s + sy * S3K_ROWB + sx * S3K_PXB + q * 8) = stem3_epi<T>(accr, b0, in);
+            }
         }
     }
     __syncthreads();

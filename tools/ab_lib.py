@@ -20,6 +20,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--offset-scale", type=float, default=0.5)
 ap.add_argument("--filter", default="")
 ap.add_argument("--reps", type=int, default=4)
+ap.add_argument("--per-op", action="store_true", help="one line per launch shape (Cin, Cout, H) instead of one per kernel name")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 opt = Opt(input_h=512, input_w=512, smpl=True, dtype=args.dtype)
@@ -49,11 +50,12 @@ med = {k: np.median(np.stack(v), axis=0) for k, v in runs.items()}
 fam = {}
 for i, nm in enumerate(names):
     if args.filter in nm:
-        fam.setdefault(nm, []).append(i)
+        op = plan.ops[i]
+        fam.setdefault(nm + (" %d->%d @%d" % (op.Cin, op.Cout, op.H) if args.per_op else ""), []).append(i)
 keys = list(builds)
 print("%-70s %4s " % ("kernel", "n") + " ".join("%12s" % k[-12:] for k in keys) + "   ratio(last/first)")
 for nm, idx in sorted(fam.items(), key=lambda kv: -med[keys[0]][kv[1]].sum()):
     t = [med[k][idx].sum() for k in keys]
-    print("%-70s %4d " % (nm[:70], len(idx)) + " ".join("%12.4f" % v for v in t) + "   %.3f" % (t[-1] / t[0]))
+    print("%-70s %4d " % (nm[-70:], len(idx)) + " ".join("%12.4f" % v for v in t) + "   %.3f" % (t[-1] / t[0]))
 tot = [sum(med[k][i] for idx in fam.values() for i in idx) for k in keys]
 print("%-70s %4s " % ("total", "") + " ".join("%12.4f" % v for v in tot) + "   %.3f" % (tot[-1] / tot[0]))
