@@ -683,7 +683,15 @@ def main():
             plan = eng.plan(batch, size, size)
             groups = per_kernel_profile(plan, iters=5)
             total_ms = sum(g["ms"] for g in groups.values())
-            name, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+            # dominant kernel = the largest instantiation of the kernel FAMILY (template name) with the most device time: with all
+            # heads in one launch that single launch outweighs any one DeformConv instantiation, but the DeformConv family as a
+            # whole (three instantiations) is still where most of the step goes -- and it is the one furthest from its roofline
+            fam_ms = {}
+            for k, v in groups.items():
+                fam_ms[k.split("<")[0]] = fam_ms.get(k.split("<")[0], 0.0) + v["ms"]
+            family = max(fam_ms, key=fam_ms.get)
+            fam_flops = sum(v["flops"] for k, v in groups.items() if k.split("<")[0] == family)
+            name, g = max(((k, v) for k, v in groups.items() if k.split("<")[0] == family), key=lambda kv: kv[1]["ms"])
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None   # HBM bytes per launch from THIS round's committed rocprofv3 --pmc passes, or null
             try:
@@ -700,6 +708,9 @@ def main():
                                 "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                                 "avg_launch_ms_min_max": [round(g["ms_min"] / g["launches"], 4), round(g["ms_max"] / g["launches"], 4)],
                                 "share_of_network_time": round(g["ms"] / total_ms, 3),
+                                "family": family, "family_ms_per_step": round(fam_ms[family], 3),
+                                "family_frac": round(fam_flops / (fam_ms[family] * 1e-3) / 1e12 / peak, 4),
+                                "family_share_of_network_time": round(fam_ms[family] / total_ms, 3),
                                 "network_ms_per_step": round(total_ms, 3),
                                 # the north_star's target is quoted on the whole DLA-34+DCNv2 forward: all conv FLOP of
                                 # the network / its device time, and the same FLOP / the whole step (decode, SMPL, gather)

@@ -209,7 +209,7 @@ __device__ __forceinline__ void heads_dma_w2(const char *w2, int head_conv, char
     }
 }
 
-template <typename T, int TH, int M2, bool BIASC>
+template <typename T, int TH, int M2, bool BIASC, bool MIXED = false>
 __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 {
     using C = HeadsCfg<T, TH>;
@@ -292,9 +292,12 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
     const unsigned long long t_start = __builtin_readcyclecounter();
 #endif
     int s = 0;
-    for (int head = 0; head < a.nheads; ++head) {
+    // one head: M2H = 32-row tiles of ITS 1x1 output.  MIXED launches (all heads of the model in one launch, so that the halo
+    // tile is staged once per workgroup for all of them) instantiate the body for every width up to M2 and pick per head
+    auto head_body = [&](auto m2_tag, int head) {
+        constexpr int M2H = decltype(m2_tag)::value;
         const char *s_b = s_bias + (head & 1) * C::LDS_BIAS;
-        f32x16 acc[2][NT], acc2[M2][NT];
+        f32x16 acc[2][NT], acc2[M2H][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 #pragma unroll
-        for (int m = 0; m < M2; ++m)
+        for (int m = 0; m < M2H; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -324,7 +327,37 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                         }
                 }
                 constexpr int NSTEP = C::TAPS * (HC_IN / 16);
-                if constexpr (ES == 2 && M2 == 1 && HEADS_PF > 0) {
+                auto plain = [&]() {
+#pragma unroll
+                    for (int tp = 0; tp < C::TAPS; ++tp) {
+                        const int tap = tr * C::TAPS + tp;
+                        const int dy = tap / 3, dx = tap - dy * 3;
+                        const char *br = s_in + dy * C::RB + dx * C::SB;
+#pragma unroll
+                        for (int kk = 0; kk < HC_IN / 16; ++kk) {
+                            const int c = (kk * 16 + 8 * h) * ES / 16;
+                            typename E::frag fa[2], fb[NT];
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) {
+                                const char *row = slot + (tp * HC_SLAB + m * 32 + r) * C::RBW;
+                                fa[m] = E::lds_frag2(row + ((c ^ sw) << 4), row + (((c + 1) ^ sw) << 4));
+                            }
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                                for (int n = 0; n < NT; ++n) {
+                                    if (FIRST && tp == 0 && kk == 0) { acc[m][n] = bt[m]; }
+                                    E::mma(acc[m][n], fa[m], fb[n]);
+                                }
+                        }
+                    }
+                                };
+                // (two levels: inside this generic lambda only a condition that does not depend on M2H keeps the fp32
+                // instantiation from type-checking the 2-byte fragment code)
+                if constexpr (ES == 2) {
+                if constexpr (M2H == 1 && HEADS_PF > 0) {
                     // bf16, narrow heads (the 3-tile instantiation spills with it, in the 2-tile one it measures the same as the
                     // compiler's schedule: 0.279 / 0.287 vs 0.280 ms at depth 2 / 1): explicit software pipeline.  The fragments of step i+1 (a step = one tap x 16 channels: 2 filter
                     // + NT pixel fragments feeding 2*NT MFMAs) are requested BEFORE the MFMAs of step i and waited for with a
@@ -369,31 +402,10 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 } else {
-#pragma unroll
-                    for (int tp = 0; tp < C::TAPS; ++tp) {
-                        const int tap = tr * C::TAPS + tp;
-                        const int dy = tap / 3, dx = tap - dy * 3;
-                        const char *br = s_in + dy * C::RB + dx * C::SB;
-#pragma unroll
-                        for (int kk = 0; kk < HC_IN / 16; ++kk) {
-                            const int c = (kk * 16 + 8 * h) * ES / 16;
-                            typename E::frag fa[2], fb[NT];
-#pragma unroll
-                            for (int m = 0; m < 2; ++m) {
-                                const char *row = slot + (tp * HC_SLAB + m * 32 + r) * C::RBW;
-                                fa[m] = E::lds_frag2(row + ((c ^ sw) << 4), row + (((c + 1) ^ sw) << 4));
-                            }
-#pragma unroll
-                            for (int n = 0; n < NT; ++n) fb[n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
-#pragma unroll
-                            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                                for (int n = 0; n < NT; ++n) {
-                                    if (FIRST && tp == 0 && kk == 0) { acc[m][n] = bt[m]; }
-                                    E::mma(acc[m][n], fa[m], fb[n]);
-                                }
-                        }
-                    }
+                    plain();
+                }
+                } else {
+                    plain();
                 }
             };
 #pragma unroll 1
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 #ifdef H3D_ABLATE
             const unsigned long long tg0 = __builtin_readcyclecounter();
 #endif
-            gemm2<T, TH, NT, M2, BIASC>(acc, acc2, s_b + slab * HC_SLAB * 4, s_w2, r, h, sw);
+            gemm2<T, TH, NT, M2H, BIASC>(acc, acc2, s_b + slab * HC_SLAB * 4, s_w2, r, h, sw);
 #ifdef H3D_ABLATE
             t_g2 += __builtin_readcyclecounter() - tg0;
 #endif
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
             if (oy < a.H && ox < a.W) {
                 float *op = out + (((size_t)b * C_head + 4 * h) * a.H + oy) * a.W + ox;
 #pragma unroll
-                for (int m2 = 0; m2 < M2; ++m2) {
+                for (int m2 = 0; m2 < M2H; ++m2) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int c = m2 * 32 + 8 * g + 4 * h;
@@ -459,6 +471,16 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                     }
                 }
             }
+        }
+        };
+    for (int head = 0; head < a.nheads; ++head) {
+        if constexpr (!MIXED) {
+            head_body(std::integral_constant<int, M2>{}, head);
+        } else {
+            const int m2h = __builtin_amdgcn_readfirstlane((a.C[head] + 31) >> 5);
+            if (m2h <= 1) head_body(std::integral_constant<int, 1>{}, head);
+            else if (M2 < 3 || m2h == 2) head_body(std::integral_constant<int, (M2 < 2 ? 1 : 2)>{}, head);
+            else head_body(std::integral_constant<int, M2>{}, head);
         }
     }
 #ifdef H3D_ABLATE
@@ -506,14 +528,32 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
             H3D_FAIL(H3D_ERR_UNSUPPORTED, "heads: head %d has %d channels (max %d)", i, d->head[i].C, 32 * HC_MT2);
         a.w2[i] = (const char *)d->head[i].w2; a.b2[i] = d->head[i].b2; a.out[i] = d->head[i].out; a.C[i] = d->head[i].C;
     }
-    int m2 = 1;
-    for (int i = 0; i < d->nheads; ++i) m2 = max(m2, (d->head[i].C + 31) / 32);   // row tiles of the widest head
+    int m2 = 1, m2min = HC_MT2;
+    for (int i = 0; i < d->nheads; ++i) {
+        m2 = max(m2, (d->head[i].C + 31) / 32);   // row tiles of the widest head
+        m2min = min(m2min, (d->head[i].C + 31) / 32);
+    }
+    // heads of different widths in one launch: the kernel picks the 1 / 2 / 3-tile body per head (2-byte plans)
+    const bool mixed = m2min != m2 && es == 2;
     const int th = es == 2 ? 16 : 8;
     a.tiles_x = cdiv(op.W, 32); a.tiles_y = cdiv(op.H, th);
     const dim3 grid(op.B * a.tiles_x * a.tiles_y), blk(512);
     const bool biasc = !(op.reserved & 0x200);    // tuning override (tools/ab_heads.py): 0x200 = separate bias / zeroing pass
-    if (h3d_note_kernel("heads_kernel<%s, %d, %d, %s>", op.dtype == H3D_BF16 ? "unsigned short" : op.dtype == H3D_F16 ? "f16_t" : "float", th, m2, biasc ? "true" : "false"))
+    if (h3d_note_kernel(mixed ? "heads_kernel<%s, %d, %d, %s, true>" : "heads_kernel<%s, %d, %d, %s>",
+                        op.dtype == H3D_BF16 ? "unsigned short" : op.dtype == H3D_F16 ? "f16_t" : "float", th, m2, biasc ? "true" : "false"))
         return H3D_OK;
+    if (mixed) {
+        if (!biasc) H3D_FAIL(H3D_ERR_UNSUPPORTED, "heads: the separate-bias tuning override applies to launches of equal-width heads");
+        if (op.dtype == H3D_BF16) {
+            if (m2 == 2) hipLaunchKernelGGL((heads_kernel<bf16_t, 16, 2, true, true>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((heads_kernel<bf16_t, 16, 3, true, true>), grid, blk, 0, st, a);
+        } else {
+            if (m2 == 2) hipLaunchKernelGGL((heads_kernel<f16_t, 16, 2, true, true>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((heads_kernel<f16_t, 16, 3, true, true>), grid, blk, 0, st, a);
+        }
+        H3D_CHECK_LAUNCH("heads_kernel");
+        return H3D_OK;
+    }
 #define H3D_HEADS_LAUNCH(T, TH, M2)                                                                 \
     do {                                                                                             \
         if (biasc) hipLaunchKernelGGL((heads_kernel<T, TH, M2, true>), grid, blk, 0, st, a);         \

@@ -343,6 +343,7 @@ class Plan:
                                # margin-2 apron; per-layer choices from a calibration batch: DLAEngine.calibrate_dcn_margins
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
+        mixed_heads=1,         # all heads in ONE launch (the kernel picks the 1 / 2 / 3-tile body per head): the halo tile is staged once
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
         stem_s2_direct=True,      # bf16 plans of the other backbones: the 7x7 stride-2 stem conv itself instead of im2col + 1x1 conv
         conv1x1_th16_min_cin=0,   # > 0: 1x1 convs with at least this many input channels (and > 32 outputs) use 16-row tiles
@@ -634,7 +635,7 @@ class Plan:
             groups = {}
             for head, c in self.pw.heads.items():
                 m2 = (c + 31) // 32
-                groups.setdefault(1 if m2 == 1 else self.wide_heads_m2 or m2, []).append(head)
+                groups.setdefault(0 if self.mixed_heads else 1 if m2 == 1 else self.wide_heads_m2 or m2, []).append(head)
             for m2 in sorted(groups):
                 w1, b1, per = self.pw.fused_heads(tuple(groups[m2]))
                 desc = _lib.H3dHeadsDesc()

@@ -326,6 +326,32 @@ def _ab(m, xs, flag, **first):
     return on, off
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_all_heads_in_one_launch_is_bit_identical_to_one_launch_per_width(dtype):
+    # engine.mixed_heads (default): ONE heads launch for the whole model, the kernel picking the 1 / 2 / 3-row-tile body per
+    # head, against one launch per width (heads <= 32 channels | hps | the SMPL pose head): the same instruction stream per head
+    from gpu_helpers import kernel_name
+    m, _ = _net(True, dtype)
+    xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=29)).to(DEV)      # ragged 16 x 32 tiles
+    eng = m.engine(xs.device)
+    on, off = _ab(m, xs, "mixed_heads")
+    names = [kernel_name(op) for op in eng.plan(2, 96, 160).ops if op.kind == _lib_mod().OP_HEADS]
+    assert len(names) == 1 and names[0].endswith(", true, true>"), names
+    eng.mixed_heads = 0
+    eng.plans.clear()
+    m(xs)
+    assert len([op for op in eng.plan(2, 96, 160).ops if op.kind == _lib_mod().OP_HEADS]) >= 2
+    eng.mixed_heads = 1
+    eng.plans.clear()
+    for k in HEADS:
+        assert torch.equal(on[k], off[k]), k
+
+
+def _lib_mod():
+    from h3d_amd import _lib
+    return _lib
+
+
 def test_streamed_conv_matches_register_staged_kernel():
     # csrc/conv2.hip (LDS-DMA operands, LDS-transposed stores) vs csrc/conv.hip on every 3x3 s1 layer:
     # same bf16 operands, same fp32 accumulation -> only the summation order inside an MFMA chain differs

@@ -13,7 +13,8 @@ from collections import defaultdict
 
 def norm(name):
     name = re.sub(r"^void ", "", name)
-    return re.sub(r"\(.*\)$", "", name).strip()
+    name = re.sub(r"\(.*\)$", "", name).strip()
+    return re.sub(r"(, false)+>$", ">", name)      # trailing defaulted template arguments: the launchers' names omit them
 
 
 def fold(path, counter):

@@ -15,7 +15,8 @@ from collections import defaultdict
 
 
 def norm(name):
-    return re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", name)).strip()
+    name = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", name)).strip()
+    return re.sub(r"(, false)+>$", ">", name)      # trailing defaulted template arguments: the launchers' names omit them
 
 
 def fold(path):
