@@ -343,7 +343,12 @@ class Plan:
                                # margin-2 apron; per-layer choices from a calibration batch: DLAEngine.calibrate_dcn_margins
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
-        mixed_heads=1,         # all heads in ONE launch (the kernel picks the 1 / 2 / 3-tile body per head): the halo tile is staged once
+        mixed_heads=0,         # 1: all heads in ONE launch (the kernel picks the 1 / 2 / 3-tile body per head; the halo tile is staged once).
+                               # Measured (batch 64, same process / same box): the heads take 1.838 instead of 1.913 ms, but the STEP with
+                               # three steps in flight gets 0.4 % slower (8424 / 8465 vs 8461 / 8499 images/s): the merged kernel
+                               # needs 256 VGPRs, two of its waves fill a SIMD's register file, and the other streams' small kernels
+                               # (up-sample + add, max-pool, gathers), which the 198-register narrow-heads launch lets onto its
+                               # CUs, have to wait
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
         stem_s2_direct=True,      # bf16 plans of the other backbones: the 7x7 stride-2 stem conv itself instead of im2col + 1x1 conv
         conv1x1_th16_min_cin=0,   # > 0: 1x1 convs with at least this many input channels (and > 32 outputs) use 16-row tiles

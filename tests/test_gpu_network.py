@@ -328,21 +328,19 @@ def _ab(m, xs, flag, **first):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_all_heads_in_one_launch_is_bit_identical_to_one_launch_per_width(dtype):
-    # engine.mixed_heads (default): ONE heads launch for the whole model, the kernel picking the 1 / 2 / 3-row-tile body per
+    # engine.mixed_heads = 1 (off by default: faster kernel, slower step with three steps in flight): ONE heads launch for the whole model, the kernel picking the 1 / 2 / 3-row-tile body per
     # head, against one launch per width (heads <= 32 channels | hps | the SMPL pose head): the same instruction stream per head
     from gpu_helpers import kernel_name
     m, _ = _net(True, dtype)
     xs = torch.from_numpy(synth.synth_images(2, 96, 160, seed=29)).to(DEV)      # ragged 16 x 32 tiles
     eng = m.engine(xs.device)
-    on, off = _ab(m, xs, "mixed_heads")
+    on, off = _ab(m, xs, "mixed_heads")                 # (leaves the flag on)
     names = [kernel_name(op) for op in eng.plan(2, 96, 160).ops if op.kind == _lib_mod().OP_HEADS]
     assert len(names) == 1 and names[0].endswith(", true, true>"), names
     eng.mixed_heads = 0
     eng.plans.clear()
     m(xs)
     assert len([op for op in eng.plan(2, 96, 160).ops if op.kind == _lib_mod().OP_HEADS]) >= 2
-    eng.mixed_heads = 1
-    eng.plans.clear()
     for k in HEADS:
         assert torch.equal(on[k], off[k]), k
 
