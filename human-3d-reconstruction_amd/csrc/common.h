@@ -316,3 +316,11 @@ __device__ __forceinline__ u32x4 pack16_f16(const float *o)
     return v;
 }
 
+
+// value of lane (l ^ 32): gfx950's v_permlane32_swap exchanges the upper half of one register with the lower half of another in the
+// vector ALU (one instruction + a select) -- `__shfl_xor(x, 32)` compiles to a ds_bpermute_b32, an LDS-crossbar round trip
+__device__ __forceinline__ uint32_t h3d_xor32(uint32_t x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // r[0]: upper lanes hold the lower lanes' x; r[1]: lower lanes hold the upper lanes' x
+    return (threadIdx.x & 32) ? r[0] : r[1];
+}

@@ -383,12 +383,12 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         for (int u = 0; u < 5; ++u)
             if (my_want[u]) { slow = true; my_geo[u] = X::zero_geo(); }
         if constexpr (NP > 0) {
-            const int o_pm = __shfl_xor(my_pm, 32);
+            const int o_pm = (int)h3d_xor32((uint32_t)my_pm);
             pmask = h == 0 ? (my_pm | (o_pm << 5)) : (o_pm | (my_pm << 5));
         }
 #pragma unroll
         for (int u = 0; u < 5; ++u) {
-            const int o_off = __shfl_xor(my_off[u], 32);
+            const int o_off = (int)h3d_xor32((uint32_t)my_off[u]);
             const typename X::geo o_geo = X::shfl_xor32(my_geo[u]);
             // tap u (u < 5) belongs to half 0, tap 5 + u (u < 4) to half 1
             boff[u] = PK ? ((h == 0 ? my_off[u] : o_off) ^ (h << 4)) : (h == 0 ? my_off[u] : o_off) + 8 * h * SS;

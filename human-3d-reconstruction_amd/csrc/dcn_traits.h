@@ -129,8 +129,8 @@ template <> struct SE<bf16_t> {
     static __device__ __forceinline__ geo shfl_xor32(const geo &g)
     {
         geo o;
-        o.w01 = (uint32_t)__shfl_xor((int)g.w01, 32);
-        o.w23 = (uint32_t)__shfl_xor((int)g.w23, 32);
+        o.w01 = h3d_xor32(g.w01);
+        o.w23 = h3d_xor32(g.w23);
         return o;
     }
     // out = v0*w0 + v1*w1 + v2*w2 + v3*w3 on 8 fp16 channels: 4 packed ops per dword, the per-pixel
