@@ -492,6 +492,25 @@ def parity_mode(args, size, images, keep, dev, steps=3):
     return out
 
 
+def fp16_plan(args, size, images, keep, dev, nslot, steps=10):
+    """The fp16 plan (H3D_F16: fp16 activations and filters, saturating epilogues) on the SAME workload and images, and its top-k
+    indices on the cpu_baseline's 2 images: three more significand bits than bf16 at the same MFMA rate."""
+    from oracle import index_match as oim
+    det16, opt16, _, gflop = build_detector("dla_34", "f16", size, args, dev)
+    if args.dcn_margin == "auto":
+        det16.model.engine(dev).calibrate_dcn_margins(images)
+    step, _ = make_step(det16, images, nslot, 1, images.shape[0], dev)
+    dt = time_steps(step, steps, nslot + 1)
+    res = det16.run(keep["images"].to(dev))
+    m = annotate_index_match(oim.index_match({k: v.cpu().numpy() for k, v in res["heads"].items()}, res["inds"].cpu().numpy(),
+                                             keep["heads"], K=opt16.K), "f16")
+    out = {"dtype": "f16", "images_per_s": round(images.shape[0] * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "steps_in_flight": nslot, "batch": int(images.shape[0]), "index_match": m}
+    del det16
+    torch.cuda.empty_cache()
+    return out
+
+
 def other_archs(args, dev, steps=5):
     """The per-GPU shards of BASELINE configs[3] / [4] (what `--arch hourglass` / `--arch resdcn_101` time), a few steps each
     after the headline measurement, so that the driver's one command observes them too: network + decode, no SMPL stage."""
@@ -746,6 +765,12 @@ def main():
             if extras:
                 line["parity_mode"] = parity_mode(args, size, images, keep, dev)
                 print("[bench] parity_mode %s" % json.dumps(line["parity_mode"]), file=sys.stderr, flush=True)
+                if args.dtype == "bf16":
+                    try:
+                        line["fp16_plan"] = fp16_plan(args, size, images, keep, dev, nslot)
+                    except Exception as e:      # a record measured AFTER the headline number must not take the line down with it
+                        line["fp16_plan"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    print("[bench] fp16_plan %s" % json.dumps(line["fp16_plan"]), file=sys.stderr, flush=True)
         if extras:
             del det, eng, images
             torch.cuda.empty_cache()
