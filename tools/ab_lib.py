@@ -11,7 +11,7 @@ sys.path.insert(0, ".")
 import h3d_amd
 from h3d_amd import _lib, arch, synth
 from h3d_amd.detector import MultiPoseDetector, Opt
-from bench import kernel_name
+from bench import kernel_name, op_bytes
 
 ap = argparse.ArgumentParser()
 ap.add_argument("libs", nargs="+")
@@ -56,6 +56,7 @@ keys = list(builds)
 print("%-70s %4s " % ("kernel", "n") + " ".join("%12s" % k[-12:] for k in keys) + "   ratio(last/first)")
 for nm, idx in sorted(fam.items(), key=lambda kv: -med[keys[0]][kv[1]].sum()):
     t = [med[k][idx].sum() for k in keys]
-    print("%-70s %4d " % (nm[-70:], len(idx)) + " ".join("%12.4f" % v for v in t) + "   %.3f" % (t[-1] / t[0]))
+    gb = sum(op_bytes(plan.ops[i]) for i in idx) / 1e9       # algorithmic HBM bytes of these launches
+    print("%-70s %4d " % (nm[-70:], len(idx)) + " ".join("%12.4f" % v for v in t) + "   %.3f   %6.0f GB/s" % (t[-1] / t[0], gb / (t[0] * 1e-3)))
 tot = [sum(med[k][i] for idx in fam.values() for i in idx) for k in keys]
 print("%-70s %4s " % ("total", "") + " ".join("%12.4f" % v for v in tot) + "   %.3f" % (tot[-1] / tot[0]))
