@@ -11,6 +11,12 @@ What is recorded
                        the only variant the reference can run on a CPU -- on synthetic weights,
                        input [2,3,96,128]; outputs = the six multi_pose heads.
   dla34_shapes.json    the reference model's state_dict {key: shape} table.
+  dla34_plain_g125.npz same model and input with the signal-preserving gain-1.25 weights (head maps with O(1) variation).
+  e2e_plain_512.npz    END TO END, images -> indices, by the reference's own code in the reference's call order
+                       (trains/trainer.py:93,127 `_sigmoid` on hm / hm_hp, then trainer.py:456-469 `multi_pose_decode`):
+                       `dla_net(heads, not_use_dcn=True)` on synth_images(2, 512, 512, seed=317) with gain-1.25 weights;
+                       records the raw `hm` / `hm_hp` logits, every 4th pixel of the other heads, `dets`, `_topk` and
+                       `_topk_channel` outputs, and the NMS survivor counts.
   decode_*.npz         reference `_nms/_topk/_topk_channel/multi_pose_decode/ctdet_decode`
                        (models/decode.py) outputs on synthetic post-sigmoid heads.
   sigmoid.npz          reference `_sigmoid` (models/utils.py:8-10) on a logit ramp.
@@ -68,6 +74,53 @@ def gen_dla():
                         **{k: v.numpy() for k, v in out.items()})
     print("dla34_plain:", {k: tuple(v.shape) for k, v in out.items()},
           "hm range", float(out["hm"].min()), float(out["hm"].max()))
+
+
+def gen_dla_gain():
+    """The 96x128 heads again with gain-1.25 weights: at gain 1.0 the maps reaching the neck are nearly constant
+    (h3d_amd/synth.py), so this is the fixture that exercises the backbone with live signal."""
+    torch.manual_seed(0)
+    m = ref_model.dla_net(HEADS, not_use_dcn=True).eval()
+    shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=1.25)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    x = synth.synth_images(2, 96, 128, seed=317)
+    with torch.no_grad():
+        out = m(torch.from_numpy(x))[0]
+    np.savez_compressed(os.path.join(OUT, "dla34_plain_g125.npz"), **{k: v.numpy() for k, v in out.items()})
+    print("dla34_plain_g125: hm range", float(out["hm"].min()), float(out["hm"].max()), "std", float(out["hm"].std()))
+
+
+def gen_e2e():
+    """images -> heads -> _sigmoid -> multi_pose_decode, all by the imported reference, at the benchmark's image size."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    m = ref_model.dla_net(HEADS, not_use_dcn=True).eval()
+    shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=1.25)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    x = synth.synth_images(2, 512, 512, seed=317)
+    K = 100
+    with torch.no_grad():
+        out = m(torch.from_numpy(x))[0]
+        rec = {"hm": out["hm"].numpy().copy(), "hm_hp": out["hm_hp"].numpy().copy()}
+        for k in ("wh", "hps", "reg", "hp_offset"):
+            rec[k + "_s4"] = out[k][:, :, ::4, ::4].contiguous().numpy().copy()
+        out["hm"] = ref_utils._sigmoid(out["hm"])                        # trainer.py:93 (in place, like the loss module)
+        out["hm_hp"] = ref_utils._sigmoid(out["hm_hp"])                  # trainer.py:127
+        rec["hm_sig"] = out["hm"].numpy().copy()
+        heat = ref_decode._nms(out["hm"])
+        s, inds, clses, ys, xs = ref_decode._topk(heat, K=K)
+        rec.update(topk_scores=s.numpy(), topk_inds=inds.numpy(), topk_clses=clses.numpy(), topk_ys=ys.numpy(), topk_xs=xs.numpy())
+        rec["nms_hm_nonzero"] = np.array([(heat[b] != 0).sum().item() for b in range(2)])
+        hs, hi, hy, hx = ref_decode._topk_channel(ref_decode._nms(out["hm_hp"]), K=K)
+        rec.update(hp_scores=hs.numpy(), hp_inds=hi.numpy())
+        dets = ref_decode.multi_pose_decode(out["hm"], out["wh"], out["hps"], reg=out["reg"], hm_hp=out["hm_hp"],
+                                            hp_offset=out["hp_offset"], K=K)            # trainer.py:456-460
+        rec["dets"] = dets.numpy()
+    np.savez_compressed(os.path.join(OUT, "e2e_plain_512.npz"), **rec)
+    print("e2e_plain_512: hm logits range", float(rec["hm"].min()), float(rec["hm"].max()), "std", float(rec["hm"].std()),
+          "survivors", rec["nms_hm_nonzero"], "top score", s[:, 0].numpy(), "100th", s[:, -1].numpy())
 
 
 def gen_decode():
@@ -138,8 +191,14 @@ if __name__ == "__main__":
     if "--utils-only" in sys.argv:
         gen_utils()
         raise SystemExit(0)
+    if "--e2e-only" in sys.argv:
+        gen_dla_gain()
+        gen_e2e()
+        raise SystemExit(0)
     gen_sigmoid()
     gen_utils()
     gen_decode()
     gen_dla()
+    gen_dla_gain()
+    gen_e2e()
     print("golden vectors written to", OUT)

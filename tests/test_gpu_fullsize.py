@@ -170,3 +170,63 @@ def test_full_size_resdcn_shard_vs_oracle(dtype):
     assert res["dets"].shape == (32, 100, 6) and torch.equal(res["dets"], res["dets"][:1].expand_as(res["dets"]))
     del det, res
     torch.cuda.empty_cache()
+
+
+def test_end_to_end_f32_plain_plan_vs_reference_output(golden_dir):
+    """The metric's second clause ("bit-exact top-k peak indices vs the reference's own CPU path") against reference
+    OUTPUT, images -> indices: tests/golden/e2e_plain_512.npz is what the imported reference returns for
+    `dla_net(heads, not_use_dcn=True)` (model.py:501-516) -> `_sigmoid` (utils.py:8-10; trainer.py:93,127) ->
+    `multi_pose_decode(K=100)` (decode.py:77-163; trainer.py:456-469) on synth_images(2, 512, 512, seed=317) with
+    gain-1.25 weights (oracle/gen_golden.py gen_e2e).  The product runs the SAME call order through its reference-named
+    entry points (h3d_amd.model.dla_net -> utils._sigmoid -> decode.multi_pose_decode), f32 plan, plain convs.
+    Tolerances: logits within 2e-3 abs (|logit| <= 40: 5e-5 relative; fp32 summation order + folded BatchNorm);
+    peak indices bit-identical on every rank whose order cannot change under the measured score difference (asserted
+    non-empty), positional agreement >= 0.95; detection rows of agreeing ranks equal within 2e-3 px."""
+    import os
+    from h3d_amd import decode, model, utils
+    from oracle import decode as odec
+    g = np.load(os.path.join(golden_dir, "e2e_plain_512.npz"))
+    heads = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
+    sd = synth.synth_state_dict(arch.state_dict_shapes(heads, False), seed=0, gain=GAIN)
+    m = model.dla_net(heads, not_use_dcn=True, dtype="f32")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    out = m(torch.from_numpy(synth.synth_images(2, 512, 512, seed=317)).to(DEV))[0]
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    for k in ("hm", "hm_hp"):
+        e = float(np.abs(got[k] - g[k]).max())
+        print("e2e vs reference output: %s max abs logit error %.3g (scale %.3g)" % (k, e, float(np.abs(g[k]).max())))
+        assert e <= 2e-3, (k, e)
+    for k in ("wh", "hps", "reg", "hp_offset"):
+        e = float(np.abs(got[k][:, :, ::4, ::4] - g[k + "_s4"]).max())
+        assert e <= 2e-3, (k, e)
+    # the reference's call order on the product's tensors
+    hm = utils._sigmoid(out["hm"].clone())
+    hm_hp = utils._sigmoid(out["hm_hp"].clone())
+    dets = decode.multi_pose_decode(hm, out["wh"], out["hps"], reg=out["reg"], hm_hp=hm_hp, hp_offset=out["hp_offset"], K=100)
+    s, inds, clses, ys, xs = decode._topk(decode._nms(hm), K=100)
+    inds = inds.cpu().numpy()
+    np.testing.assert_allclose(hm.cpu().numpy(), g["hm_sig"], rtol=0, atol=5e-4)
+    m_ = oim.index_match(got, inds, {"hm": g["hm"]}, K=100)
+    print("e2e vs reference output: index_match %s" % m_)
+    assert m_["robust_prefix"] > 0 and m_["robust_prefix_equal"], m_
+    assert m_["agreement"] >= 0.95 and m_["set_overlap"] >= 0.98, m_
+    same = inds == g["topk_inds"]
+    np.testing.assert_allclose(s.cpu().numpy()[same], g["topk_scores"][same], rtol=0, atol=5e-4)
+    d = dets.cpu().numpy()
+    np.testing.assert_allclose(d[same][:, :5], g["dets"][same][:, :5], rtol=0, atol=2e-3)
+    np.testing.assert_array_equal(d[same][:, 39], g["dets"][same][:, 39])
+    # the product's decode on the REFERENCE's post-sigmoid maps: indices bit-identical on every rank (no ties among real peaks)
+    s2, i2, _, _, _ = decode._topk(decode._nms(torch.from_numpy(g["hm_sig"]).to(DEV)), K=100)
+    np.testing.assert_array_equal(i2.cpu().numpy(), g["topk_inds"])
+    np.testing.assert_array_equal(s2.cpu().numpy(), g["topk_scores"])
+    # joint heat maps: indices on each channel's tie-free prefix (several maps saturate at the 1 - 1e-4 clamp)
+    hs, hi, _, _ = decode._topk_channel(decode._nms(hm_hp), K=100)
+    hi = hi.cpu().numpy()
+    checked = 0
+    for b in range(2):
+        for j in range(17):
+            q = odec.strict_prefix(g["hp_scores"][b, j], 100)
+            checked += q
+            assert q == 0 or (hi[b, j, :q] == g["hp_inds"][b, j, :q]).mean() >= 0.95, (b, j, q)
+    assert checked >= 500
