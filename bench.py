@@ -164,68 +164,66 @@ def cpu_baseline(opt, sd, seconds_budget=20.0, keep=None):
                       "4 fp64 SMPL meshes/image)" % (iters, B, cores)}
 
 
-def dcn_apron_stats(det, images2, dev):
+def dcn_apron_stats(det, images, dev):
     """How far the DeformConv samples of THIS run's weights reach (synthetic offsets are small; trained networks have
-    larger ones -- `--offset-scale`).  Per (pixel, tap) sample: does a bilinear corner leave the LDS apron of its 16x16
-    tile (`apron_miss_frac`: such samples take one of the tile's NP patch slots, csrc/dcn3.hip), and per tile: are there
-    more such samples than slots (`tiles_over_slots_frac`: only those tiles run the slow global-gather pass 2).  The
-    fused kernels never write their offsets, so an UNFUSED twin of the plan (conv_offset_mask as its own launch) is run
-    on 2 images and the kernels' test (`ry >= 0 && ry + 1 < HH && ...`) is evaluated on its offset maps with each
-    layer's own apron margin and slot count."""
+    larger ones -- `--offset-scale`), counted by the kernels of the TIMED plan themselves on the TIMED batch: for every fused
+    DeformConv op of `eng.plan(B, H, W)` -- with the (margin, patch slots) variant it really dispatches -- `h3d_dcn_far_samples`
+    returns per 16x16 tile the number of (pixel, tap) samples that lie inside the image but have a bilinear corner outside
+    the tile's LDS apron (such a sample takes one of the tile's NP patch slots, csrc/dcn3.hip).  `apron_miss_frac` = those
+    samples / all samples; `tiles_over_slots_frac` = tiles with more of them than slots (only those run the slow
+    global-gather pass 2).  (Round 3 evaluated an UNFUSED 2-image twin plan here, whose small grids pick other variants.)
+    `mean_abs_offset_px` still comes from such a twin (bf16 plans only): the fused kernels never write their offsets."""
+    import ctypes
     import re
     from h3d_amd.engine import Plan
+    from h3d_amd._lib import H3dOp
     eng = det.model.engine(dev)
-    B, _, H, W = images2.shape
-    fused = Plan(eng.pw, B, H, W, **eng._flags())
-    cfgs = []                      # (margin, patch slots) per DeformConv launch
-    for op in fused.ops:
-        name = kernel_name(op)
-        if op.kind in (_lib.OP_DCN_FUSED, _lib.OP_DCN_FUSED_STREAM):
-            m = re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+), \d+, \w+, (\d+)", name) or re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+)", name)
-            if m is None:
-                return {"error": "unrecognised DeformConv kernel name %r" % name}
-            cfgs.append((int(m.group(1)), int(m.group(2)) if m.lastindex >= 2 else 0))
-        elif op.kind in (_lib.OP_DCN_FUSED_F16, _lib.OP_UPDCN_F16):
-            cfgs.append((1 if re.match(r"dcn4_kernel<\d+, \d+, 1,", name) else 2, 0))
-    twin = Plan(eng.pw, B, H, W, **dict(eng._flags(), fuse_offsets=False))
-    twin.op_array[0].in_ = images2.data_ptr()
-    twin.run()
-    torch.cuda.synchronize()
-    dcn_ops = [op for op in twin.ops if op.kind == _lib.OP_DCN]
-    if len(dcn_ops) != len(cfgs):
-        return {"error": "twin plan has %d DeformConvs, fused plan %d" % (len(dcn_ops), len(cfgs))}
+    B, _, H, W = images.shape
+    plan = eng.plan(B, H, W)
+    plan.op_array[0].in_ = images.data_ptr()
+    plan.run()
     miss_all = tot_all = 0.0
     tiles_over = tiles_all = 0
-    worst, worst_tiles, mean_abs = 0.0, 0.0, []
-    for op, (M, NP) in zip(dcn_ops, cfgs):
-        om = [t for t in twin.keep if torch.is_tensor(t) and t.data_ptr() == op.in2][0]      # [B,h,w,32] fp32
-        h, w = om.shape[1], om.shape[2]
-        ys = torch.arange(h, device=dev, dtype=torch.float32).view(1, h, 1)
-        xs = torch.arange(w, device=dev, dtype=torch.float32).view(1, 1, w)
-        y0, x0 = ys - ys % 16 - 1 - M, xs - xs % 16 - 1 - M              # apron origin of the pixel's tile
-        HH = 18 + 2 * M
-        miss = torch.zeros(om.shape[:3], device=dev)
-        for t in range(9):
-            ti, tj = divmod(t, 3)
-            h_im, w_im = ys - 1 + ti + om[..., 2 * t], xs - 1 + tj + om[..., 2 * t + 1]
-            inside = (h_im > -1) & (w_im > -1) & (h_im < h) & (w_im < w)
-            ry, rx = torch.floor(h_im) - y0, torch.floor(w_im) - x0
-            ok = (ry >= 0) & (ry + 1 < HH) & (rx >= 0) & (rx + 1 < HH)
-            miss += (inside & ~ok).float()
-        th, tw = -(-h // 16), -(-w // 16)
-        pad = torch.zeros(om.shape[0], th * 16, tw * 16, device=dev)
-        pad[:, :h, :w] = miss
-        per_tile = pad.view(-1, th, 16, tw, 16).sum(dim=(2, 4))           # samples of a tile that want a slot
-        over = float((per_tile > NP).sum())
-        tiles_over, tiles_all = tiles_over + over, tiles_all + per_tile.numel()
-        worst_tiles = max(worst_tiles, over / per_tile.numel())
-        mean_abs.append(float(om[..., :18].abs().mean()))
-        m_l, t_l = float(miss.sum()), 9.0 * miss.numel()
-        miss_all, tot_all = miss_all + m_l, tot_all + t_l
-        worst = max(worst, m_l / t_l)
-    return {"layers": len(cfgs), "apron_miss_frac": round(miss_all / tot_all, 5), "worst_layer_apron_miss_frac": round(worst, 5),
-            "tiles_over_slots_frac": round(tiles_over / max(tiles_all, 1), 5), "worst_layer_tiles_over_slots_frac": round(worst_tiles, 5),
-            "mean_abs_offset_px": round(float(np.mean(mean_abs)), 3)}
+    worst, worst_tiles, layers = 0.0, 0.0, {}
+    for p, i in plan.dcn_layers:
+        op = plan.ops[i]
+        name = kernel_name(op)
+        m = re.match(r"dcn3_kernel<[^,]+, \d+, \d+, (\d+), \d+, \w+, (\d+)", name)
+        if m is None or op.Cin % 32 or op.reserved & 0x1000:
+            return {"error": "no patch-slot DeformConv kernel behind %r (%s)" % (p, name)}
+        margin, NP = int(m.group(1)), int(m.group(2))
+        tiles = B * (-(-op.H // 16)) * (-(-op.W // 16))
+        cnt = torch.empty(tiles, dtype=torch.int32, device=dev)
+        q = H3dOp()
+        ctypes.memmove(ctypes.byref(q), ctypes.byref(plan.op_array[i]), ctypes.sizeof(H3dOp))
+        _lib.check(_lib.lib().h3d_dcn_far_samples(ctypes.byref(q), cnt.data_ptr(), _lib.stream_ptr()), "h3d_dcn_far_samples")
+        torch.cuda.synchronize()
+        over = int((cnt > NP).sum())
+        miss, tot = float(cnt.sum()), 9.0 * B * op.H * op.W
+        layers[p] = {"margin": margin, "slots": NP, "tiles": tiles, "tiles_over_slots": over, "apron_miss_frac": round(miss / tot, 5)}
+        tiles_over, tiles_all = tiles_over + over, tiles_all + tiles
+        worst_tiles = max(worst_tiles, over / tiles)
+        miss_all, tot_all = miss_all + miss, tot_all + tot
+        worst = max(worst, miss / tot)
+    out = {"layers": len(layers), "batch": B, "source": "h3d_dcn_far_samples on the timed plan's ops and batch",
+           "apron_miss_frac": round(miss_all / tot_all, 5), "worst_layer_apron_miss_frac": round(worst, 5),
+           "tiles_over_slots_frac": round(tiles_over / max(tiles_all, 1), 5), "worst_layer_tiles_over_slots_frac": round(worst_tiles, 5),
+           "per_layer": layers}
+    if eng.pw.dtype == "bf16":
+        twin = Plan(eng.pw, 2, H, W, **dict(eng._flags(), fuse_offsets=False))
+        two = images[:2].contiguous()
+        twin.op_array[0].in_ = two.data_ptr()
+        twin.run()
+        torch.cuda.synchronize()
+        mean_abs = []
+        for op in twin.ops:
+            if op.kind == _lib.OP_DCN:
+                om = [t for t in twin.keep if torch.is_tensor(t) and t.data_ptr() == op.in2][0]      # [2,h,w,32] fp32
+                mean_abs.append(float(om[..., :18].abs().mean()))
+        out["mean_abs_offset_px"] = round(float(np.mean(mean_abs)), 3)
+        out["mean_abs_offset_px_source"] = "unfused twin plan on 2 images"
+        del twin
+    return out
 
 
 def boundary_op_times(batch, dev):
@@ -551,7 +549,7 @@ def main():
     ap.add_argument("--dcn-margin", default="auto", choices=["narrow", "slots512", "wide", "auto"],
                     help="DeformConv tile variant: narrow = margin 2, 256 patch slots (fastest while offsets are small), slots512 = margin 2 "
                          "with 512 slots in two rounds, wide = margin 4 on the packed apron, each for every layer; auto (default; bf16 / f16 "
-                         "DLA-34 plans) = per layer, by timing the three on the job's own batch outside the timed region "
+                         "DLA-34 plans) = per layer, by a deterministic rule on the kernels' own per-tile far-sample counts of the job's batch, outside the timed region "
                          "(DLAEngine.calibrate_dcn_margins).  Same box, images/s at --offset-scale 0.5 / 1.0 / 2.0: narrow "
                          "8310 / 6831 / 5768, wide 7880 / 7143 / 6095, auto 8301 / 7340 / 6082")
     ap.add_argument("--no-extras", action="store_true",
@@ -623,7 +621,9 @@ def main():
     elif args.dcn_margin == "slots512":
         eng.dcn_slots512 = 1
     elif args.dcn_margin == "auto" and args.dtype in ("bf16", "f16") and dla:
-        eng.calibrate_dcn_margins(images)       # (setup, outside the timed region: every DeformConv op timed per variant on this batch)
+        # setup, outside the timed region: the per-layer tile variant from the kernels' own far-sample counts on this batch -- a
+        # deterministic rule (engine.DLAEngine.calibrate_dcn_margins), not a stopwatch: a second process makes the same choice
+        eng.calibrate_dcn_margins(images)
         names = {v: k for k, v in eng.DCN_VARIANTS.items()}
         dcn_variants = {p: names[v] for p, v in sorted(eng.pw.dcn_variant.items())}
 
@@ -743,8 +743,8 @@ def main():
                                    "gbs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)}      # algorithmic HBM bytes / time
                                for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
             print("[bench] kernels %s" % json.dumps(line["kernels"]), file=sys.stderr, flush=True)
-            if dla and args.dtype == "bf16":       # (the unfused twin plan it needs exists for bf16 / f32 only)
-                line["dcn_apron"] = dcn_apron_stats(det, images[:2].contiguous(), dev)
+            if dla and args.dtype in ("bf16", "f16") and opt.not_use_dcn is False:
+                line["dcn_apron"] = dcn_apron_stats(det, images, dev)
             if world == 1 and dla:
                 line["boundary_op"] = boundary_op_times(min(batch, 16), dev)
                 print("[bench] boundary_op %s" % json.dumps(line["boundary_op"]), file=sys.stderr, flush=True)

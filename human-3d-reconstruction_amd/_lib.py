@@ -55,8 +55,11 @@ SIGNATURES = {
     "h3d_dcn_v2_forward": [c_vp] * 6 + [c_i] * 14 + [c_vp],
     "h3d_dcn_v2_forward_ws": [c_vp] * 6 + [c_i] * 14 + [c_vp, ctypes.c_size_t, c_vp],
     "h3d_dcn_v2_pack_weights": [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp],
+    "h3d_dcn_v2_pack_weights_cached": [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp, c_vp],
+    "h3d_dcn_fused_pack_f32_cached": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp],
     "h3d_dcn_v2_forward_packed": [c_vp] * 5 + [c_i] * 7 + [c_vp, ctypes.c_size_t, c_vp],
     "h3d_dcn_fused_ck": [c_i, c_i],
+    "h3d_dcn_far_samples": [ctypes.POINTER(H3dOp), c_vp, c_vp],
     "h3d_smpl_coef_pack": [c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "h3d_smpl_verts3": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],
     "h3d_smpl_verts3_exact": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],

@@ -17,6 +17,7 @@
 //                          size / stride / pad / dilation / deformable groups, fp32 FMA.
 #include "common.h"
 #include "epilogue.h"
+#include <algorithm>
 
 // ------------------------------------------------------------------------------------------------
 // sampling geometry of one (pixel, tap): exactly the reference's float arithmetic
@@ -475,6 +476,137 @@ extern "C" int h3d_dcn_v2_pack_weights(const float *weight, const float *bias, i
     else
         hipLaunchKernelGGL(dcn_w_pack_f16_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, bias, (_Float16 *)packed, bp, Cout, C, rows);
     H3D_CHECK_LAUNCH("dcn_w_pack_kernel");
+    return H3D_OK;
+}
+
+// ---- packs that VALIDATE themselves on the device (round 4) -------------------------------------------------------------
+// A host-side cache keyed on (data_ptr, tensor._version) is not proof that the filters are unchanged: the reference edits its
+// parameters through `.data` (dcn_v2.py:80-81 reset_parameters, DCNv2/test.py:21 `weight.data.zero_()`, model.py:462), which
+// does not bump `_version`, and an address can be reused.  Asking the device "did the bytes change?" from the host would cost a
+// synchronisation per call, so the question is asked AND answered on the device: every call hashes the parameter bytes into
+// state[1] (order-independent 64-bit sum of mixed words), the pack kernels return at once when it equals state[0] -- the hash of
+// what the packed image was built from -- and a one-thread kernel then commits state[1] to state[0].  Everything is stream
+// ordered on the caller's stream: a consumer on another stream re-validates itself before it reads, and if it finds the pack
+// stale it re-packs the SAME bytes (a benign overlap).  state = 2 x uint64 on the device, zero-initialised by the host.
+__device__ __forceinline__ unsigned long long sig_mix(unsigned long long x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void sig_kernel(const uint32_t *__restrict__ p, size_t nwords, unsigned long long salt, unsigned long long *acc)
+{
+    unsigned long long h = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+        h += sig_mix(((unsigned long long)p[i] << 32 | (unsigned long long)(uint32_t)i) + salt + (i >> 32));
+#pragma unroll
+    for (int d = 32; d; d >>= 1) h += __shfl_xor(h, d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, h);
+}
+__global__ void sig_commit_kernel(unsigned long long *state) { state[0] = state[1]; }
+
+static int sig_begin(unsigned long long *state, const void *const *bufs, const size_t *nbytes, int n, hipStream_t st)
+{
+    if (hipMemsetAsync(state + 1, 0, 8, st) != hipSuccess) H3D_FAIL(H3D_ERR_LAUNCH, "pack signature: hipMemsetAsync failed");
+    for (int k = 0; k < n; ++k) {
+        const size_t nw = nbytes[k] / 4;
+        if (!nw) continue;
+        const unsigned blocks = (unsigned)std::min<size_t>((nw + 1023) / 1024, 512);
+        hipLaunchKernelGGL(sig_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)bufs[k], nw, 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1), state + 1);
+        H3D_CHECK_LAUNCH("sig_kernel");
+    }
+    return H3D_OK;
+}
+
+__global__ void dcn_w_pack_if_kernel(const float *__restrict__ w, const float *__restrict__ bias, void *__restrict__ wp_, float *__restrict__ bp,
+                                     int Cout, int C, int rows, int f16, const unsigned long long *__restrict__ state)
+{
+    if (state[0] == state[1]) return;                      // the packed image was built from exactly these bytes
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)rows * 9 * C;
+    if (i < (size_t)rows) bp[i] = i < (size_t)Cout ? bias[i] : 0.f;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int tap = (int)((i / C) % 9);
+    const int o = (int)(i / ((size_t)9 * C));
+    const float v = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+    if (f16) ((_Float16 *)wp_)[i] = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    else ((float *)wp_)[i] = v;
+}
+
+extern "C" int h3d_dcn_v2_pack_weights_cached(const float *weight, const float *bias, int Cout, int C, int dtype, void *packed, void *state_,
+                                              void *stream)
+{
+    if (!weight || !bias || !packed || !state_) H3D_FAIL(H3D_ERR_ARG, "dcn_v2_pack_weights_cached: null pointer");
+    if (Cout <= 0 || C <= 0 || C % 16) H3D_FAIL(H3D_ERR_SHAPE, "dcn_v2_pack_weights_cached: C=%d must be a positive multiple of 16", C);
+    if (dtype != H3D_F32 && dtype != H3D_BF16) H3D_FAIL(H3D_ERR_DTYPE, "dcn_v2_pack_weights_cached: dtype %d (f32 | bf16)", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *state = (unsigned long long *)state_;
+    const void *bufs[2] = {weight, bias};
+    const size_t nb[2] = {(size_t)Cout * C * 9 * 4, (size_t)Cout * 4};
+    int rc = sig_begin(state, bufs, nb, 2, st);
+    if (rc != H3D_OK) return rc;
+    const int rows = (Cout + 127) / 128 * 128;
+    const size_t wtotal = (size_t)rows * 9 * C;
+    float *bp = (float *)((char *)packed + ws_align(wtotal * (dtype == H3D_F32 ? 4 : 2)));
+    hipLaunchKernelGGL(dcn_w_pack_if_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, st, weight, bias, packed, bp, Cout, C, rows,
+                       dtype == H3D_F32 ? 0 : 1, state);
+    H3D_CHECK_LAUNCH("dcn_w_pack_if_kernel");
+    hipLaunchKernelGGL(sig_commit_kernel, dim3(1), dim3(1), 0, st, state);
+    H3D_CHECK_LAUNCH("sig_commit_kernel");
+    return H3D_OK;
+}
+
+// The stand-alone `DCN` module's four parameters (dcn_v2.py:97-116: weight, bias, conv_offset_mask.{weight,bias}) in the fp32 layout of
+// the fused DeformConv kernel (csrc/dcn3.hip): wp [rows][9][C] main filters, wo [128][9][C] offset/mask filters with the 27 channels
+// spread over 32 MFMA rows -- value i = 3u + c of lane half h in row (i&3) + 8(i>>2) + 4h; half 0 = taps 0..4, half 1 = taps 5..8;
+// c = 0: dh (channel 2 tap), 1: dw (2 tap + 1), 2: mask (18 + tap) -- and bias_out [rows main | 32 offset].  Validated as above.
+__global__ void dcn_fused_pack_f32_if_kernel(const float *__restrict__ w, const float *__restrict__ bias, const float *__restrict__ ow,
+                                             const float *__restrict__ ob, float *__restrict__ wp, float *__restrict__ wo, float *__restrict__ bo,
+                                             int Cout, int C, int rows, const unsigned long long *__restrict__ state)
+{
+    if (state[0] == state[1]) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t main_total = (size_t)rows * 9 * C, total = main_total + (size_t)128 * 9 * C;
+    auto src_channel = [](int row) {                       // MFMA row of the permuted offset conv -> conv_offset_mask channel (-1: unused)
+        if (row >= 32) return -1;
+        const int hh = (row >> 2) & 1, i3 = (row & 3) + 4 * (row >> 3);
+        const int u = i3 / 3, c = i3 - 3 * u;
+        if (u > 4 || (hh == 1 && u > 3)) return -1;
+        const int tap = hh ? 5 + u : u;
+        return c == 0 ? 2 * tap : c == 1 ? 2 * tap + 1 : 18 + tap;
+    };
+    if (i < (size_t)rows) bo[i] = i < (size_t)Cout ? bias[i] : 0.f;
+    if (i < 32) { const int ch = src_channel((int)i); bo[rows + i] = ch >= 0 ? ob[ch] : 0.f; }
+    if (i >= total) return;
+    const bool off = i >= main_total;
+    const size_t j = off ? i - main_total : i;
+    const int c = (int)(j % C);
+    const int tap = (int)((j / C) % 9);
+    const int o = (int)(j / ((size_t)9 * C));
+    if (!off) { wp[j] = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f; return; }
+    const int ch = src_channel(o);
+    wo[j] = ch >= 0 ? ow[((size_t)ch * C + c) * 9 + tap] : 0.f;
+}
+
+extern "C" int h3d_dcn_fused_pack_f32_cached(const float *weight, const float *bias, const float *off_weight, const float *off_bias, int Cout, int C,
+                                             float *wp, float *wo, float *bias_out, void *state_, void *stream)
+{
+    if (!weight || !bias || !off_weight || !off_bias || !wp || !wo || !bias_out || !state_) H3D_FAIL(H3D_ERR_ARG, "dcn_fused_pack_f32_cached: null pointer");
+    if (Cout <= 0 || C <= 0 || C % 16) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_pack_f32_cached: C=%d must be a positive multiple of 16", C);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *state = (unsigned long long *)state_;
+    const void *bufs[4] = {weight, bias, off_weight, off_bias};
+    const size_t nb[4] = {(size_t)Cout * C * 9 * 4, (size_t)Cout * 4, (size_t)27 * C * 9 * 4, (size_t)27 * 4};
+    int rc = sig_begin(state, bufs, nb, 4, st);
+    if (rc != H3D_OK) return rc;
+    const int rows = (Cout + 127) / 128 * 128;
+    const size_t total = ((size_t)rows + 128) * 9 * C;
+    hipLaunchKernelGGL(dcn_fused_pack_f32_if_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, bias, off_weight, off_bias, wp, wo,
+                       bias_out, Cout, C, rows, state);
+    H3D_CHECK_LAUNCH("dcn_fused_pack_f32_if_kernel");
+    hipLaunchKernelGGL(sig_commit_kernel, dim3(1), dim3(1), 0, st, state);
+    H3D_CHECK_LAUNCH("sig_commit_kernel");
     return H3D_OK;
 }
 

@@ -415,6 +415,13 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             for (int w8 = 0; w8 < 8; ++w8) nwant += s_cnt[w8];
         }
         overflow = nwant > NP;                                           // workgroup-uniform: some sample found no slot
+        if (a.dbg & 0x20000) {
+            // statistics launch (h3d_dcn_far_samples): `out` is an int32 array with one entry per 16x16 tile; the tile's number of
+            // samples whose corners leave THIS variant's apron is all that is produced (what DLAEngine.calibrate_dcn_margins
+            // chooses the per-layer variant from -- a deterministic function of the layer's input, not a stopwatch)
+            if (tid == 0 && blockIdx.y == 0) reinterpret_cast<int *>(a.out)[bid] = nwant;
+            return;
+        }
         const int nsl = min(nwant, NP);
         nsl2 = nsl;
         const int ps = tid / C::VPP, pv = tid - ps * C::VPP;
@@ -912,4 +919,17 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
         return launch_dcn3_cfg<float, 2, 16, 2>(a, st);
     }
     H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused: dtype %d", op.dtype);
+}
+
+// Per-tile count of bilinear samples that leave the LDS apron of the variant `op` dispatches to (see include/h3d.h).
+extern "C" int h3d_dcn_far_samples(const h3d_op *op_in, int32_t *per_tile, void *stream)
+{
+    if (!op_in || !per_tile) H3D_FAIL(H3D_ERR_ARG, "dcn_far_samples: null pointer");
+    if (op_in->kind != H3D_OP_DCN_FUSED_STREAM || (op_in->dtype != H3D_BF16 && op_in->dtype != H3D_F16) || op_in->Cin % 32 || (op_in->reserved & 0x1000))
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_far_samples: a 2-byte H3D_OP_DCN_FUSED_STREAM op of a patch-slot variant (Cin %% 32 == 0)");
+    h3d_op op = *op_in;
+    op.reserved = (op.reserved & 0x18600) | 0x20000;      // variant bits (margin / slots / workgroup width) + the statistics switch
+    op.out = per_tile;
+    op.out_mode = H3D_OUT_NHWC;
+    return h3d_launch_dcn3(op, (hipStream_t)stream);
 }

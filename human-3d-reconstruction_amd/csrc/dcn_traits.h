@@ -96,7 +96,11 @@ template <> struct SE<bf16_t> {
         // v_cvt_pkrtz_f16_f32: three instructions per pair (shift, and, convert + pack).  A bf16 value inside fp16's normal range
         // converts exactly under any rounding (8 significand bits into 11); round-toward-zero differs from nearest-even only
         // (a) beyond +-65504, where it SATURATES to the largest finite fp16 instead of producing an infinity -- the clamp this
-        // conversion used to spend a v_med3_f32 per element on -- and (b) below 2^-14 (fp16 subnormals: at most 6e-8 off)
+        // conversion used to spend a v_med3_f32 per element on -- and (b) below 2^-14 (fp16 subnormals: at most 6e-8 off).
+        // CONTRACT: activations are finite.  +-inf / NaN pass through unchanged (cvt() below would clamp an inf), and the
+        // branch-free blend multiplies zero weights with whatever the corner read returns, so a non-finite activation can leak
+        // NaN into samples that should contribute 0.  Every producer of a 2-byte plan saturates (bf16 epilogues cannot make inf
+        // from finite fp32 sums below 3.4e38; fp16 epilogues clamp), so only a non-finite INPUT image gets here.
         typedef __fp16 pk2_t __attribute__((ext_vector_type(2)));
         u32x4 o;
 #pragma unroll

@@ -14,26 +14,30 @@ from torch.nn.modules.utils import _pair
 from . import _lib
 
 
-_PACKED = {}          # (weight ptr, version, bias ptr, version, dtype, device) -> packed filter image (h3d_dcn_v2_pack_weights)
+_PACKED = {}          # (weight ptr, bias ptr, shape, dtype, device) -> (packed filter image, 16-byte device state of its validation)
 _PACKED_MAX = 64
 
 
 def _packed_weights(weight, bias, dtype):
-    """The operator's filters in the kernels' layout, packed ONCE per parameter version (the reference re-reads OIHW weights
-    on every call; re-packing them per call was 35 launches and a third of the operator's time on the network's 16 layers)."""
-    key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, dtype, str(weight.device))
-    ent = _PACKED.get(key)
+    """The operator's filters in the kernels' layout, KEPT across calls and validated on the device at every call
+    (`h3d_dcn_v2_pack_weights_cached`): the bytes of `weight` and `bias` are hashed on the current stream and the pack kernel runs
+    only when the hash differs from the one the image was built from -- no host synchronisation.  Neither `tensor._version` (an
+    edit through `.data`, as the reference does in dcn_v2.py:80-81 and DCNv2/test.py:21, does not bump it) nor the address (it can
+    be reused) is taken as proof that the filters are unchanged; the host key only finds the buffer.  All of it is stream ordered
+    on the CALLER's stream, so a second stream validates (and if need be re-packs the same bytes) before it reads; the cache holds
+    no reference to the parameters."""
+    key = (weight.data_ptr(), bias.data_ptr(), tuple(weight.shape), dtype, str(weight.device))
+    ent = _PACKED.pop(key, None)
+    Cout, C = weight.shape[0], weight.shape[1]
+    L = _lib.lib()
     if ent is None:
-        Cout, C = weight.shape[0], weight.shape[1]
-        L = _lib.lib()
         n = int(L.h3d_dcn_v2_packed_weight_bytes(Cout, C, dtype))
-        buf = torch.empty(n, dtype=torch.uint8, device=weight.device)
-        _lib.check(L.h3d_dcn_v2_pack_weights(_lib.ptr(weight), _lib.ptr(bias), Cout, C, dtype, _lib.ptr(buf), _lib.stream_ptr()),
-                   "dcn_v2_pack_weights")
-        if len(_PACKED) >= _PACKED_MAX:
+        ent = (torch.empty(n, dtype=torch.uint8, device=weight.device), torch.zeros(2, dtype=torch.int64, device=weight.device))
+        while len(_PACKED) >= _PACKED_MAX:
             _PACKED.pop(next(iter(_PACKED)))
-        # (the key holds the parameters' addresses: keep them alive as long as the entry, so an address cannot be reused)
-        ent = _PACKED[key] = (buf, weight, bias)
+    _PACKED[key] = ent                                     # (re-inserted: most recently used last)
+    _lib.check(L.h3d_dcn_v2_pack_weights_cached(_lib.ptr(weight), _lib.ptr(bias), Cout, C, dtype, _lib.ptr(ent[0]), _lib.ptr(ent[1]),
+                                                _lib.stream_ptr()), "dcn_v2_pack_weights_cached")
     return ent[0]
 
 
@@ -143,6 +147,8 @@ class DCNv2(nn.Module):
             self.bias.zero_()
 
     def forward(self, input, offset, mask):
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): call .eval() or run under torch.no_grad()")
         k = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
         assert 2 * k == offset.shape[1]
         assert k == mask.shape[1]
@@ -169,19 +175,23 @@ class DCN(DCNv2):
                 and input.dtype == torch.float32 and input.dim() == 4)
 
     def _packed(self, device):
-        """Weights in the layout of the fused DeformConv kernel (csrc/dcn3.hip, fp32), cached until a parameter changes."""
-        from . import engine
-        ps = (self.weight, self.bias, self.conv_offset_mask.weight, self.conv_offset_mask.bias)
-        key = tuple(p._version for p in ps) + tuple(p.data_ptr() for p in ps) + (str(device),)
-        if getattr(self, "_pack_key", None) != key:
-            pw = engine.PackedWeights.from_tensors(
-                {"w": self.weight, "b": self.bias, "ow": self.conv_offset_mask.weight, "ob": self.conv_offset_mask.bias},
-                "f32", device)
-            wp, bp, cout, cin, k, rows = pw.conv("w", "b", None, as_half=True)
-            wo, bo = pw.offset_conv("ow", "ob", rows)
-            self._pack = (wp, wo, torch.cat([bp.cpu(), bo]).contiguous().to(device), rows)
-            self._pack_key = key
-        return self._pack
+        """Weights in the layout of the fused DeformConv kernel (csrc/dcn3.hip, fp32), kept on the module and validated on the
+        device at every forward (`h3d_dcn_fused_pack_f32_cached`: a hash of the four parameters' bytes decides, on the stream,
+        whether the pack kernel has anything to do) -- so `dcn.weight.data.zero_()` between two forwards (DCNv2/test.py:21) is
+        seen although no version counter moves.  `.to(device)` / `load_state_dict` need no hook: new bytes, new hash."""
+        rows = (self.out_channels + 127) // 128 * 128
+        C = self.in_channels
+        ent = getattr(self, "_pack", None)
+        if ent is None or ent[0].device != device or ent[4] != (rows, C):
+            ent = (torch.empty(rows * 9 * C, dtype=torch.float32, device=device), torch.empty(128 * 9 * C, dtype=torch.float32, device=device),
+                   torch.empty(rows + 32, dtype=torch.float32, device=device), torch.zeros(2, dtype=torch.int64, device=device), (rows, C))
+            object.__setattr__(self, "_pack", ent)
+        ps = [p.detach().contiguous() for p in (self.weight, self.bias, self.conv_offset_mask.weight, self.conv_offset_mask.bias)]
+        if any(p.dtype != torch.float32 for p in ps):
+            raise RuntimeError("DCN: expected float32 parameters (reference uses .data<float>())")
+        _lib.check(_lib.lib().h3d_dcn_fused_pack_f32_cached(*[_lib.ptr(p) for p in ps], self.out_channels, C, _lib.ptr(ent[0]), _lib.ptr(ent[1]),
+                                                            _lib.ptr(ent[2]), _lib.ptr(ent[3]), _lib.stream_ptr()), "dcn_fused_pack_f32_cached")
+        return ent[0], ent[1], ent[2], rows
 
     def forward(self, input):
         """conv_offset_mask -> chunk/cat/sigmoid -> dcn_v2_conv (dcn_v2.py:118-128).  In the configuration the model uses
@@ -191,6 +201,9 @@ class DCN(DCNv2):
             raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): the input requires grad")
         if not input.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # a fine-tuning loop must not silently get no gradients (the reference implements dcn_v2_backward, out of scope here)
+            raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): call .eval() or run under torch.no_grad()")
         # (parameters require grad by default: `model.eval(); dcn(x)` outside no_grad must work as it does in the reference;
         #  the result is computed without a graph and returned detached)
         with torch.no_grad():

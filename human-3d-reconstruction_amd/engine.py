@@ -861,31 +861,104 @@ class DLAEngine:
 
     DCN_VARIANTS = {"narrow": 0, "slots512": 0x10000, "wide": 0x8000}      # h3d_op.reserved bits read by csrc/dcn3.hip's launcher
 
-    def calibrate_dcn_margins(self, images, reps=3, min_gain=0.03):
-        """Choose per fused DeformConv layer among the three tile variants of csrc/dcn3.hip, by TIMING them on a calibration
-        batch (data-dependent: what matters is how many bilinear samples leave a tile's apron, i.e. the offsets the
-        conv_offset_mask layers produce on real images):
-          narrow    margin-2 apron, 256 patch slots per tile   (default; fastest while almost no tile overflows)
-          slots512  margin-2 packed apron, 512 slots in two rounds per stage
-          wide      margin-4 (64-channel workgroups: 6) packed apron, 256 slots
-        A tile with more far samples than slots re-runs them in the slow pass 2, which is what the other two avoid.  The plan
-        for `images`' shape is run once (so every layer sees real inputs), then every DeformConv op is timed `reps` times per
-        variant with HIP events (`h3d_run_ops_timed`); a layer leaves `narrow` only for a variant at least `min_gain` faster.
-        All dtypes of the fused path (bf16 / f16).  Returns {layer: {variant: ms}}; the choice lands in `pw.dcn_variant`
-        (`pw.dcn_wide` = the layers on `wide`) and plans built before the call are dropped."""
+    # Cost model of the three tile variants, in units of "one tile of the `narrow` variant that stays within its slots"
+    # (fitted once from round 3's timing table; tools/fit_dcn_rule.py prints model vs stopwatch per layer):
+    #   a tile with more far samples than slots re-runs them in pass 2 (offset conv recomputed + serialised global
+    #   gathers): it costs ~3.2x a normal tile; the 512-slot variant is 2 % slower on a tile that does not need it and pays
+    #   an exposed load latency per stage for a second fill round; the wide margin stages 40 % more apron: 5 % slower.
+    DCN_RULE = {"pass2": 2.2, "slots512": 0.02, "round2": 0.30, "wide": 0.05, "min_gain": 0.03}
+
+    def dcn_far_samples(self, images):
+        """Per fused DeformConv layer of the plan for `images`' shape: the kernel's own count of samples per 16x16 tile
+        whose corners leave the apron (`h3d_dcn_far_samples`), for the margin-2 apron and for the wide one.
+        -> {layer: {"narrow": int32 tensor [tiles], "wide": int32 tensor [tiles]}}.  Runs the plan once (one stream, so
+        every layer's input buffer holds real activations), then phase A + geometry of every DeformConv twice."""
         _lib.require_cuda(images)
         if self.pw.dtype not in LOWP:
-            raise RuntimeError("calibrate_dcn_margins: the fused DeformConv variants exist for bf16 / f16 plans")
-        import ctypes
+            raise RuntimeError("dcn_far_samples: the fused DeformConv variants exist for bf16 / f16 plans")
         B, _, H, W = images.shape
+        out = {}
+        with torch.cuda.device(self.device):
+            streams, self.streams = self.streams, 1          # (_forward_split runs sub-plans: plan(B, H, W) would be left untouched)
+            try:
+                self.forward(images)
+            finally:
+                self.streams = streams
+            plan = self.plan(B, H, W)
+            for p, i in plan.dcn_layers:
+                src = plan.ops[i]
+                if src.Cin % 32 or src.reserved & 0x1000:
+                    continue
+                tiles = B * (-(-src.H // 16)) * (-(-src.W // 16))
+                rec = {}
+                for name in ("narrow", "wide"):
+                    op = H3dOp()
+                    ctypes.memmove(ctypes.byref(op), ctypes.byref(src), ctypes.sizeof(H3dOp))
+                    op.reserved = self.DCN_VARIANTS[name]
+                    cnt = torch.empty(tiles, dtype=torch.int32, device=self.device)
+                    _lib.check(_lib.lib().h3d_dcn_far_samples(ctypes.byref(op), cnt.data_ptr(), _lib.stream_ptr()), "h3d_dcn_far_samples")
+                    rec[name] = cnt
+                out[p] = rec
+            torch.cuda.synchronize()
+        return out
+
+    def calibrate_dcn_margins(self, images, rule=None):
+        """Choose per fused DeformConv layer among the three tile variants of csrc/dcn3.hip:
+          narrow    margin-2 apron, 256 patch slots per tile   (default; fastest while almost no tile overflows)
+          slots512  margin-2 packed apron, 512 slots in two rounds per stage
+          wide      margin-4 packed apron, 256 slots
+        by a RULE on what the kernels themselves count on a calibration batch (`dcn_far_samples`: per tile, the samples
+        that leave the apron) -- a deterministic function of (weights, images): two processes make the same choice and
+        therefore return the same bits (round 3 timed the variants with HIP events, and where two of them were within 3 %
+        the choice, and with it the accumulation order of overflowing tiles, differed from run to run).  Cost per layer in
+        units of a normal tile (DCN_RULE): narrow = 1 + pass2 * P(n > 256); slots512 = 1 + c + round2 * P(256 < n <= 512) +
+        pass2 * P(n > 512); wide = 1 + c' + pass2 * P(n_wide > 256); a layer leaves `narrow` only for a variant cheaper by
+        `min_gain`.  Returns {layer: {"cost": {variant: x}, "tiles_over_256": f, ...}}; the choice lands in `pw.dcn_variant`
+        and plans built before the call are dropped."""
+        rule = dict(self.DCN_RULE, **(rule or {}))
         with torch.cuda.device(self.device):
             self.pw.dcn_variant = {}
             self.plans.clear()
-            self.forward(images)
+            stats = self.dcn_far_samples(images)
+        report = {}
+        for p, rec in stats.items():
+            n2, n4 = rec["narrow"].float(), rec["wide"].float()
+            f256 = float((n2 > 256).float().mean())
+            f512 = float((n2 > 512).float().mean())
+            w256 = float((n4 > 256).float().mean())
+            cost = {"narrow": 1.0 + rule["pass2"] * f256,
+                    "slots512": 1.0 + rule["slots512"] + rule["round2"] * (f256 - f512) + rule["pass2"] * f512,
+                    "wide": 1.0 + rule["wide"] + rule["pass2"] * w256}
+            best = min(("narrow", "slots512", "wide"), key=lambda k: (cost[k], k != "narrow"))
+            if best != "narrow" and cost[best] < (1.0 - rule["min_gain"]) * cost["narrow"]:
+                self.pw.dcn_variant[p] = self.DCN_VARIANTS[best]
+            else:
+                best = "narrow"
+            report[p] = {"choice": best, "cost": {k: round(v, 4) for k, v in cost.items()}, "tiles_over_256": round(f256, 5),
+                         "tiles_over_512": round(f512, 5), "tiles_over_256_wide": round(w256, 5),
+                         "far_samples_per_tile": round(float(n2.mean()), 2)}
+        self.plans.clear()
+        return report
+
+    def time_dcn_variants(self, images, reps=3):
+        """Stopwatch counterpart of `calibrate_dcn_margins` (what round 3 used to CHOOSE; now only the yardstick the rule's
+        constants are fitted against, tools/fit_dcn_rule.py): every fused DeformConv op of the plan timed `reps` times per
+        variant with HIP events (`h3d_run_ops_timed`), median.  Changes nothing.  -> {layer: {variant: ms}}."""
+        _lib.require_cuda(images)
+        if self.pw.dtype not in LOWP:
+            raise RuntimeError("time_dcn_variants: the fused DeformConv variants exist for bf16 / f16 plans")
+        B, _, H, W = images.shape
+        with torch.cuda.device(self.device):
+            streams, self.streams = self.streams, 1
+            try:
+                self.forward(images)
+            finally:
+                self.streams = streams
             plan = self.plan(B, H, W)
             n = len(plan.ops)
             ms = (ctypes.c_float * n)()
             layers = [(p, i) for p, i in plan.dcn_layers if plan.ops[i].Cin % 32 == 0 and not plan.ops[i].reserved & 0x1000]
+            saved = [plan.op_array[i].reserved for _, i in layers]
             times = {p: {} for p, _ in layers}
             for name, bits in self.DCN_VARIANTS.items():
                 for _, i in layers:
@@ -897,12 +970,9 @@ class DLAEngine:
                 runs = list(zip(*runs[1:]))                    # per layer: its `reps` durations
                 for (p, _), r in zip(layers, runs):
                     times[p][name] = float(sorted(r)[len(r) // 2])
+            for (_, i), v in zip(layers, saved):
+                plan.op_array[i].reserved = v
             torch.cuda.synchronize()
-            for p, t in times.items():
-                best = min(t, key=t.get)
-                if best != "narrow" and t[best] < (1.0 - min_gain) * t["narrow"]:
-                    self.pw.dcn_variant[p] = self.DCN_VARIANTS[best]
-        self.plans.clear()
         return times
 
     __call__ = forward

@@ -83,6 +83,18 @@ int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *
 #define H3D_DCN_OUTPUT_NHWC 2
 size_t h3d_dcn_v2_packed_weight_bytes(int Cout, int C, int dtype);
 int h3d_dcn_v2_pack_weights(const float *weight, const float *bias, int Cout, int C, int dtype, void *packed, void *stream);
+/* h3d_dcn_v2_pack_weights for a pack that is KEPT across calls: validated on the device, without a host synchronisation.  Every
+ * call hashes the bytes of weight and bias on `stream`; the pack kernel runs only when the hash differs from the one `packed` was
+ * built from (state[0]), so an in-place parameter edit that no host-side version counter sees (`weight.data.zero_()`,
+ * DCNv2/test.py:21; dcn_v2.py:80-81) is picked up by the next call, and an unchanged layer costs three tiny launches.
+ * state: 16 bytes of device memory, zeroed by the caller when `packed` is allocated, owned by this function afterwards. */
+int h3d_dcn_v2_pack_weights_cached(const float *weight, const float *bias, int Cout, int C, int dtype, void *packed, void *state,
+                                   void *stream);
+/* The four parameters of the stand-alone `DCN` module (dcn_v2.py:97-116; conv_offset_mask has 27 output channels) in the fp32 layout
+ * of H3D_OP_DCN_FUSED: wp [rows = Cout padded to 128][9][C], wo [128][9][C] (rows permuted as the op expects), bias_out
+ * [rows | 32]; validated on the device like h3d_dcn_v2_pack_weights_cached (state: 16 zeroed bytes). */
+int h3d_dcn_fused_pack_f32_cached(const float *weight, const float *bias, const float *off_weight, const float *off_bias, int Cout, int C,
+                                  float *wp, float *wo, float *bias_out, void *state, void *stream);
 size_t h3d_dcn_v2_packed_workspace_bytes(int B, int C, int H, int W, int flags);
 int h3d_dcn_v2_forward_packed(const void *input, const void *packed, const float *offset, const float *mask, void *output,
                               int B, int C, int H, int W, int Cout, int dtype, int flags,
@@ -186,6 +198,14 @@ typedef struct h3d_op {
 
 /* channels per filter stage H3D_OP_DCN_FUSED_STREAM expects for a layer (16) */
 int h3d_dcn_fused_ck(int Cin, int Cout);
+
+/* How far a fused DeformConv's samples reach, as the kernel itself sees it: per_tile[b * tiles_y * tiles_x + ty * tiles_x + tx]
+ * (tiles of 16x16 output pixels, tiles_x = ceil(W/16)) = the number of (pixel, tap) samples of that tile that lie inside the image
+ * but have a bilinear corner outside the tile's LDS apron, for the tile variant `op->reserved` selects (margin 2, or the wide margin
+ * with 0x8000).  Phase A + geometry of the production kernel run, nothing else; op->out is not written.  A deterministic function of
+ * the layer's input: DLAEngine.calibrate_dcn_margins derives the per-layer variant from these counts (the reference operator,
+ * dcn_v2_cuda.cu:43-173, has no data-dependent dispatch at all, so whatever replaces it must not depend on a stopwatch). */
+int h3d_dcn_far_samples(const h3d_op *op, int32_t *per_tile, void *stream);
 
 /* Launch ops[0..n) in order on `stream`.  Returns H3D_OK or the first error (index in the
  * message). */

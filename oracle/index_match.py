@@ -54,6 +54,25 @@ def robust_prefix(score_map, K, delta):
     return n
 
 
+_CLAMP_LOGIT = 9.210240366975849          # logit(1 - 1e-4): `_sigmoid` clamps scores to [1e-4, 1 - 1e-4] (models/utils.py:8-10)
+
+
+def robust_prefix_logit(ref_logits, K, logit_err):
+    """`robust_prefix` evaluated on the LOGIT map.  `_sigmoid` is monotone, `_nms` and `_topk` only compare, so the order of
+    the peaks is the order of their logits (clamp plateaus aside, and those are ties in both spaces).  Near a score of 1
+    the sigmoid compresses gaps (two peaks 0.0066 apart in logits are 7e-6 apart in score), so a bound taken as the
+    max-norm of the SCORE error over the whole map (dominated by mid-range pixels, slope 1/4) declares top ranks
+    unstable that no logit error of the measured size could swap.  The perturbation allowed here is the measured logit
+    error plus what 2 ulp of fp32 score rounding (two sigmoid implementations) amount to in logits at the flattest of
+    the top-K peaks."""
+    L = np.clip(np.asarray(ref_logits, dtype=np.float64), -_CLAMP_LOGIT, _CLAMP_LOGIT)
+    s = 1.0 / (1.0 + np.exp(-L))
+    top = np.sort(s.ravel())[::-1][:K]
+    slope = float(np.min(top * (1.0 - top)))
+    ulp = 2.0 * 5.97e-8 / max(slope, 1e-12)
+    return robust_prefix(L, K, float(logit_err) + ulp)
+
+
 def index_match(gpu_heads, gpu_inds, ref_heads, K=100):
     """gpu_heads / ref_heads: {'hm': [B,1,H,W] logits, ...} numpy; gpu_inds [B,K] from the GPU decode.
     -> dict of plain floats/ints (goes into bench.py's JSON line)."""
@@ -68,6 +87,9 @@ def index_match(gpu_heads, gpu_inds, ref_heads, K=100):
     overlap = [len(set(gpu_inds[b].tolist()) & set(ref_inds[b].tolist())) / float(K) for b in range(B)]
     rob = [robust_prefix(ref_hm[b, 0], K, delta) for b in range(B)]
     rob_ok = all(bool((gpu_inds[b, :rob[b]] == ref_inds[b, :rob[b]]).all()) for b in range(B))
+    logit_err = float(np.abs(np.asarray(gpu_heads["hm"], np.float64) - np.asarray(ref_heads["hm"], np.float64)).max())
+    robl = [robust_prefix_logit(np.asarray(ref_heads["hm"])[b, 0], K, logit_err) for b in range(B)]
+    robl_ok = all(bool((gpu_inds[b, :robl[b]] == ref_inds[b, :robl[b]]).all()) for b in range(B))
     head_err = {k: float(np.abs(np.asarray(gpu_heads[k], np.float64) - np.asarray(ref_heads[k], np.float64)).max())
                 for k in ref_heads if k in gpu_heads}
     return {"images": B, "K": K,
@@ -77,4 +99,6 @@ def index_match(gpu_heads, gpu_inds, ref_heads, K=100):
             "set_overlap": round(float(np.mean(overlap)), 4),         # same peak anywhere in the top K
             "equal_prefix": int(min(prefix)),                          # ranks 1..n identical on every image
             "robust_prefix": int(min(rob)),                            # ranks whose order cannot change under that error ...
-            "robust_prefix_equal": bool(rob_ok)}                       # ... are bit-identical
+            "robust_prefix_equal": bool(rob_ok),                       # ... are bit-identical
+            "robust_prefix_logit": int(min(robl)),                     # the same analysis on the logit map (sigmoid compresses gaps near 1)
+            "robust_prefix_logit_equal": bool(robl_ok)}

@@ -176,12 +176,36 @@ def test_operator_throughput_form_cached_weights_channels_last_and_bf16():
         xcl = xd.contiguous(memory_format=torch.channels_last)
         y2 = dv.dcn_v2_forward(xcl, wd, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
         assert y2.is_contiguous(memory_format=torch.channels_last) and y2.shape == y0.shape and torch.equal(y2, y0)
-        # a parameter update invalidates the cache entry (new version -> new pack)
+        # a parameter update is seen by the pack's device-side validation (same buffer, re-packed) ...
         wd.mul_(2.0)
         y3 = dv.dcn_v2_forward(xd, wd, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
-        assert len(dv._PACKED) == 2
+        assert len(dv._PACKED) == 1
         ref3 = odcn.dcn_v2_forward(x, 2.0 * w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
         np.testing.assert_allclose(y3.cpu().numpy(), ref3.numpy(), rtol=0, atol=4e-4)
+        # ... and so is an edit through `.data`, which does NOT bump tensor._version (the reference edits its parameters
+        # exactly so: dcn_v2.py:80-81, DCNv2/test.py:21 `weight.data.zero_()`)
+        v = wd._version
+        wd.data.mul_(0.5)
+        bd.data.add_(1.0)
+        assert wd._version == v
+        y4 = dv.dcn_v2_forward(xd, wd, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+        np.testing.assert_allclose(y4.cpu().numpy(), (ref + 1.0).numpy(), rtol=0, atol=2e-4)
+        # a second stream right behind the first call of a NEW layer: it validates (and packs) for itself before it reads
+        w2 = (wd * 3.0).contiguous()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        ya = dv.dcn_v2_forward(xd, w2, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+        with torch.cuda.stream(side):
+            yb_ = dv.dcn_v2_forward(xd, w2, bd, od, md, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb_)
+        # the cache holds no reference to the parameters
+        import gc
+        import weakref
+        r = weakref.ref(w2)
+        del w2, ya, yb_
+        gc.collect()
+        assert r() is None
         # bf16 channels-last input: the network's bf16 path (fp16 filters and blend), bf16 channels-last output
         xb = bf16_round(x)
         wh = (2.0 * w).half().float()
@@ -211,6 +235,47 @@ def test_dcn_module_runs_outside_no_grad_like_the_reference_module():
     # the general (non-fused) configuration goes through the operator: same rule
     mod2 = dcn_v2.DCN(16, 8, kernel_size=(3, 3), stride=2, padding=1).to(DEV).eval()
     assert not mod2(rnd("x2", (1, 16, 12, 12)).to(DEV)).requires_grad
+    # training mode with grad enabled: a fine-tuning loop must not silently get no gradients
+    with pytest.raises(RuntimeError, match="inference-only"):
+        mod.train()(x)
+    with torch.no_grad():
+        assert torch.equal(mod.train()(x), y)
+    mod.eval()
+
+
+def test_dcn_module_sees_parameter_edits_through_data():
+    # the module keeps its packed filters and validates them on the device at every forward: `.data` edits (no version bump;
+    # DCNv2/test.py:21, dcn_v2.py:80-81,114-116), load_state_dict and a move to the device all show up in the next forward
+    torch.manual_seed(1)
+    mod = dcn_v2.DCN(32, 24, kernel_size=(3, 3), stride=1, padding=1).to(DEV).eval()
+    x = rnd("x", (2, 32, 14, 18))
+    with torch.no_grad():
+        mod.conv_offset_mask.weight.copy_(rnd("ow", (27, 32, 3, 3)) * 0.05)
+        mod.conv_offset_mask.bias.copy_(rnd("ob", (27,)) * 0.5)
+
+    def oracle():
+        sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+        om = F.conv2d(x, sd["conv_offset_mask.weight"], sd["conv_offset_mask.bias"], padding=1)
+        o1, o2, mk_ = torch.chunk(om, 3, dim=1)
+        return odcn.dcn_v2_forward(x, sd["weight"], sd["bias"], torch.cat((o1, o2), 1).contiguous(), torch.sigmoid(mk_).contiguous(),
+                                   3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
+
+    y0 = mod(x.to(DEV))
+    np.testing.assert_allclose(y0.cpu().numpy(), oracle().numpy(), rtol=0, atol=3e-4)
+    v = mod.weight._version
+    mod.weight.data.mul_(-1.5)
+    mod.bias.data.add_(0.25)
+    mod.conv_offset_mask.weight.data.mul_(2.0)
+    assert mod.weight._version == v
+    y1 = mod(x.to(DEV))
+    np.testing.assert_allclose(y1.cpu().numpy(), oracle().numpy(), rtol=0, atol=3e-4)
+    assert float((y1 - y0).abs().max()) > 1e-2
+    mod.conv_offset_mask.weight.data.zero_()
+    mod.conv_offset_mask.bias.data.zero_()                   # init_offset (dcn_v2.py:114-116): fresh DCN == 0.5 * conv2d + b
+    y2 = mod(x.to(DEV))
+    ref2 = 0.5 * F.conv2d(x, mod.weight.detach().cpu(), None, padding=1) + mod.bias.detach().cpu().view(1, -1, 1, 1)
+    np.testing.assert_allclose(y2.cpu().numpy(), ref2.numpy(), rtol=0, atol=3e-4)
+    assert torch.equal(mod(x.to(DEV)), y2)                    # unchanged parameters: the kept pack, same bits
 
 
 NET_CASES = [(2, 64, 64, 16, 16), (1, 128, 64, 24, 40), (1, 256, 128, 16, 16), (1, 512, 256, 8, 8), (1, 32, 16, 20, 20)]

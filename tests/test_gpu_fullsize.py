@@ -209,8 +209,11 @@ def test_end_to_end_f32_plain_plan_vs_reference_output(golden_dir):
     np.testing.assert_allclose(hm.cpu().numpy(), g["hm_sig"], rtol=0, atol=5e-4)
     m_ = oim.index_match(got, inds, {"hm": g["hm"]}, K=100)
     print("e2e vs reference output: index_match %s" % m_)
-    assert m_["robust_prefix"] > 0 and m_["robust_prefix_equal"], m_
-    assert m_["agreement"] >= 0.95 and m_["set_overlap"] >= 0.98, m_
+    # ranks whose order no logit error of the measured size can change (oracle/index_match.robust_prefix_logit: the analysis in
+    # logit space -- near a score of 1 the sigmoid compresses a 0.0066 logit gap to 7e-6, below the map-wide score error):
+    # 6 and 12 on these two images; they must be bit-identical, and the set must not be empty
+    assert m_["robust_prefix_logit"] > 0 and m_["robust_prefix_logit_equal"] and m_["robust_prefix_equal"], m_
+    assert m_["agreement"] >= 0.95 and m_["set_overlap"] >= 0.98, m_      # (measured on the round-4 box: all 100 ranks of both images identical)
     same = inds == g["topk_inds"]
     np.testing.assert_allclose(s.cpu().numpy()[same], g["topk_scores"][same], rtol=0, atol=5e-4)
     d = dets.cpu().numpy()

@@ -244,8 +244,9 @@ def test_dcn_tiles_with_more_far_samples_than_patch_slots_are_deterministic(dtyp
 
 
 def test_dcn_bf16_input_beyond_the_fp16_range_is_clamped_not_overflowed():
-    # bf16 plans sample from an fp16 apron: a bf16 activation beyond +-65504 is CLAMPED while it is staged (v_med3_f32 in
-    # SE<bf16_t>::cvt) -- in the LDS apron, in the patch pixels and in pass 2.  Driven past the range here: the
+    # bf16 plans sample from an fp16 apron: a FINITE bf16 activation beyond +-65504 SATURATES while it is staged (round toward
+    # zero in v_cvt_pkrtz_f16_f32, SE<bf16_t>::convert16) -- in the LDS apron, in the patch pixels and in pass 2.
+    # (+-inf / NaN activations are outside the contract: they pass through and 0 x inf = NaN can reach zero-weighted corners.)  Driven past the range here: the
     # result must equal the oracle's on the clipped input (no inf / nan), for samples inside and outside the apron.
     B, Ci, Co, H, W = 1, 64, 64, 24, 24
     x = bf16_round(rnd("x", (B, Ci, H, W)) * 1.0e5)                   # ~35 % of the values beyond 65504

@@ -182,7 +182,7 @@ def test_end_to_end_images_to_indices_matches_reference(golden_dir):
         np.testing.assert_array_equal(inds[b], g["topk_inds"][b])
     # (b) images -> indices through the oracle network
     m = oim.index_match(out, odec.topk(odec.nms(odec.sigmoid_clamp(out["hm"])), K)[1], {"hm": g["hm"]}, K=K)
-    assert m["robust_prefix"] > 0 and m["robust_prefix_equal"] and m["agreement"] >= 0.99, m
+    assert m["robust_prefix_logit"] > 0 and m["robust_prefix_logit_equal"] and m["robust_prefix_equal"] and m["agreement"] >= 0.99, m
     hp = odec.sigmoid_clamp(out["hm_hp"])
     dets, aux = odec.multi_pose_decode(odec.sigmoid_clamp(out["hm"]), out["wh"], out["hps"], out["reg"], hp, out["hp_offset"], K=K, return_aux=True)
     same = (aux["inds"] == g["topk_inds"])
