@@ -120,27 +120,28 @@ def per_kernel_profile(plan, iters):
     return groups
 
 
-def cpu_baseline(opt, sd, seconds_budget=20.0, keep=None):
-    """Oracle (torch-CPU restatement, kind 'port') on a bounded sample of the same workload.
-    keep: dict that receives the sample's input images and the oracle's head maps (for index_match)."""
+def cpu_baseline(opt, sd, keep=None):
+    """Oracle (torch-CPU restatement, kind 'port') on a bounded sample of the same workload, as SURVEY 8(d) specifies it: fp32,
+    batch 8, `torch.set_num_threads(N)` with N = ALL host cores this process may run on (stated: `cores`; `host_cores` = what
+    the machine has), warm-up 1, >= 5 timed iterations (about 10-15 s); then the 8-thread figure for comparison with the
+    survey container's probe (4.2 images/s at B = 8, plain-conv variant), 3 iterations.
+    keep: dict that receives the first 2 images of the sample and the oracle's head maps for them (index_match)."""
     from oracle import decode as odec, dla as odla, smpl as osmpl
     from h3d_amd import smpl as psmpl
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))                          # the 1-GPU box's CPU share is 16 cores
-    torch.set_num_threads(cores)
     net = odla.DLAOracle(sd, opt.heads, use_dcn=not opt.not_use_dcn)
     model = psmpl.SMPLModel.synthetic().numpy_dict()
-    B = 2
+    B = 8
     x = torch.from_numpy(synth.synth_images(B, opt.input_h, opt.input_w))
 
     def step():
         with torch.no_grad():
             o = {k: v.numpy() for k, v in net(x)[0].items()}
         if keep is not None and "heads" not in keep:
-            keep["images"], keep["heads"] = x, o
+            keep["images"], keep["heads"] = x[:2].clone(), {k: v[:2].copy() for k, v in o.items()}
         dets, aux = odec.multi_pose_decode(odec.sigmoid_clamp(o["hm"]), o["wh"], o["hps"], o["reg"],
                                            odec.sigmoid_clamp(o["hm_hp"]), o["hp_offset"], K=opt.K, return_aux=True)
         n = 4                                             # meshes per image in the CPU sample (fp64 numpy)
@@ -149,19 +150,74 @@ def cpu_baseline(opt, sd, seconds_budget=20.0, keep=None):
         be = np.stack([o["shape"][i].reshape(10, -1)[:, idx[i]].T for i in range(B)]).reshape(-1, 10)
         osmpl.lbs(be, th, model)
 
-    t0 = time.time()
-    step()                                                # warm-up
-    print("[bench] cpu_baseline warm-up step %.1f s on %d threads" % (time.time() - t0, cores), file=sys.stderr, flush=True)
-    t0 = time.time()
-    iters = 0
-    while iters < 2 or (time.time() - t0 < seconds_budget and iters < 12):
-        step()
-        iters += 1
-        print("[bench] cpu_baseline step %d: %.1f s elapsed" % (iters, time.time() - t0), file=sys.stderr, flush=True)
-    dt = time.time() - t0
-    return {"value": round(B * iters / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of batch %d (512x512, DLA-34+DCNv2+heads fp32 via torch-CPU threads=%d, numpy decode, "
-                      "4 fp64 SMPL meshes/image)" % (iters, B, cores)}
+    def run(threads, min_iters, budget):
+        torch.set_num_threads(threads)
+        t0 = time.time()
+        step()                                            # warm-up
+        print("[bench] cpu_baseline warm-up step %.1f s on %d threads" % (time.time() - t0, threads), file=sys.stderr, flush=True)
+        t0 = time.time()
+        iters = 0
+        while iters < min_iters or (time.time() - t0 < budget and iters < 12):
+            step()
+            iters += 1
+            print("[bench] cpu_baseline (%d threads) step %d: %.1f s elapsed" % (threads, iters, time.time() - t0), file=sys.stderr, flush=True)
+        return B * iters / (time.time() - t0), iters
+
+    v_all, it_all = run(cores, 5, 12.0)
+    v8, it8 = (v_all, it_all) if cores == 8 else run(min(8, cores), 3, 6.0)
+    torch.set_num_threads(cores)
+    return {"value": round(v_all, 3), "unit": "images/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
+            "value_8_threads": round(v8, 3),
+            "sample": "%d steps of batch %d on %d threads (all cores this process may use), then %d steps on %d threads: 512x512, "
+                      "DLA-34+DCNv2+heads fp32 via torch-CPU, numpy decode, 4 fp64 SMPL meshes/image"
+                      % (it_all, B, cores, it8, min(8, cores))}
+
+
+def frames_uint8(det, dev, batch, size, nslot, steps=20):
+    """The loop the reference's path really starts with (datasets/coco_hp.py:151-212 -> H2D, trainer.py:259-261): `batch` raw
+    uint8 BGR frames of size x size in PINNED host memory -> asynchronous H2D copy on the slot's stream -> `h3d_preprocess`
+    (warp + normalise, csrc/preprocess.hip) -> network -> decode -> SMPL, `nslot` steps in flight (each slot its own pinned
+    buffer, device frame buffer and plan buffers), so that the copy of step i+1 runs beside the kernels of step i.  Measured after
+    the timed region; `value` stays the resident-in-HBM rate.  uint8 frames are 1/4 of the fp32 batch (50 MB instead of 201 MB
+    per 64 images), which is what makes hiding the copy possible at all."""
+    from h3d_amd import preprocess
+    rng = np.random.default_rng(317)
+    host = [torch.from_numpy(rng.integers(0, 256, size=(batch, size, size, 3), dtype=np.uint8)).pin_memory() for _ in range(nslot)]
+    devb = [torch.empty(batch, size, size, 3, dtype=torch.uint8, device=dev) for _ in range(nslot)]
+    streams = _streams(nslot, dev) if nslot > 1 else [torch.cuda.current_stream()]
+    counter = [0]
+
+    def step():
+        k = counter[0] % nslot
+        counter[0] += 1
+        with torch.cuda.stream(streams[k]):
+            devb[k].copy_(host[k], non_blocking=True)
+            inp, c, s_ = preprocess.pre_process(devb[k], input_res=size)
+            return det.run(inp, slot=k)["dets"]
+
+    issued = []
+    dt = time_steps(step, steps, nslot + 1, issued)
+    # the two new stages alone, HIP events on one stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    h2d, pre = [], []
+    for _ in range(5):
+        ev[0].record()
+        devb[0].copy_(host[0], non_blocking=True)
+        ev[1].record()
+        preprocess.pre_process(devb[0], input_res=size)
+        ev[2].record()
+        torch.cuda.synchronize()
+        h2d.append(ev[0].elapsed_time(ev[1]))
+        pre.append(ev[1].elapsed_time(ev[2]))
+    h2d_ms, pre_ms = float(np.median(h2d)), float(np.median(pre))
+    nbytes = batch * size * size * 3
+    return {"images_per_s": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "steps_in_flight": nslot,
+            "batch": batch, "host_issue_ms_per_step": round(1e3 * issued[0] / steps, 3),
+            "h2d_ms": round(h2d_ms, 3), "h2d_gb_per_s": round(nbytes / h2d_ms / 1e6, 1), "h2d_share_of_step": round(h2d_ms / (1e3 * dt / steps), 3),
+            "preprocess_ms": round(pre_ms, 3),
+            "note": "pinned uint8 frames -> H2D on the slot stream -> h3d_preprocess -> network -> decode -> SMPL; h2d_ms / preprocess_ms are the "
+                    "stand-alone durations of those two stages (HIP events, one stream); with %d steps in flight the copy overlaps the "
+                    "previous steps' kernels" % nslot}
 
 
 def dcn_apron_stats(det, images, dev):
@@ -763,6 +819,11 @@ def main():
                                                                        res["inds"].cpu().numpy(), keep["heads"], K=opt.K), args.dtype)
             print("[bench] index_match %s" % json.dumps(line["index_match"]), file=sys.stderr, flush=True)
             if extras:
+                try:
+                    line["frames_uint8"] = frames_uint8(det, dev, batch, size, nslot)
+                except Exception as e:          # a record measured AFTER the headline number must not take the line down with it
+                    line["frames_uint8"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                print("[bench] frames_uint8 %s" % json.dumps(line["frames_uint8"]), file=sys.stderr, flush=True)
                 line["parity_mode"] = parity_mode(args, size, images, keep, dev)
                 print("[bench] parity_mode %s" % json.dumps(line["parity_mode"]), file=sys.stderr, flush=True)
                 if args.dtype == "bf16":
@@ -771,6 +832,18 @@ def main():
                     except Exception as e:      # a record measured AFTER the headline number must not take the line down with it
                         line["fp16_plan"] = {"error": "%s: %s" % (type(e).__name__, e)}
                     print("[bench] fp16_plan %s" % json.dumps(line["fp16_plan"]), file=sys.stderr, flush=True)
+                    f16 = line["fp16_plan"]
+                    if "images_per_s" in f16:
+                        # co-headline: the SAME workload in fp16 (same MFMA rate, three more significand bits per stored activation)
+                        im16, im = f16["index_match"], line["index_match"]
+                        line["metric_note"] += (
+                            "  CO-HEADLINE fp16 plan (Opt(dtype='f16')): %.1f images/s (%.3f of the bf16 value), max head error vs the fp32 oracle "
+                            "%.3g (bf16: %.3g), top-k set overlap %.3f (bf16: %.3f), positional agreement %.3f (bf16: %.3f).  Which to run: "
+                            "bf16 is the arithmetic north_star prices the roofline in and stays `value`; run fp16 when the ranking of the "
+                            "peaks matters more than ~2 %% of throughput (the stored activations of DLA-34 stay far inside +-65504 and the fp16 "
+                            "epilogues saturate), and f32 (parity_mode) when indices must match the reference bit for bit."
+                            % (f16["images_per_s"], f16["images_per_s"] / line["value"], im16["max_abs_head_err"], im["max_abs_head_err"],
+                               im16["set_overlap"], im["set_overlap"], im16["agreement"], im["agreement"]))
         if extras:
             del det, eng, images
             torch.cuda.empty_cache()

@@ -22,7 +22,16 @@ SMPL_HEADS = {"pose": 72, "shape": 10}
 
 
 class Opt:
-    """The option names the path consumes (reference opts.py; defaults of the multi_pose task)."""
+    """The option names the path consumes (reference opts.py; defaults of the multi_pose task).
+
+    dtype (extension; the reference computes in fp32): the arithmetic of the launch plan.
+      "bf16"  bf16 activations and filters, fp32 accumulation (DeformConv samples and blends in fp16).  The throughput headline
+              (north_star prices the roofline in bf16).  On noise-like random-weight heat maps the top-k ORDER shuffles
+              (head error ~0.75 on maps of std 1-2.5: set overlap 0.72, positional agreement 0.04).
+      "f16"   fp16 activations and filters at the same MFMA rate, saturating epilogues: ~2 % slower, head error 7x smaller
+              (0.10), set overlap 0.945, agreement 0.40 -- run this when the ranking matters more than 2 % of throughput.
+      "f32"   parity mode: exact fmaf chains on v_mfma_f32_32x32x2_f32, 1/8 of the throughput; heads within 2e-4 of the
+              reference's own output, top-k indices identical to it (tests/test_gpu_fullsize.py, tests/golden/e2e_plain_512.npz)."""
 
     def __init__(self, **kw):
         self.task = "multi_pose"

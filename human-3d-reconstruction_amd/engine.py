@@ -866,7 +866,11 @@ class DLAEngine:
     #   a tile with more far samples than slots re-runs them in pass 2 (offset conv recomputed + serialised global
     #   gathers): it costs ~3.2x a normal tile; the 512-slot variant is 2 % slower on a tile that does not need it and pays
     #   an exposed load latency per stage for a second fill round; the wide margin stages 40 % more apron: 5 % slower.
-    DCN_RULE = {"pass2": 2.2, "slots512": 0.02, "round2": 0.30, "wide": 0.05, "min_gain": 0.03}
+    #   tail: a launch ends with its slowest workgroup -- on a grid of few rounds (workgroups / resident workgroups) ONE overflowing
+    #   tile delays the end by a good part of a tile time, whatever the share of such tiles (measured, round 4: 256 -> 256 @32x32
+    #   at batch 64, two rounds, 0.4 % of the tiles over their slots: 0.166 ms narrow vs 0.144 with 512 slots; 256 -> 64 @32x32,
+    #   half a round, 7 % of the wide variant's tiles over: 0.108 ms wide vs 0.075 with 512 slots).
+    DCN_RULE = {"pass2": 2.2, "slots512": 0.02, "round2": 0.30, "wide": 0.05, "tail": 0.30, "min_gain": 0.03}
 
     def dcn_far_samples(self, images):
         """Per fused DeformConv layer of the plan for `images`' shape: the kernel's own count of samples per 16x16 tile
@@ -926,19 +930,36 @@ class DLAEngine:
             f256 = float((n2 > 256).float().mean())
             f512 = float((n2 > 512).float().mean())
             w256 = float((n4 > 256).float().mean())
-            cost = {"narrow": 1.0 + rule["pass2"] * f256,
-                    "slots512": 1.0 + rule["slots512"] + rule["round2"] * (f256 - f512) + rule["pass2"] * f512,
-                    "wide": 1.0 + rule["wide"] + rule["pass2"] * w256}
+            rounds = self._dcn_rounds(p, n2.numel())
+
+            def over(f):                                    # cost of the tiles that run pass 2: their share, or the launch's tail
+                return max(rule["pass2"] * f, min(rule["pass2"], rule["tail"] / rounds) if f > 0 else 0.0)
+            cost = {"narrow": 1.0 + over(f256),
+                    "slots512": 1.0 + rule["slots512"] + rule["round2"] * (f256 - f512) + over(f512),
+                    "wide": 1.0 + rule["wide"] + over(w256)}
             best = min(("narrow", "slots512", "wide"), key=lambda k: (cost[k], k != "narrow"))
             if best != "narrow" and cost[best] < (1.0 - rule["min_gain"]) * cost["narrow"]:
                 self.pw.dcn_variant[p] = self.DCN_VARIANTS[best]
             else:
                 best = "narrow"
             report[p] = {"choice": best, "cost": {k: round(v, 4) for k, v in cost.items()}, "tiles_over_256": round(f256, 5),
-                         "tiles_over_512": round(f512, 5), "tiles_over_256_wide": round(w256, 5),
+                         "tiles_over_512": round(f512, 5), "tiles_over_256_wide": round(w256, 5), "rounds": round(rounds, 3),
                          "far_samples_per_tile": round(float(n2.mean()), 2)}
         self.plans.clear()
         return report
+
+    def _dcn_rounds(self, p, tiles):
+        """Workgroups of DeformConv layer `p` per resident workgroup of the device (csrc/dcn3.hip's launcher: <= 64-channel
+        workgroups, two per CU; 128-channel ones, one per CU, unless that grid would leave CUs idle)."""
+        cout = int(self.pw.sd[p + ".conv.weight"].shape[0])
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if cout <= 64:
+            groups, per_cu = 1, 2
+        elif tiles * (-(-cout // 128)) < 192:
+            groups, per_cu = -(-cout // 64), 2
+        else:
+            groups, per_cu = -(-cout // 128), 1
+        return max(tiles * groups / float(cus * per_cu), 1e-3)
 
     def time_dcn_variants(self, images, reps=3):
         """Stopwatch counterpart of `calibrate_dcn_margins` (what round 3 used to CHOOSE; now only the yardstick the rule's

@@ -50,6 +50,9 @@ def _invert(M):
     return M
 
 
+_CONST = {}      # (B, h, w, res, mean, std, device) -> (minv [B,6] f64, mean [3], std [3]) on the device: uploaded once, not per batch
+
+
 @torch.no_grad()
 def pre_process(images, input_res=512, mean=MEAN, std=STD):
     """images [B,h,w,3] uint8 (BGR, as cv2.imread yields) on the device -> (inp [B,3,res,res] fp32,
@@ -61,11 +64,16 @@ def pre_process(images, input_res=512, mean=MEAN, std=STD):
     B, h, w, _ = images.shape
     c = np.array([w / 2., h / 2.], dtype=np.float32)
     s = max(w, h) * 1.0
-    minv = np.tile(_invert(get_affine_transform(c, s, [input_res, input_res])), (B, 1))
     dev = images.device
-    minv_t = torch.from_numpy(minv).to(dev)
-    mean_t = torch.tensor(mean, dtype=torch.float32, device=dev)
-    std_t = torch.tensor(std, dtype=torch.float32, device=dev)
+    key = (B, h, w, input_res, tuple(mean), tuple(std), str(dev))
+    if key not in _CONST:
+        minv = np.tile(_invert(get_affine_transform(c, s, [input_res, input_res])), (B, 1))
+        if len(_CONST) >= 32:
+            _CONST.pop(next(iter(_CONST)))
+        _CONST[key] = (torch.from_numpy(minv).to(dev), torch.tensor(mean, dtype=torch.float32, device=dev),
+                       torch.tensor(std, dtype=torch.float32, device=dev))
+        torch.cuda.current_stream(dev).synchronize()         # (the uploads are complete before any other stream may use them)
+    minv_t, mean_t, std_t = _CONST[key]
     out = torch.empty(B, 3, input_res, input_res, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().h3d_preprocess(_lib.ptr(images), B, h, w, 3 * w, _lib.ptr(minv_t), _lib.ptr(mean_t),
                                          _lib.ptr(std_t), input_res, input_res, _lib.ptr(out), _lib.stream_ptr()),

@@ -206,6 +206,8 @@ def test_operator_throughput_form_cached_weights_channels_last_and_bf16():
         del w2, ya, yb_
         gc.collect()
         assert r() is None
+        wd.data.mul_(2.0)                                     # (back to 2 w and b for the bf16 form below)
+        bd.data.sub_(1.0)
         # bf16 channels-last input: the network's bf16 path (fp16 filters and blend), bf16 channels-last output
         xb = bf16_round(x)
         wh = (2.0 * w).half().float()

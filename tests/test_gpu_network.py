@@ -137,9 +137,11 @@ def test_dcn_wide_margin_flag_and_calibration():
     assert chosen and set(chosen.values()) <= {0x8000, 0x10000}, (chosen, rep)
     R = eng.DCN_RULE
     for p_, r in rep.items():                            # the choice IS the rule applied to the reported tile shares
-        c = {"narrow": 1 + R["pass2"] * r["tiles_over_256"],
-             "slots512": 1 + R["slots512"] + R["round2"] * (r["tiles_over_256"] - r["tiles_over_512"]) + R["pass2"] * r["tiles_over_512"],
-             "wide": 1 + R["wide"] + R["pass2"] * r["tiles_over_256_wide"]}
+        def over(f):
+            return max(R["pass2"] * f, min(R["pass2"], R["tail"] / r["rounds"]) if f > 0 else 0.0)
+        c = {"narrow": 1 + over(r["tiles_over_256"]),
+             "slots512": 1 + R["slots512"] + R["round2"] * (r["tiles_over_256"] - r["tiles_over_512"]) + over(r["tiles_over_512"]),
+             "wide": 1 + R["wide"] + over(r["tiles_over_256_wide"])}
         best = min(c, key=c.get)
         want = best if best != "narrow" and c[best] < (1 - R["min_gain"]) * c["narrow"] - 1e-3 else None
         got = {0x8000: "wide", 0x10000: "slots512"}.get(chosen.get(p_))
