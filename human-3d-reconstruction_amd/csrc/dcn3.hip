@@ -111,11 +111,17 @@ __device__ __forceinline__ u32x4 dcn3_patch_corner(const char *img, int bytes, i
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
 
-template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false, int NP = 0, bool PK = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
+// F16IN (round 4, bf16 plans): the INPUT tensor is fp16 although the plan (filters' companion type, output, epilogue) is bf16 -- the
+// `node` DeformConvs of IDAUp read a tensor only they consume (`node(up(proj(x)) + skip)`, model.py:384-390), so the up-sample + add
+// kernel writes it as fp16 (H3D_OUT_NHWC_F16) and the bf16 -> fp16 conversion of every staged apron vector (3 VALU per pair, between
+// the two barriers of a stage where all eight waves do the same thing) disappears; the sample is also more precise (11 significand
+// bits instead of 8).  Selected by h3d_op.reserved & 0x40000.
+template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false, int NP = 0, bool PK = false, bool F16IN = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
 __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dcn3Args a)
 {
     using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP, PK>;
-    using X = SE<T>;
+    using X = SE<std::conditional_t<F16IN, f16_t, T>>;
+    static_assert(!F16IN || (std::is_same<T, bf16_t>::value && WDMA && NP > 0), "fp16 input: an option of the bf16 patch-slot variants");
     constexpr int ES = C::ES, SS = C::SS;
     __shared__ __attribute__((aligned(256))) char smem[C::LDS];
     char *s_w = smem + C::PB + C::LDS_H;       // filters of stage buffer 0 (pass 2) / of the WDMA ring
@@ -787,7 +793,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     H3D_STAMP(blockIdx.x, 5);
 }
 
-template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0, bool PK = false>
+template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0, bool PK = false, bool F16IN = false>
 static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
 {
     using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP, PK>;
@@ -805,20 +811,27 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
     const bool lean = a.out_mode == H3D_OUT_NHWC && a.Cout % 4 == 0 && ((uintptr_t)a.bias & 15) == 0;
     const int epi = (sizeof(T) == 2 && MT >= 2 && lean && a.Cout % 8 == 0 && a.out_cs % 8 == 0 && ((uintptr_t)a.out & 15) == 0) ? 2 : lean ? 1 : 0;
-    if (h3d_note_kernel(PK ? "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d, true>" : "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", h3d_tname<T>(), MT, CK, MARGIN, epi,
+    if (h3d_note_kernel(F16IN ? (PK ? "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d, true, true>" : "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d, false, true>")
+                              : PK ? "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d, true>" : "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", h3d_tname<T>(), MT, CK, MARGIN, epi,
                         WDMA ? "true" : "false", NP))
         return H3D_OK;
     if constexpr (sizeof(T) == 2 && MT >= 2) {
         if (epi == 2) {
-            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2, WDMA, NP, PK>), grid, dim3(C::THREADS), 0, st, a);
+            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2, WDMA, NP, PK, F16IN>), grid, dim3(C::THREADS), 0, st, a);
             H3D_CHECK_LAUNCH("dcn3_kernel");
             return H3D_OK;
         }
     }
+    if constexpr (F16IN) {
+        // (only the LDS-transposed epilogue is instantiated for the fp16-input variants: every layer of the network that uses them
+        //  has Cout % 8 == 0 and an aligned NHWC output)
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused_stream with an fp16 input: needs an NHWC output with Cout %% 8 == 0 (Cout=%d)", a.Cout);
+    } else {
     if (epi == 1)
         hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1, WDMA, NP, PK>), grid, dim3(C::THREADS), 0, st, a);
     else
         hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 0, WDMA, NP, PK>), grid, dim3(C::THREADS), 0, st, a);
+    }
     H3D_CHECK_LAUNCH("dcn3_kernel");
     return H3D_OK;
 }
@@ -827,9 +840,13 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
 extern "C" int h3d_dcn_fused_ck(int Cin, int Cout) { (void)Cin; (void)Cout; return 16; }
 
 // 2-byte plans (bf16_t: the apron is converted to fp16 while it is staged; f16_t: it is fp16 already)
-template <typename T>
+template <typename T, bool F16IN = false>
 static int launch_dcn3_lowp(const h3d_op &op, const Dcn3Args &a, bool wdma, hipStream_t st)
 {
+    if constexpr (F16IN) {
+        if (!wdma || (op.reserved & 0x1000) || op.Cin % 32 || op.Cout <= 32)
+            H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused_stream: the fp16-input option (reserved & 0x40000) exists for the patch-slot variants with > 32 output channels");
+    }
     if (wdma) {
         if ((op.reserved & 0x1000) || op.Cin % 32) {     // tuning override: round 1's configurations (no patches: every sample that
                                                          // leaves the apron goes through pass 2); also Cin = 16 (mod 32): the
@@ -844,8 +861,8 @@ static int launch_dcn3_lowp(const h3d_op &op, const Dcn3Args &a, bool wdma, hipS
             // many samples outside a margin-2 apron): margin 4 at two workgroups per CU (73 KB).  The 128-channel variant has
             // margin 4 anyway (a margin-6 packed apron needs a fourth staging register set: 14 spilled registers)
             if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 4, true, 256, true>(a, st);
-            if (op.Cout <= 64 || ((wgs4w < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400))) return launch_dcn3_cfg<T, 2, 16, 4, true, 256, true>(a, st);
-            return launch_dcn3_cfg<T, 4, 16, 4, true, 256>(a, st);
+            if (op.Cout <= 64 || ((wgs4w < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400))) return launch_dcn3_cfg<T, 2, 16, 4, true, 256, true, F16IN>(a, st);
+            return launch_dcn3_cfg<T, 4, 16, 4, true, 256, false, F16IN>(a, st);
         }
         // <= 64 output channels: margin-2 apron, 16-channel stages, <= 128 VGPRs and 78 KB of LDS -> two workgroups
         // (16 waves) per CU, one computing while the other waits at its stage barriers; 256 patch slots per tile.
@@ -855,15 +872,15 @@ static int launch_dcn3_lowp(const h3d_op &op, const Dcn3Args &a, bool wdma, hipS
             // experiment / candidate default: margin 2 on the PACKED apron (15 KB instead of 28) with 512 patch slots per tile, the second
             // 256 filled in a second round per stage
             if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 2, true, 512, true>(a, st);
-            if (op.Cout <= 64 || ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400))) return launch_dcn3_cfg<T, 2, 16, 2, true, 512, true>(a, st);
-            return launch_dcn3_cfg<T, 4, 16, 4, true, 512>(a, st);
+            if (op.Cout <= 64 || ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400))) return launch_dcn3_cfg<T, 2, 16, 2, true, 512, true, F16IN>(a, st);
+            return launch_dcn3_cfg<T, 4, 16, 4, true, 512, false, F16IN>(a, st);
         }
         if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 16, 2, true, 256>(a, st);
-        if (op.Cout <= 64) return launch_dcn3_cfg<T, 2, 16, 2, true, 256>(a, st);
+        if (op.Cout <= 64) return launch_dcn3_cfg<T, 2, 16, 2, true, 256, false, F16IN>(a, st);
         // a layer whose 128-channel workgroups would leave CUs idle (16 x 16 maps at batch 64: 128 workgroups on 256 CUs)
         // runs 64-channel workgroups instead: twice the gather / blend work, on CUs that had nothing to do
-        if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) return launch_dcn3_cfg<T, 2, 16, 2, true, 256>(a, st);
-        return launch_dcn3_cfg<T, 4, 16, 4, true, 256>(a, st);
+        if ((wgs4 < 192 || (op.reserved & 0x200)) && !(op.reserved & 0x400)) return launch_dcn3_cfg<T, 2, 16, 2, true, 256, false, F16IN>(a, st);
+        return launch_dcn3_cfg<T, 4, 16, 4, true, 256, false, F16IN>(a, st);
     }
     if (op.Cin % 32 == 0 && op.Cout <= 64) {
         if (op.Cout <= 32) return launch_dcn3_cfg<T, 1, 32, 2>(a, st);
@@ -907,6 +924,7 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.dbg = op.reserved;
     a.G = op.wrows / 32;
     if (wdma && (size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
+    if (op.dtype == H3D_BF16 && (op.reserved & 0x40000)) return launch_dcn3_lowp<bf16_t, true>(op, a, wdma, st);
     if (op.dtype == H3D_BF16) return launch_dcn3_lowp<bf16_t>(op, a, wdma, st);
     // fp16 plans: the apron needs no conversion while it is staged.  csrc/dcn5.hip also moves it by LDS-DMA (double buffered, one
     // barrier per phase-A stage): measured 5.7 % SLOWER on the ten <= 64-channel launches of the batch-64 plan (1.519 vs 1.437 ms,
@@ -928,7 +946,7 @@ extern "C" int h3d_dcn_far_samples(const h3d_op *op_in, int32_t *per_tile, void 
     if (op_in->kind != H3D_OP_DCN_FUSED_STREAM || (op_in->dtype != H3D_BF16 && op_in->dtype != H3D_F16) || op_in->Cin % 32 || (op_in->reserved & 0x1000))
         H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_far_samples: a 2-byte H3D_OP_DCN_FUSED_STREAM op of a patch-slot variant (Cin %% 32 == 0)");
     h3d_op op = *op_in;
-    op.reserved = (op.reserved & 0x18600) | 0x20000;      // variant bits (margin / slots / workgroup width) + the statistics switch
+    op.reserved = (op.reserved & 0x58600) | 0x20000;      // variant bits (margin / slots / workgroup width) + the statistics switch
     op.out = per_tile;
     op.out_mode = H3D_OUT_NHWC;
     return h3d_launch_dcn3(op, (hipStream_t)stream);

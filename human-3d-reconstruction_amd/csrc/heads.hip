@@ -25,6 +25,9 @@ constexpr int HEADS_MAX = 16;
 constexpr int HC_IN = 64;     // channels of y (DLA-34 first_level = 2)
 constexpr int HC_SLAB = 64;   // intermediate channels per slab (two 32-row MFMA tiles)
 constexpr int HC_MT2 = 3;     // up to 96 output channels per head
+#ifndef HEADS_PF_WIDE
+#define HEADS_PF_WIDE 0 // the same pipeline in the 2- and 3-tile bodies (wide heads)
+#endif
 #ifndef HEADS_PF
 #define HEADS_PF 2      // measured 0: 1.363, 1: 1.348, 2: 1.335, 3: 1.343 ms (batch 64, the narrow-heads launch)
 #endif
@@ -315,17 +318,17 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
             // bias tile (accumulator row = channel), so neither a zeroing pass nor a bias pass exists
             auto stage = [&](auto first_tag, const char *slot, int tr) {
                 constexpr bool FIRST = decltype(first_tag)::value;
-                f32x16 bt[2];
-                if constexpr (FIRST) {
+                // the bias tile goes from LDS straight INTO the accumulators (accumulator row = channel).  Round 3 built it in 32
+                // registers first and copied it into each N-tile: those 32 registers were live together with the fragment
+                // pipeline and pushed the 3-tile body into scratch (256 VGPRs + 24-36 bytes spilled)
+                auto load_bias = [&](f32x16 &dst, int m) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4 *>(s_b + (slab * HC_SLAB + m * 32 + 8 * g + 4 * h) * 4);
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 bv = *reinterpret_cast<const f32x4 *>(s_b + (slab * HC_SLAB + m * 32 + 8 * g + 4 * h) * 4);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) bt[m][4 * g + i] = bv[i];
-                        }
-                }
+                        for (int i = 0; i < 4; ++i) dst[4 * g + i] = bv[i];
+                    }
+                };
                 constexpr int NSTEP = C::TAPS * (HC_IN / 16);
                 auto plain = [&]() {
 #pragma unroll
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                             for (int m = 0; m < 2; ++m)
 #pragma unroll
                                 for (int n = 0; n < NT; ++n) {
-                                    if (FIRST && tp == 0 && kk == 0) { acc[m][n] = bt[m]; }
+                                    if (FIRST && tp == 0 && kk == 0) { load_bias(acc[m][n], m); }
                                     E::mma(acc[m][n], fa[m], fb[n]);
                                 }
                         }
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                 // (two levels: inside this generic lambda only a condition that does not depend on M2H keeps the fp32
                 // instantiation from type-checking the 2-byte fragment code)
                 if constexpr (ES == 2) {
-                if constexpr (M2H == 1 && HEADS_PF > 0) {
+                if constexpr ((M2H == 1 && HEADS_PF > 0) || (M2H > 1 && HEADS_PF_WIDE > 0)) {
                     // bf16, narrow heads (the 3-tile instantiation spills with it, in the 2-tile one it measures the same as the
                     // compiler's schedule: 0.279 / 0.287 vs 0.280 ms at depth 2 / 1): explicit software pipeline.  The fragments of step i+1 (a step = one tap x 16 channels: 2 filter
                     // + NT pixel fragments feeding 2*NT MFMAs) are requested BEFORE the MFMAs of step i and waited for with a
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 #pragma unroll
                     for (int kk = 0; kk < HC_IN / 16; ++kk) fa_base[kk] = ring + (((2 * kk + h) ^ sw) << 4);
                     const uint32_t fb_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)s_in + boff[0] + tr * C::RB;
-                    constexpr int PF = HEADS_PF, NBUF = PF + 1;          // steps in flight ahead of the MFMAs
+                    constexpr int PF = M2H == 1 ? HEADS_PF : HEADS_PF_WIDE, NBUF = PF + 1;          // steps in flight ahead of the MFMAs
                     static_assert(PF * (NT + 2) <= 15, "lgkmcnt field");
                     u32x4 fa[NBUF][2], fb[NBUF][NT];
                     auto fetch = [&](auto step_tag) {
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
                             for (int n = 0; n < NT; ++n) {
-                                if (FIRST && STEP == 0) { acc[m][n] = bt[m]; }
+                                if (FIRST && STEP == 0) { load_bias(acc[m][n], m); }
                                 typename E::frag a_, b_;
                                 a_.v = fa[BUF][m]; b_.v = fb[BUF][n];
                                 E::mma(acc[m][n], a_, b_);

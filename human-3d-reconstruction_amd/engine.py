@@ -26,6 +26,7 @@ from ._lib import H3dOp
 
 _TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 _H3D_DT = {"bf16": _lib.H3D_BF16, "f16": _lib.H3D_F16, "f32": _lib.H3D_F32}
+DCN_F16IN = 0x40000         # h3d_op.reserved of a fused DeformConv in a bf16 plan: its input tensor holds fp16 values (csrc/dcn3.hip F16IN)
 LOWP = ("bf16", "f16")      # the 2-byte plans: same kernels, lowering and tile choices; "f16" = BASELINE configs[4]'s arithmetic
 
 
@@ -341,6 +342,8 @@ class Plan:
         dcn_wide_margin=0,     # 1: every fused DeformConv (<= 64-channel workgroups) on the margin-4 packed apron (csrc/dcn3.hip PK): slower
                                # while the offsets stay small (more apron to stage), far faster once many samples of a tile leave a
                                # margin-2 apron; per-layer choices from a calibration batch: DLAEngine.calibrate_dcn_margins
+        node_f16=True,         # bf16 plans: the up-sample + add kernel writes the `node` DeformConvs' input as fp16 (only they read it) and those
+                               # DeformConvs run csrc/dcn3.hip's fp16-input variants (no conversion while the apron is staged)
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
         mixed_heads=0,         # 1: all heads in ONE launch (the kernel picks the 1 / 2 / 3-tile body per head; the halo tile is staged once).
@@ -516,8 +519,16 @@ class Plan:
         return (self.pw.use_dcn and self.fuse_offsets and self.stream_dcn and self.pw.dtype == "bf16"
                 and w.shape[1] == 64 and w.shape[0] <= 64)
 
-    def _deform(self, x, p, out=None, x_is_f16=False):
-        """DeformConv (model.py:346-362): DCN or plain 3x3 conv, then BN + ReLU (folded)."""
+    def _node_f16_ok(self, p):
+        """`node` DeformConvs of a bf16 plan that take an fp16 input (csrc/dcn3.hip F16IN): the fused patch-slot variants with more
+        than 32 output channels."""
+        w = self.pw.sd[p + ".conv.weight"]
+        return (self.node_f16 and self.pw.use_dcn and self.fuse_offsets and self.pw.dtype == "bf16" and self.stream_dcn3 and self.dcn_patches
+                and w.shape[1] % 32 == 0 and w.shape[0] > 32 and w.shape[0] % 8 == 0)
+
+    def _deform(self, x, p, out=None, x_is_f16=False, in_f16=False):
+        """DeformConv (model.py:346-362): DCN or plain 3x3 conv, then BN + ReLU (folded).  in_f16: `x` holds fp16 values in a
+        bf16 plan (written by `upadd(..., f16=True)`) and the op carries the fp16-input bit."""
         if x_is_f16:
             wimg, woimg, bias, cout, cin, rows = self.pw.dcn_stream(p)
             if out is None:
@@ -542,9 +553,10 @@ class Plan:
             self._op(_lib.OP_DCN_FUSED_STREAM, in_=x.ptr, in2=woimg.data_ptr(), w=wimg.data_ptr(), bias=bias.data_ptr(),
                      out=out.ptr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3,
                      stride=1, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows,
-                     reserved=var if self.dcn_patches else 0x1000)
+                     reserved=(var | (DCN_F16IN if in_f16 else 0)) if self.dcn_patches else 0x1000)
             self.dcn_layers.append((p, len(self.ops) - 1))
             return out
+        assert not in_f16, p
         if self.pw.use_dcn and self.fuse_offsets:
             wp, bp, cout, cin, k, rows = self.pw.conv(p + ".conv.weight", p + ".conv.bias", p + ".actf.0", as_half=True)
             wo, bo = self.pw.offset_conv(p + ".conv.conv_offset_mask.weight", p + ".conv.conv_offset_mask.bias", rows)
@@ -575,8 +587,9 @@ class Plan:
             if f16 and self.fuse_upnode and self.pw.up("%s.up_%d.weight" % (p, k))[1] // 2 >= self.fuse_upnode_min_f:
                 layers[i] = self._updcn(y, layers[i - 1], "%s.up_%d.weight" % (p, k), "%s.node_%d" % (p, k))
                 continue
-            y = self.upadd(y, layers[i - 1], "%s.up_%d.weight" % (p, k), f16=f16)
-            layers[i] = self._deform(y, "%s.node_%d" % (p, k), x_is_f16=f16)
+            nf16 = not f16 and self._node_f16_ok("%s.node_%d" % (p, k))
+            y = self.upadd(y, layers[i - 1], "%s.up_%d.weight" % (p, k), f16=f16 or nf16)
+            layers[i] = self._deform(y, "%s.node_%d" % (p, k), x_is_f16=f16, in_f16=nf16)
 
     def _updcn(self, x, skip, wkey, p):
         """node(up(x) + skip) in one launch (csrc/dcn4.hip UP = 1): the up-sampled sum never reaches HBM."""
@@ -898,7 +911,7 @@ class DLAEngine:
                 for name in ("narrow", "wide"):
                     op = H3dOp()
                     ctypes.memmove(ctypes.byref(op), ctypes.byref(src), ctypes.sizeof(H3dOp))
-                    op.reserved = self.DCN_VARIANTS[name]
+                    op.reserved = self.DCN_VARIANTS[name] | (src.reserved & DCN_F16IN)
                     cnt = torch.empty(tiles, dtype=torch.int32, device=self.device)
                     _lib.check(_lib.lib().h3d_dcn_far_samples(ctypes.byref(op), cnt.data_ptr(), _lib.stream_ptr()), "h3d_dcn_far_samples")
                     rec[name] = cnt
@@ -982,8 +995,8 @@ class DLAEngine:
             saved = [plan.op_array[i].reserved for _, i in layers]
             times = {p: {} for p, _ in layers}
             for name, bits in self.DCN_VARIANTS.items():
-                for _, i in layers:
-                    plan.op_array[i].reserved = bits
+                for (_, i), v in zip(layers, saved):
+                    plan.op_array[i].reserved = bits | (v & DCN_F16IN)
                 runs = []
                 for _ in range(reps + 1):                       # (first run of a variant: code-object load, dropped)
                     _lib.check(_lib.lib().h3d_run_ops_timed(plan.op_array, n, _lib.stream_ptr(), ms), "h3d_run_ops_timed")

@@ -183,6 +183,7 @@ def dcn_fused_op(kind, x, w, b, wo, bo, dtype="bf16", reserved=0, skip=None, w_u
     """DeformConv with conv_offset_mask fused in, through one of
          'fused'   H3D_OP_DCN_FUSED        (csrc/dcn3.hip, register-staged filters; f32 or bf16)
          'stream'  H3D_OP_DCN_FUSED_STREAM (csrc/dcn3.hip WDMA; bf16)
+         'stream16' the same op of a bf16 plan with an fp16 INPUT (reserved | 0x40000: csrc/dcn3.hip F16IN; x is stored as fp16)
          'f16'     H3D_OP_DCN_FUSED_F16    (csrc/dcn4.hip; x is stored as fp16)
          'updcn'   H3D_OP_UPDCN_F16        (csrc/dcn4.hip UP = 1; x is the LOW-resolution bf16 map, skip/w_up given)
     x/skip NCHW fp32 cpu, w [Co,Ci,3,3], wo [27,Ci,3,3], w_up [C,1,2f,2f].  BatchNorm = identity, ReLU on."""
@@ -200,13 +201,18 @@ def dcn_fused_op(kind, x, w, b, wo, bo, dtype="bf16", reserved=0, skip=None, w_u
         keep += [wp, wop, bias, xin]
     else:
         assert dtype in ("bf16", "f16") and (dtype == "bf16" or kind == "stream")
-        ck = int(_lib.lib().h3d_dcn_fused_ck(Ci, w.shape[0])) if kind == "stream" else 16
+        ck = int(_lib.lib().h3d_dcn_fused_ck(Ci, w.shape[0])) if kind in ("stream", "stream16") else 16
         wimg, woimg, bias, cout, cin, rows = pw.dcn_stream("p", ck)
         wptr = wimg.data_ptr()
         keep += [wimg, woimg, bias]
         if kind == "stream":
             xin, xptr = nhwc(x, dtype)
             opk, in2 = _lib.OP_DCN_FUSED_STREAM, woimg.data_ptr()
+        elif kind == "stream16":
+            xin = x.permute(0, 2, 3, 1).contiguous().to(torch.float16).to(DEV)
+            xptr = xin.data_ptr()
+            opk, in2 = _lib.OP_DCN_FUSED_STREAM, woimg.data_ptr()
+            reserved |= 0x40000
         elif kind == "f16":
             xin = x.permute(0, 2, 3, 1).contiguous().to(torch.float16).to(DEV)
             xptr = xin.data_ptr()

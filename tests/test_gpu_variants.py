@@ -165,6 +165,17 @@ DCN_CASES = [
     ("stream", "bf16", 0x10000, 1, 64, 32, 20, 20, 12.0),  # dcn3<bf16,1,16,2,WDMA,512,PK>
     ("stream", "bf16", 0x10400, 1, 256, 256, 24, 24, 8.0), # dcn3<bf16,4,16,4,WDMA,512>
     ("stream", "f16", 0x10000, 2, 64, 64, 40, 24, 4.0),
+    # stream16: bf16 plan, fp16 INPUT (reserved | 0x40000, csrc/dcn3.hip F16IN: the `node` DeformConvs behind an up-sample + add that
+    # writes fp16); bf16 output
+    ("stream16", "bf16", 0, 2, 64, 64, 40, 24, 0.5),       # dcn3<bf16,2,16,2,WDMA,256,false,F16IN>: the five 64 -> 64 @128x128 nodes
+    ("stream16", "bf16", 0, 2, 64, 64, 40, 24, 6.0),       #   ... patches AND pass 2
+    ("stream16", "bf16", 0, 1, 64, 64, 16, 16, 40.0),
+    ("stream16", "bf16", 0x400, 1, 128, 128, 16, 32, 3.0), # dcn3<bf16,4,16,4,WDMA,256,false,F16IN>: 128 -> 128 @64x64, 256 -> 256 @32x32
+    ("stream16", "bf16", 0x400, 1, 256, 256, 24, 24, 8.0),
+    ("stream16", "bf16", 0, 1, 256, 256, 16, 16, 3.0),     # small grid: 64-channel workgroups
+    ("stream16", "bf16", 0x8000, 2, 64, 64, 40, 24, 6.0),  # wide margin, packed apron
+    ("stream16", "bf16", 0x10000, 2, 64, 64, 40, 24, 4.0), # 512 slots, two rounds
+    ("stream16", "bf16", 0x10400, 1, 256, 256, 24, 24, 8.0),
     # 0x4000: csrc/dcn5.hip (apron AND filters by LDS-DMA; measured slower, kept selectable: DESIGN.md 2.2)
     ("stream", "f16", 0x4000, 2, 128, 64, 24, 40, 0.5),    # dcn5<2,2,.,256>
     ("stream", "f16", 0x4000, 1, 256, 64, 16, 32, 3.0),
@@ -204,8 +215,8 @@ def _dcn_built(case):
                + skip.double()).float().half().float()                    # the folded sum is rounded once, to fp16
         built = dcn_fused_op("updcn", x, w, b, wo, bo, dtype, ov, skip, w_up)
     else:
-        xin = x.half().float() if kind == "f16" else x
-        built = dcn_fused_op(kind, xin if kind == "f16" else x, w, b, wo, bo, dtype, ov)
+        xin = x.half().float() if kind in ("f16", "stream16") else x
+        built = dcn_fused_op(kind, xin if kind in ("f16", "stream16") else x, w, b, wo, bo, dtype, ov)
     return xin, w, b, wo, bo, built
 
 
