@@ -433,6 +433,12 @@ def dry_run(args, world, rank):
 
 def build_detector(arch_name, dtype, size, args, dev, people=None):
     """-> (detector, opt, synthetic state_dict, conv GFLOP per image) for one of the three backbones."""
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # (the factory prints "==> Use DeformConv." like the reference's, model.py:513;
+        return _build_detector(arch_name, dtype, size, args, dev, people)      # stdout carries the ONE JSON line only)
+
+
+def _build_detector(arch_name, dtype, size, args, dev, people=None):
     if arch_name == "dla_34":
         opt = Opt(input_h=size, input_w=size, smpl=True, smpl_people=args.people if people is None else people, dtype=dtype, K=100)
         sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, offset_scale=args.offset_scale, gain=args.weight_gain)
