@@ -60,6 +60,7 @@ SIGNATURES = {
     "h3d_dcn_v2_forward_packed": [c_vp] * 5 + [c_i] * 7 + [c_vp, ctypes.c_size_t, c_vp],
     "h3d_dcn_fused_ck": [c_i, c_i],
     "h3d_dcn_far_samples": [ctypes.POINTER(H3dOp), c_vp, c_vp],
+    "h3d_smpl_pose_heads": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp],
     "h3d_smpl_coef_pack": [c_vp, c_vp, c_i, c_i, c_vp, c_vp],
     "h3d_smpl_verts3": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],
     "h3d_smpl_verts3_exact": [c_vp] * 6 + [c_i] * 5 + [c_vp, c_vp],

@@ -20,21 +20,59 @@ constexpr int SMPL_PF = 207;
 // the outputs are joint-parallel; the kinematic chain walks the joints in their (topological) order and lane j
 // fetches its parent's transform by a shuffle -- 23 short steps instead of a 24-joint serial program per lane with
 // its 24 x 12 transform table in scratch memory (0.13 ms -> 0.02 ms at 6400 persons).
+// HEADS (round 4: the detector's tail as fewer launches): the parameters are read where the network left them -- person p is
+// detection q = p % n of image b = p / n, its betas / thetas are the `shape` / `pose` head maps [B,10|72,HW] at pixel inds[b*K + q]
+// (what `_transpose_and_gather_feat`, utils.py:23-27, would have copied out in two launches) -- and the generation-3 coefficient
+// operand coefK3 [Ppad][14][3][16] (h3d_smpl_coef_pack's output: the h / m / l bf16 terms of [beta | pose_feat | 0], zero rows for
+// p >= P) is written by the lanes that hold the values.  Same arithmetic on the same values: bit-identical to the three launches.
+struct SmplHeadsSrc {
+    const float *pose_map, *shape_map;
+    const int64_t *inds;
+    int n, K, HW;
+    float *betas_out;        // [P,10] (API output; may be NULL)
+    bf16_t *coefK3;          // [Ppad][14][3][16]
+};
+__device__ __forceinline__ void split3(float v, bf16_t &h, bf16_t &m, bf16_t &l);
+
+template <bool HEADS>
 __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__ betas, const float *__restrict__ thetas,
                                                        const float *__restrict__ j_template,
                                                        const float *__restrict__ j_shapedirs,
                                                        const int32_t *__restrict__ parents, int P,
                                                        float *__restrict__ pose_feat, float *__restrict__ A,
-                                                       float *__restrict__ joints, float *__restrict__ coefT, int Ppad)
+                                                       float *__restrict__ joints, float *__restrict__ coefT, int Ppad, SmplHeadsSrc hs)
 {
     const int l = threadIdx.x, j = l & 31, half = l >> 5;
     const int p = blockIdx.x * 2 + half;
     const bool act = p < P && j < SMPL_J;
     const int pc = p < P ? p : P - 1, jc = j < SMPL_J ? j : 0;       // clamped: every lane computes, only `act` lanes store
     float beta[SMPL_NB];
+    [[maybe_unused]] size_t hb = 0;
+    [[maybe_unused]] int hpix = 0;
+    if constexpr (HEADS) {
+        hb = (size_t)(pc / hs.n);
+        const int64_t pix = hs.inds[hb * hs.K + (pc - (int)hb * hs.n)];
+        hpix = (int)(pix < 0 ? 0 : pix >= hs.HW ? hs.HW - 1 : pix);
+#pragma unroll
+        for (int k = 0; k < SMPL_NB; ++k) beta[k] = hs.shape_map[(hb * SMPL_NB + k) * hs.HW + hpix];
+        if (hs.betas_out && p < P && j < SMPL_NB) hs.betas_out[(size_t)p * SMPL_NB + j] = beta[j];
+    } else {
 #pragma unroll
     for (int k = 0; k < SMPL_NB; ++k) beta[k] = betas[(size_t)pc * SMPL_NB + k];
+    }
     if (coefT && p < P && j < SMPL_NB) coefT[(size_t)j * Ppad + p] = beta[j];     // k-major [beta | pose_feat] (gen 2 kernel)
+    [[maybe_unused]] auto put_coef = [&](int k, float v) {          // coefK3[p][k >> 4][term][k & 15], zero rows for p >= P
+        bf16_t hh, mm, ll;
+        split3(p < P ? v : 0.f, hh, mm, ll);
+        bf16_t *o = hs.coefK3 + ((size_t)p * 14 + (k >> 4)) * 48 + (k & 15);
+        o[0] = hh; o[16] = mm; o[32] = ll;
+    };
+    if constexpr (HEADS) {
+        if (p < Ppad) {
+            if (j < SMPL_NB) put_coef(j, beta[j]);
+            if (j >= SMPL_J && j < SMPL_J + 7) put_coef(SMPL_NB + SMPL_PF + (j - SMPL_J), 0.f);      // K padding 217..223
+        }
+    }
     // rest joint of (p, j)
     float jr[3];
 #pragma unroll
@@ -45,7 +83,13 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__
         jr[c] = s;
     }
     // Rodrigues with the smplx convention: angle = ||theta + 1e-8||, axis = theta / angle
-    const float tx = thetas[(size_t)pc * 72 + jc * 3], ty = thetas[(size_t)pc * 72 + jc * 3 + 1], tz = thetas[(size_t)pc * 72 + jc * 3 + 2];
+    float tx, ty, tz;
+    if constexpr (HEADS) {
+        const float *tp = hs.pose_map + (hb * 72 + jc * 3) * hs.HW + hpix;
+        tx = tp[0]; ty = tp[hs.HW]; tz = tp[2 * (size_t)hs.HW];
+    } else {
+        tx = thetas[(size_t)pc * 72 + jc * 3]; ty = thetas[(size_t)pc * 72 + jc * 3 + 1]; tz = thetas[(size_t)pc * 72 + jc * 3 + 2];
+    }
     const float ex = tx + 1e-8f, ey = ty + 1e-8f, ez = tz + 1e-8f;
     const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
     const float inv = 1.f / angle;
@@ -70,6 +114,12 @@ __global__ __launch_bounds__(64) void smpl_pose_kernel(const float *__restrict__
             const float f = R[i] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f);
             pf[i] = f;
             if (coefT) coefT[(size_t)(SMPL_NB + (j - 1) * 9 + i) * Ppad + p] = f;
+        }
+    }
+    if constexpr (HEADS) {
+        if (p < Ppad && j > 0 && j < SMPL_J) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) put_coef(SMPL_NB + (j - 1) * 9 + i, R[i] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f));
         }
     }
     // local transform L = [R | jr - jr(parent)] (root: [R | jr]); G starts as L and becomes G(parent) . L
@@ -121,8 +171,25 @@ extern "C" int h3d_smpl_pose(const float *betas, const float *thetas, const floa
     if (!betas || !thetas || !j_template || !j_shapedirs || !parents || !pose_feat || !A || !joints)
         H3D_FAIL(H3D_ERR_ARG, "smpl_pose: null pointer");
     if (P <= 0 || (coefT && Ppad < P)) H3D_FAIL(H3D_ERR_SHAPE, "smpl_pose: P=%d Ppad=%d", P, Ppad);
-    hipLaunchKernelGGL(smpl_pose_kernel, dim3(cdiv(P, 2)), dim3(64), 0, (hipStream_t)stream, betas, thetas, j_template,
-                       j_shapedirs, parents, P, pose_feat, A, joints, coefT, Ppad);
+    hipLaunchKernelGGL(smpl_pose_kernel<false>, dim3(cdiv(P, 2)), dim3(64), 0, (hipStream_t)stream, betas, thetas, j_template,
+                       j_shapedirs, parents, P, pose_feat, A, joints, coefT, Ppad, SmplHeadsSrc{});
+    H3D_CHECK_LAUNCH("smpl_pose_kernel");
+    return H3D_OK;
+}
+
+extern "C" int h3d_smpl_pose_heads(const float *pose_map, const float *shape_map, const int64_t *inds, int B, int K, int n, int HW,
+                                   const float *j_template, const float *j_shapedirs, const int32_t *parents, float *betas_out,
+                                   float *pose_feat, float *A, float *joints, void *coefK3, int Ppad, void *stream)
+{
+    if (!pose_map || !shape_map || !inds || !j_template || !j_shapedirs || !parents || !pose_feat || !A || !joints || !coefK3)
+        H3D_FAIL(H3D_ERR_ARG, "smpl_pose_heads: null pointer");
+    const int P = B * n;
+    if (B <= 0 || n <= 0 || n > K || HW <= 0 || Ppad < P || Ppad % 128) H3D_FAIL(H3D_ERR_SHAPE, "smpl_pose_heads: B=%d K=%d n=%d HW=%d Ppad=%d", B, K, n, HW, Ppad);
+    SmplHeadsSrc hs;
+    hs.pose_map = pose_map; hs.shape_map = shape_map; hs.inds = inds; hs.n = n; hs.K = K; hs.HW = HW; hs.betas_out = betas_out;
+    hs.coefK3 = (bf16_t *)coefK3;
+    hipLaunchKernelGGL(smpl_pose_kernel<true>, dim3(cdiv(Ppad, 2)), dim3(64), 0, (hipStream_t)stream, nullptr, nullptr, j_template, j_shapedirs,
+                       parents, P, pose_feat, A, joints, nullptr, Ppad, hs);
     H3D_CHECK_LAUNCH("smpl_pose_kernel");
     return H3D_OK;
 }

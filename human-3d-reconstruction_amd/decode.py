@@ -64,9 +64,24 @@ def _map_topk2(a, b, K, flags):
     return outs
 
 
+_ZERO_CLS = {}
+SINGLE_CLASS_SHORTCUT = True      # False: always launch topk_merge_kernel (A/B and bit-identity tests)
+
+
 def _merge(s, i, y, x, K):
     B, C, _ = s.shape
     dev = s.device
+    if C == 1 and SINGLE_CLASS_SHORTCUT:
+        # stage 2 of `_topk` (decode.py:34-39) over ONE class is the identity: the K stage-1 candidates already come sorted by
+        # (score descending, flat index ascending) and the merge orders equal scores by position -- the multi_pose task has one
+        # class (opts.py:248), so its `_topk` is one launch less (64 workgroups of a bitonic sort that moved nothing)
+        key = (B, K, str(dev))
+        if key not in _ZERO_CLS:
+            if len(_ZERO_CLS) >= 16:
+                _ZERO_CLS.pop(next(iter(_ZERO_CLS)))
+            _ZERO_CLS[key] = torch.zeros(B, K, dtype=torch.int32, device=dev)
+            torch.cuda.current_stream(dev).synchronize()         # (filled before any other stream reads it; read-only afterwards)
+        return s.view(B, K), i.view(B, K), _ZERO_CLS[key], y.view(B, K), x.view(B, K)
     o_s = torch.empty(B, K, dtype=torch.float32, device=dev)
     o_i = torch.empty(B, K, dtype=torch.int64, device=dev)
     o_c = torch.empty(B, K, dtype=torch.int32, device=dev)

@@ -85,6 +85,7 @@ class MultiPoseDetector:
             self.model.load_state_dict(state_dict, strict=True)
         self.model.to(self.device).eval()
         self.smpl_model = smpl_model
+        self.fused_tail = True         # False: the decode / SMPL tail as round 3 issued it (A/B and bit-identity tests)
         if opt.smpl and smpl_model is None:
             self.smpl_model = _smpl.SMPLModel.synthetic()
 
@@ -111,13 +112,19 @@ class MultiPoseDetector:
         res = {"dets": dets, "inds": aux["inds"], "heads": out}
         if opt.smpl:
             n = opt.smpl_people or opt.K
-            inds = aux["inds"][:, :n].contiguous()
-            B = inds.shape[0]
-            thetas = _transpose_and_gather_feat(out["pose"], inds).view(B * n, 72)
-            betas = _transpose_and_gather_feat(out["shape"], inds).view(B * n, 10)
-            # f32 (parity-mode) detectors keep all six products of the blend-shape split (fp32-level accuracy end to end)
-            verts, joints = _smpl.lbs(self.smpl_model, betas, thetas, return_joints=True,
-                                      kernel="auto_exact" if opt.dtype == "f32" else "auto")
+            B = aux["inds"].shape[0]
+            if B * n >= 64 and self.fused_tail:
+                # per-detection pose / shape read from the two extra heads at the detection centres INSIDE the SMPL pose kernel, which
+                # also writes the blend-shape operand: two launches instead of six (gathers x 2, index copy, pose, pack, verts)
+                verts, joints = _smpl.lbs_from_heads(self.smpl_model, out["pose"], out["shape"], aux["inds"], n, return_joints=True,
+                                                     exact=opt.dtype == "f32")
+            else:
+                inds = aux["inds"][:, :n].contiguous()
+                thetas = _transpose_and_gather_feat(out["pose"], inds).view(B * n, 72)
+                betas = _transpose_and_gather_feat(out["shape"], inds).view(B * n, 10)
+                # f32 (parity-mode) detectors keep all six products of the blend-shape split (fp32-level accuracy end to end)
+                verts, joints = _smpl.lbs(self.smpl_model, betas, thetas, return_joints=True,
+                                          kernel="auto_exact" if opt.dtype == "f32" else "auto")
             res["verts"] = verts.view(B, n, -1, 3)
             res["joints"] = joints.view(B, n, 24, 3)
         if meta is not None:

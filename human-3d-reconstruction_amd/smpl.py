@@ -169,3 +169,43 @@ def lbs(model, betas, thetas, return_joints=False, kernel="auto"):
                                         _lib.ptr(d["lbs_w"]), d["nnz"], P, d["V"], d["Vpad"], _lib.ptr(verts), st),
                        "smpl_verts")
     return (verts, joints) if return_joints else verts
+
+
+def lbs_from_heads(model, pose_map, shape_map, inds, n, return_joints=False, exact=False):
+    """The detector's SMPL stage straight from the network's outputs: pose_map [B,72,H,W], shape_map [B,10,H,W] (contiguous fp32
+    head maps), inds [B,K] int64 (the decode's centre indices), the first `n` detections of every image -> vertices
+    [B*n,V,3] (and joints [B*n,24,3]).  Two launches -- `h3d_smpl_pose_heads` (gathers + Rodrigues + kinematic chain + the
+    generation-3 coefficient operand) and `h3d_smpl_verts3` -- instead of the five of `_transpose_and_gather_feat` x 2 + `lbs`;
+    bit-identical to them (tests/test_gpu_smpl.py).  Needs <= 4 skinning weights per vertex (generation 3)."""
+    import torch
+    from . import _lib
+    _lib.require_cuda(pose_map, shape_map, inds)
+    dev = pose_map.device
+    if model._dev is None or model._dev["v_template"].device != dev:
+        model._dev = _device_pack(model, dev)
+    d = model._dev
+    if d["nnz"] > 4:
+        raise RuntimeError("lbs_from_heads: more than 4 skinning weights per vertex (use lbs)")
+    if (pose_map.dtype != torch.float32 or shape_map.dtype != torch.float32 or not pose_map.is_contiguous() or not shape_map.is_contiguous()
+            or inds.dtype != torch.int64 or not inds.is_contiguous()):
+        raise RuntimeError("lbs_from_heads: contiguous fp32 head maps and int64 indices expected")
+    B, K = inds.shape
+    HW = pose_map.shape[2] * pose_map.shape[3]
+    if pose_map.shape[:2] != (B, 72) or shape_map.shape[:2] != (B, NUM_BETAS) or shape_map.shape[2:] != pose_map.shape[2:] or not 0 < n <= K:
+        raise RuntimeError("lbs_from_heads: pose [B,72,H,W], shape [B,10,H,W], inds [B,K], 0 < n <= K")
+    P = B * n
+    Ppad = ((P + 127) // 128) * 128
+    pf = torch.empty(P, NUM_POSE_FEAT, dtype=torch.float32, device=dev)
+    A = torch.empty(P, NUM_JOINTS, 12, dtype=torch.float32, device=dev)
+    joints = torch.empty(P, NUM_JOINTS, 3, dtype=torch.float32, device=dev)
+    verts = torch.empty(P, d["V"], 3, dtype=torch.float32, device=dev)
+    coefK = torch.empty(Ppad, 14, 3, 16, dtype=torch.bfloat16, device=dev)
+    L, st = _lib.lib(), _lib.stream_ptr()
+    with torch.cuda.device(dev):
+        _lib.check(L.h3d_smpl_pose_heads(_lib.ptr(pose_map), _lib.ptr(shape_map), _lib.ptr(inds), B, K, n, HW, _lib.ptr(d["j_template"]),
+                                         _lib.ptr(d["j_shapedirs"]), _lib.ptr(d["parents"]), None, _lib.ptr(pf), _lib.ptr(A), _lib.ptr(joints),
+                                         _lib.ptr(coefK), Ppad, st), "smpl_pose_heads")
+        fn = L.h3d_smpl_verts3_exact if exact else L.h3d_smpl_verts3
+        _lib.check(fn(_lib.ptr(coefK), _lib.ptr(A), _lib.ptr(d["v_template"]), _lib.ptr(d["dirsK3"]), _lib.ptr(d["lbs_idx"]), _lib.ptr(d["lbs_w"]),
+                      d["nnz"], P, Ppad, d["V"], d["Vpad"], _lib.ptr(verts), st), "smpl_verts3")
+    return (verts, joints) if return_joints else verts

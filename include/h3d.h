@@ -318,6 +318,14 @@ int h3d_multi_pose_post_process(const float *dets, const float *c, const float *
 int h3d_smpl_pose(const float *betas, const float *thetas, const float *j_template,
                   const float *j_shapedirs, const int32_t *parents, int P,
                   float *pose_feat, float *A, float *joints, float *coefT, int Ppad, void *stream);
+/* h3d_smpl_pose + the two gathers in front of it + h3d_smpl_coef_pack behind it in ONE launch (the detector's tail: at a per-GPU shard
+ * of 8 images every launch of the tail is a sub-wave-count grid on the critical path): person p = detection p % n of image p / n reads
+ * its thetas / betas from the `pose` [B,72,HW] / `shape` [B,10,HW] head maps at pixel inds[(p / n) * K + p % n] -- what
+ * _transpose_and_gather_feat (utils.py:23-27) would copy out -- and coefK3 [Ppad][14][3][16] is written by the lanes that hold the
+ * values (zero rows for p >= B*n; Ppad multiple of 128).  betas_out [B*n,10] may be NULL.  Bit-identical to the separate launches. */
+int h3d_smpl_pose_heads(const float *pose_map, const float *shape_map, const int64_t *inds, int B, int K, int n, int HW,
+                        const float *j_template, const float *j_shapedirs, const int32_t *parents, float *betas_out,
+                        float *pose_feat, float *A, float *joints, void *coefK3, int Ppad, void *stream);
 /* generation 3: blend shapes on the bf16 matrix cores with every fp32 operand split into three bf16 terms
  * (fp32-level accuracy, csrc/smpl.hip).  coefK3 [Ppad][14][3][16] bf16 = per person and K step of 16 the h/m/l terms
  * of [beta | pose_feat | 0] (h3d_smpl_coef_pack; Ppad multiple of 128), dirsK3 [3][Vpad][14][3][16] bf16 = the same

@@ -248,3 +248,22 @@ def test_gather_and_flip_helpers_match_reference_golden(golden_dir):
     assert np.array_equal(utils.flip_tensor(torch.from_numpy(hm).to(DEV)).cpu().numpy(), g["flip_tensor"])
     assert np.array_equal(utils.flip_lr(torch.from_numpy(hm).to(DEV), FLIP_IDX).cpu().numpy(), g["flip_lr"])
     assert np.array_equal(utils.flip_lr_off(torch.from_numpy(hps).to(DEV), FLIP_IDX).cpu().numpy(), g["flip_lr_off"])
+
+
+def test_single_class_topk_shortcut_equals_the_merge_kernel(golden_dir):
+    # multi_pose has ONE class (opts.py:248): stage 2 of `_topk` over one class is the identity, so `_merge` returns views instead of
+    # launching topk_merge_kernel -- the same bits as the kernel, also on a map full of ties, and the same dets end to end
+    from h3d_amd import decode as dec
+    for name, (B, H, W) in (("decode_16x24_k100_tied", (2, 16, 24)), ("decode_128x128_k100", (2, 128, 128))):
+        h = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synth_heads(B, H, W, 17, 2 if "tied" in name else 0).items()}
+        outs = []
+        for flag in (True, False):
+            dec.SINGLE_CLASS_SHORTCUT = flag
+            try:
+                t = dec._topk(dec._nms(h["hm"]), K=100)
+                d = dec.multi_pose_decode(h["hm"], h["wh"], h["hps"], reg=h["reg"], hm_hp=h["hm_hp"], hp_offset=h["hp_offset"], K=100)
+            finally:
+                dec.SINGLE_CLASS_SHORTCUT = True
+            outs.append([x.clone() for x in t] + [d.clone()])
+        for a, b in zip(*outs):
+            assert a.dtype == b.dtype and torch.equal(a, b), name

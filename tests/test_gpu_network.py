@@ -716,3 +716,22 @@ def test_two_processes_return_identical_bits(scale):
     assert outs[0] == outs[1], outs
     if scale >= 2.0:
         assert "[]" not in outs[0], outs[0]                  # some layer did leave the default variant
+
+
+def test_fused_tail_is_bit_identical_to_the_separate_launches():
+    # detector.fused_tail (round 4): no topk_merge launch for the single multi_pose class, the pose / shape gathers and the
+    # blend-shape operand pack inside the SMPL pose kernel -- against round 3's tail (nine launches) on the same heads
+    from h3d_amd import decode as dec
+    opt = Opt(input_h=128, input_w=128, smpl=True, smpl_people=40, dtype="bf16", K=100)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=1.25)
+    det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    x = torch.from_numpy(synth.synth_images(4, 128, 128, seed=11)).to(DEV)
+    a = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in det.run(x).items() if k != "heads"}
+    det.fused_tail, dec.SINGLE_CLASS_SHORTCUT = False, False
+    try:
+        b = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in det.run(x).items() if k != "heads"}
+    finally:
+        det.fused_tail, dec.SINGLE_CLASS_SHORTCUT = True, True
+    assert set(a) == set(b) == {"dets", "inds", "verts", "joints"}
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

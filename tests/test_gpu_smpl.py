@@ -69,3 +69,22 @@ def test_matrix_core_kernel_agrees_with_vector_kernel(model):
     v3x = smpl.lbs(model, betas, thetas, kernel="gen3x")
     assert float((v3x - v2).abs().max()) < 2e-6
     assert float((v3x - v3).abs().max()) > 0.0           # (it is a different kernel instantiation)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_lbs_from_heads_is_bit_identical_to_gathers_plus_lbs(model, exact):
+    # the detector's fused tail (h3d_smpl_pose_heads: gathers + pose + coefficient pack in one launch) against the separate
+    # launches it replaces, on head maps and indices of the detector's shapes; P = 3 x 50 is not a multiple of 128 (zero rows)
+    from h3d_amd.utils import _transpose_and_gather_feat
+    B, K, n, H, W = 3, 100, 50, 16, 24
+    pose = torch.from_numpy(synth.normalish("pose_map", (B, 72, H, W), 0.0, 0.3, 5)).to(DEV)
+    shape = torch.from_numpy(synth.normalish("shape_map", (B, 10, H, W), 0.0, 1.0, 5)).to(DEV)
+    inds = torch.from_numpy((synth.uniform01("inds", (B, K), 5) * H * W).astype(np.int64)).to(DEV)
+    v1, j1 = smpl.lbs_from_heads(model, pose, shape, inds, n, return_joints=True, exact=exact)
+    sub = inds[:, :n].contiguous()
+    thetas = _transpose_and_gather_feat(pose, sub).view(B * n, 72)
+    betas = _transpose_and_gather_feat(shape, sub).view(B * n, 10)
+    v2, j2 = smpl.lbs(model, betas, thetas, return_joints=True, kernel="gen3x" if exact else "gen3")
+    assert torch.equal(v1, v2) and torch.equal(j1, j2)
+    v_ref, _ = osmpl.lbs(betas[:4].cpu().numpy(), thetas[:4].cpu().numpy(), model.numpy_dict())
+    assert np.abs(v1[:4].cpu().numpy() - v_ref).max() < 1e-4
