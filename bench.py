@@ -60,8 +60,8 @@ def op_flops(op):
         return 2.0 * px * (op.Cout + 27) * op.Cin * 9
     if op.kind == _lib.OP_UPDCN_F16:    # DeformConv (+ offset conv) at the output resolution, plus the 2x2-tap up-sampling
         return 2.0 * px * ((op.Cout + 27) * op.Cin * 9 + op.Cin * 4)
-    if op.kind == _lib.OP_STEM3:        # 7x7 3->16 and 3x3 16->16 at full resolution, 3x3 16->32 at half
-        return 2.0 * op.B * (op.H * op.W * 16 * (3 * 49 + 16 * 9) + op.Ho * op.Wo * 32 * 16 * 9)
+    if op.kind == _lib.OP_STEM3:        # 7x7 3->16 and 3x3 16->16 at full resolution, 3x3 16->32 at half (+ level2's 1x1 project 32->64 at a quarter)
+        return 2.0 * op.B * (op.H * op.W * 16 * (3 * 49 + 16 * 9) + op.Ho * op.Wo * 32 * 16 * 9 + (op.Ho // 2) * (op.Wo // 2) * 64 * 32 * (1 if op.in2 else 0))
     if op.kind == _lib.OP_UPADD:
         return 2.0 * px * op.Cout * 4
     if op.kind == _lib.OP_HEADS:
@@ -76,7 +76,7 @@ def op_bytes(op):
     es = 4 if op.dtype == _lib.H3D_F32 else 2
     pin, pout = op.B * op.H * op.W, op.B * op.Ho * op.Wo
     if op.kind in (_lib.OP_STEM, _lib.OP_STEM3, _lib.OP_IM2COL):
-        return 4.0 * pin * op.Cin + es * pout * op.Cout
+        return 4.0 * pin * op.Cin + es * pout * op.Cout + (es * (pout // 4) * 64 if op.kind == _lib.OP_STEM3 and op.in2 else 0)
     if op.kind == _lib.OP_HEADS:
         d = ctypes.cast(op.in2, ctypes.POINTER(_lib.H3dHeadsDesc)).contents
         return es * pin * op.Cin + 4.0 * pout * sum(d.head[i].C for i in range(d.nheads))
@@ -532,7 +532,7 @@ def time_steps(step, steps, warmup, issued=None):
     return time.perf_counter() - t0
 
 
-def shard_sweep(det, images, nslot, dev, batches, steps=30):
+def shard_sweep(det, images, nslot, dev, batches, steps=200):
     """images/s of the SAME detector on the first B images of the batch, for the shard sizes a strong-scaling run of the
     headline batch would hand one GPU (64 over 8 / 4 / 2 GPUs).  Same step as the timed region (network + decode + SMPL,
     `nslot` steps in flight); measured after it, on one GPU."""
@@ -544,9 +544,11 @@ def shard_sweep(det, images, nslot, dev, batches, steps=30):
         ns = steps_in_flight_default("dla_34", b)
         step, _ = make_step(det, sub, ns, 1, b, dev)
         issued = []
-        dt = time_steps(step, steps, ns + 2, issued)          # (the first call of every slot lowers its plan: all inside the warm-up)
-        out[str(b)] = {"images_per_s": round(b * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
-                       "host_issue_ms_per_step": round(1e3 * issued[0] / steps, 3), "steps_in_flight": ns}
+        st = steps if b <= 16 else max(30, steps * 16 // b)     # (a batch-8 step is ~1 ms: 30 steps were 33 ms, ramp and drain of the four
+                                                                #  steps in flight included -- 5 % of the measurement)
+        dt = time_steps(step, st, ns + 2, issued)             # (the first call of every slot lowers its plan: all inside the warm-up)
+        out[str(b)] = {"images_per_s": round(b * st / dt, 1), "ms_per_step": round(1e3 * dt / st, 3),
+                       "host_issue_ms_per_step": round(1e3 * issued[0] / st, 3), "steps_in_flight": ns, "steps": st}
     return out
 
 

@@ -29,6 +29,12 @@ struct Stem3Args {
     int B, H, W, Ho, Wo, out_cs;
     int tiles_x, tiles_y;
     int dbg;               // ABLATE builds: stop after phase dbg (1..3)
+    // PROJ (round 4): level2's residual branch in the same launch -- project(max_pool2x2(level1)) (Tree.downsample + Tree.project,
+    // model.py:200-207, 211-212: level2 is not a level_root, so nothing else reads the pooled map)
+    const uint16_t *wproj;   // [64][32] T: 1x1 filters (BatchNorm folded)
+    const float *bproj;      // [64]
+    void *res_out;           // [B,Ho/2,Wo/2,res_cs] T
+    int res_cs;
 };
 
 constexpr int S3K_TPB = 8;                           // consecutive tiles per workgroup (image patch prefetched one tile ahead)
@@ -37,6 +43,10 @@ constexpr int S3K_ROWB = 1792, S3K_PXB = 48;         // S and L0 tiles: 48 B per
 constexpr int S3K_SH = 19, S3K_LH = 17, S3K_LW = 33;    // (the stem region is 19 x 35)
 constexpr int S3K_LDS_I = S3K_IH * S3K_IW * 8, S3K_LDS_S = S3K_SH * S3K_ROWB, S3K_LDS_L = S3K_LH * S3K_ROWB;
 constexpr int S3K_LDS = S3K_LDS_I + S3K_LDS_S + S3K_LDS_L + 4096;     // + slack: masked lanes of the last groups read past a row
+// PROJ: waves 0-3 each keep 8 pooled level1 pixels x 32 channels (512 B) inside the 4 KB slack above (nothing is ever WRITTEN there
+// by P1 / P2, and what their masked lanes read from it is unused); the 32-pixel B fragments of the `project` MFMAs read 2 KB from a
+// wave's base: stale bytes for pixels 8..31, results unused
+constexpr int S3K_POOL_OFF = S3K_LDS - 4096;
 
 // bias + ReLU + bf16 rounding of one accumulator quad, zero outside the image -- branch free: the ReLU runs on the packed
 // pairs (v_pk_max_i16 against 0: a negative bf16 is a negative int16, rounding never changes the sign, so
@@ -61,7 +71,7 @@ __device__ __forceinline__ f32x4_s3 stem3_mfma16(const u32x4 &fa, const u32x4 &f
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb), acc, 0, 0, 0);
 }
 
-template <typename T>      // bf16_t | f16_t
+template <typename T, bool PROJ = false>      // bf16_t | f16_t
 __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
 {
     __shared__ __attribute__((aligned(16))) char smem[S3K_LDS];
@@ -250,7 +260,80 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
         EpiArgs e;
         e.bias = a.bias + 32; e.res = nullptr; e.out = (char *)a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = 32;
         e.out_cs = a.out_cs; e.res_cs = 0; e.relu = 1; e.out_mode = H3D_OUT_NHWC;
-        tile_epilogue<T, 1, 1, true>(acc, e, b, oy1, ox1, 0, wv, r, h);
+        if constexpr (!PROJ) {
+            tile_epilogue<T, 1, 1, true>(acc, e, b, oy1, ox1, 0, wv, r, h);
+        } else {
+            // level1 output as tile_epilogue's FAST path writes it, then: 2x2 max-pool of the wave's 2 x 16 pixels by two cross-lane
+            // exchanges on the PACKED values (after the ReLU every value is >= +0, so the integer maximum of the bit patterns is the
+            // floating-point maximum, bf16 and fp16 alike) -> 8 pooled pixels x 32 channels in a wave-private LDS tile -> the 1x1
+            // `project` conv on them (64 output channels, K = 32: two accumulating 32x32x16 MFMAs per 32 channels, the instruction
+            // and K order of csrc/conv.hip's 1x1 kernel: bit-identical to the three launches this replaces) -> residual map.
+            typedef short s16x2_p __attribute__((ext_vector_type(2)));
+            char *lp = smem + S3K_POOL_OFF + wv * 512;
+            static_assert(S3K_POOL_OFF + 3 * 512 + 31 * 64 + 64 <= S3K_LDS, "pooled tiles + fragment over-read inside the slack");
+            const int oy = oy1 + py, ox = ox1 + px;
+            const bool in = oy < a.Ho && ox < a.Wo;
+            T *op = reinterpret_cast<T *>(a.out) + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.out_cs + 4 * h;
+            // project filters: lane (r = output channel within a 32-row tile, h) holds K = 16 ks + 8 h .. + 7
+            u32x4 fp[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fp[m][ks] = *reinterpret_cast<const u32x4 *>(a.wproj + (m * 32 + r) * 32 + 16 * ks + 8 * h);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4 *>(a.bias + 32 + 8 * g + 4 * h);
+                const float v0 = fmaxf(acc[0][0][4 * g + 0] + bv.x, 0.f), v1 = fmaxf(acc[0][0][4 * g + 1] + bv.y, 0.f);
+                const float v2 = fmaxf(acc[0][0][4 * g + 2] + bv.z, 0.f), v3 = fmaxf(acc[0][0][4 * g + 3] + bv.w, 0.f);
+                if (in) store4<T>(op + 8 * g, v0, v1, v2, v3);
+                u32x2 pk;
+                if constexpr (std::is_same_v<T, f16_t>) pk = u32x2{pack_f16x2(__builtin_amdgcn_fmed3f(v0, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v1, -65504.f, 65504.f)),
+                                                                  pack_f16x2(__builtin_amdgcn_fmed3f(v2, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(v3, -65504.f, 65504.f))};
+                else pk = u32x2{EP<T>::pack2(v0, v1), EP<T>::pack2(v2, v3)};
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    uint32_t m0 = pk[e2];
+                    m0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_p, m0), __builtin_bit_cast(s16x2_p, (uint32_t)__shfl_xor((int)m0, 1))));
+                    m0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_p, m0), __builtin_bit_cast(s16x2_p, (uint32_t)__shfl_xor((int)m0, 16))));
+                    pk[e2] = m0;
+                }
+                if ((r & 17) == 0) *reinterpret_cast<u32x2 *>(lp + (r >> 1) * 64 + (8 * g + 4 * h) * 2) = pk;      // pooled pixel r / 2 of this wave's row
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's LDS writes are done
+            __builtin_amdgcn_wave_barrier();
+            f32x16 pacc[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pacc[m][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typename ET<T>::frag fb_;
+                fb_.v = *reinterpret_cast<const u32x4 *>(lp + r * 64 + (16 * ks + 8 * h) * 2);      // (pixels 8..31 of the tile: stale bytes, results unused)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    typename ET<T>::frag fa_;
+                    fa_.v = fp[m][ks];
+                    ET<T>::mma(pacc[m], fa_, fb_);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();             // (the tile is rewritten by the next tile's epilogue: reads first)
+            const int qy = (oy1 >> 1) + wv, qx = (ox1 >> 1) + r;
+            const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
+            if (r < 8 && qy < Hp && qx < Wp) {
+                T *rp = reinterpret_cast<T *>(a.res_out) + (((size_t)b * Hp + qy) * Wp + qx) * a.res_cs + 4 * h;
+                const float ninf = -__builtin_inff();
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(a.bproj + m * 32 + 8 * g + 4 * h);
+                        const u32x2 pk = {EP<T>::pack2(EP<T>::clamp(pacc[m][4 * g + 0] + bv.x, ninf), EP<T>::clamp(pacc[m][4 * g + 1] + bv.y, ninf)),
+                                          EP<T>::pack2(EP<T>::clamp(pacc[m][4 * g + 2] + bv.z, ninf), EP<T>::clamp(pacc[m][4 * g + 3] + bv.w, ninf))};
+                        *reinterpret_cast<u32x2 *>(rp + m * 32 + 8 * g) = pk;
+                    }
+            }
+        }
     }
     }   // tiles of this workgroup
 }
@@ -264,13 +347,26 @@ int h3d_launch_stem3(const h3d_op &op, hipStream_t st)
                  (op.W - 1) / 2 + 1, op.Cin, op.Cout, op.Ho, op.Wo);
     if (((uintptr_t)op.bias & 15) || ((uintptr_t)op.w & 15)) H3D_FAIL(H3D_ERR_ARG, "stem3: weights / bias must be 16-byte aligned");
     Stem3Args a;
+    a.wproj = nullptr; a.bproj = nullptr; a.res_out = nullptr; a.res_cs = 0;
+    const bool proj = op.in2 != nullptr;       // in2 = level2's residual map [B,Ho/2,Wo/2,in2_cs] (output); its filters follow level1's in w / bias
+    if (proj) {
+        if (op.in2_cs % 4 || op.in2_cs < 64 || ((uintptr_t)op.in2 & 7) || (op.Ho | op.Wo) & 1)
+            H3D_FAIL(H3D_ERR_SHAPE, "stem3: the fused residual branch needs an even level1 map and a 64-channel output (stride %d)", op.in2_cs);
+        a.wproj = (const uint16_t *)op.w + 16 * 7 * 32 + 5 * 16 * 32 + 32 * 9 * 16;
+        a.bproj = op.bias + 64;
+        a.res_out = (void *)op.in2; a.res_cs = op.in2_cs;
+    }
     a.img = (const float *)op.in; a.w = (const uint16_t *)op.w; a.bias = op.bias; a.out = op.out;
     a.B = op.B; a.H = op.H; a.W = op.W; a.Ho = op.Ho; a.Wo = op.Wo; a.out_cs = op.out_cs;
     a.tiles_x = cdiv(op.Wo, 16); a.tiles_y = cdiv(op.Ho, 8);
     a.dbg = op.reserved;
-    if (h3d_note_kernel("stem3_kernel<%s>", op.dtype == H3D_F16 ? "f16_t" : "unsigned short")) return H3D_OK;
-    if (op.dtype == H3D_F16) hipLaunchKernelGGL(stem3_kernel<f16_t>, dim3(cdiv(op.B * a.tiles_x * a.tiles_y, S3K_TPB)), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(stem3_kernel<bf16_t>, dim3(cdiv(op.B * a.tiles_x * a.tiles_y, S3K_TPB)), dim3(512), 0, st, a);
+    if (h3d_note_kernel(proj ? "stem3_kernel<%s, true>" : "stem3_kernel<%s>", op.dtype == H3D_F16 ? "f16_t" : "unsigned short")) return H3D_OK;
+    const dim3 grid(cdiv(op.B * a.tiles_x * a.tiles_y, S3K_TPB));
+    if (proj) {
+        if (op.dtype == H3D_F16) hipLaunchKernelGGL((stem3_kernel<f16_t, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((stem3_kernel<bf16_t, true>), grid, dim3(512), 0, st, a);
+    } else if (op.dtype == H3D_F16) hipLaunchKernelGGL(stem3_kernel<f16_t>, grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(stem3_kernel<bf16_t>, grid, dim3(512), 0, st, a);
     H3D_CHECK_LAUNCH("stem3_kernel");
     return H3D_OK;
 }

@@ -200,10 +200,17 @@ class PackedWeights:
             self.t[key] = (wp.reshape(co, 7, 32).to(_TORCH_DT[self.dtype]).contiguous().to(self.device), b.float().contiguous().to(self.device))
         return self.t[key]
 
-    def stem3(self):
+    def stem3(self, proj=False):
         """base_layer + level0 + level1 packed for csrc/stem3.hip: bf16 [16][7][32] | [5][16][32] | [32][9][16] and
-        fp32 biases [16 | 16 | 32] (BatchNorm folded)."""
-        key = ("stem3",)
+        fp32 biases [16 | 16 | 32] (BatchNorm folded).  proj: + level2's `project` 1x1 conv (model.py:202-207) [64][32] and its
+        bias [64], for the launch that also produces level2's residual branch."""
+        key = ("stem3", proj)
+        if key not in self.t and proj:
+            flat, bias = self.stem3(False)
+            wp, bp = self._fold(self.sd["base.level2.project.0.weight"], None, "base.level2.project.1")      # [64,32,1,1]
+            assert tuple(wp.shape) == (64, 32, 1, 1)
+            self.t[key] = (torch.cat([flat.cpu(), wp.reshape(64, 32).to(_TORCH_DT[self.dtype])]).contiguous().to(self.device),
+                           torch.cat([bias.cpu(), bp.float()]).contiguous().to(self.device))
         if key not in self.t:
             w0, b0 = self.stem()
             w1, b1 = self._fold(self.sd["base.level0.0.weight"], None, "base.level0.1")       # [16,16,3,3]
@@ -346,6 +353,8 @@ class Plan:
                                # DeformConvs run csrc/dcn3.hip's fp16-input variants (no conversion while the apron is staged)
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
+        fuse_stem_proj=True,   # the fused stem launch also max-pools its output and applies level2's `project` conv (the residual branch of
+                               # level2's first block: nothing else reads the pooled map): two HBM-bound launches and a 67 MB map less
         mixed_heads=0,         # 1: all heads in ONE launch (the kernel picks the 1 / 2 / 3-tile body per head; the halo tile is staged once).
                                # Measured (batch 64, same process / same box): the heads take 1.838 instead of 1.913 ms, but the STEP with
                                # three steps in flight gets 0.4 % slower (8424 / 8465 vs 8461 / 8499 images/s): the merged kernel
@@ -480,7 +489,7 @@ class Plan:
         t = self.conv(x, p + ".conv1.weight", bn=p + ".bn1", stride=stride)
         return self.conv(t, p + ".conv2.weight", bn=p + ".bn2", res=residual, out=out)
 
-    def _tree1(self, x, p, cin, cout, stride, level_root, out, cat=None, bottom=None):
+    def _tree1(self, x, p, cin, cout, stride, level_root, out, cat=None, bottom=None, residual=None):
         """One-level Tree (model.py:209-218).  `cat` = pre-allocated Root input whose trailing
         slices (children) the caller has filled; layout [x2 | x1 | children...].  `bottom`: the
         max-pooled x when the caller already has it (the reference pools the same tensor in the outer
@@ -489,13 +498,17 @@ class Plan:
         if cat is None:
             cat = self._alloc(Ho, Wo, 2 * cout + (cin if level_root else 0))
         s_x2, s_x1 = cat.slice(0, cout), cat.slice(cout, cout)
-        if bottom is not None:
+        if residual is not None:                             # (the caller already has project(pool(x)): csrc/stem3.hip PROJ)
+            assert stride > 1 and not level_root and cin != cout and (residual.H, residual.W, residual.C) == (Ho, Wo, cout)
+        elif bottom is not None:
             assert stride > 1 and not level_root and (bottom.H, bottom.W, bottom.C) == (Ho, Wo, cin)
         elif stride > 1:
             bottom = self.pool(x, cat.slice(2 * cout, cin) if level_root else None)
         else:
             bottom = x
-        if cin != cout:
+        if residual is not None:
+            pass
+        elif cin != cout:
             residual = self.conv(bottom, p + ".project.0.weight", bn=p + ".project.1", relu=False)
         else:
             residual = bottom
@@ -612,10 +625,13 @@ class Plan:
         if self.fuse_stem and self.pw.dtype in LOWP and C[0] == 16 and C[1] == 32:
             # base_layer + level0 + level1 in one launch: the two full-resolution maps never reach HBM (nothing else
             # reads them: DLAUp starts at level 2)
-            w, b = self.pw.stem3()
             y0 = None
             y1 = self._alloc((H - 1) // 2 + 1, (W - 1) // 2 + 1, C[1])
-            self._op(_lib.OP_STEM3, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=y1.ptr, H=H, W=W,
+            proj = self.fuse_stem_proj and C[2] == 64 and y1.H % 2 == 0 and y1.W % 2 == 0
+            w, b = self.pw.stem3(proj)
+            res2 = self._alloc(y1.H // 2, y1.W // 2, C[2]) if proj else None
+            self._op(_lib.OP_STEM3, in_=self.images.data_ptr(), in2=res2.ptr if proj else None, in2_cs=res2.cs if proj else 0,
+                     w=w.data_ptr(), bias=b.data_ptr(), out=y1.ptr, H=H, W=W,
                      Cin=3, in_cs=3, Ho=y1.H, Wo=y1.W, Cout=C[1], out_cs=y1.cs, ksize=7, stride=2, relu=1)
         else:
             w, b = self.pw.stem()
@@ -624,7 +640,8 @@ class Plan:
                      Cin=3, in_cs=3, Ho=H, Wo=W, Cout=C[0], out_cs=x.cs, ksize=7, stride=1, relu=1)
             y0 = self.conv(x, "base.level0.0.weight", bn="base.level0.1")
             y1 = self.conv(y0, "base.level1.0.weight", bn="base.level1.1", stride=2)
-        y2 = self._tree1(y1, "base.level2", C[1], C[2], 2, False, None)
+            res2 = None
+        y2 = self._tree1(y1, "base.level2", C[1], C[2], 2, False, None, residual=res2)
         y3 = self._tree2(y2, "base.level3", C[2], C[3], None)
         y4 = self._tree2(y3, "base.level4", C[3], C[4], None)
         y5 = self._tree1(y4, "base.level5", C[4], C[5], 2, True, None)

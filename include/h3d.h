@@ -131,7 +131,10 @@ enum {
                                      [9*CK/8 + 1 slots][8]: slot tap*CK/8 + j = channels CK*stage + 8j.. of tap `tap` */
     H3D_OP_STEM3 = 13,  /* base_layer + level0 + level1 fused (bf16, csrc/stem3.hip): in = NCHW fp32 images, out = level1 map
                            [B,Ho,Wo,32]; w = bf16 [16][7][32] stem (k = dx*4+c) | [5][16][32] level0 (k = (tap&1)*16+c of tap pair)
-                           | [32][9][16] level1; bias = fp32 [16 | 16 | 32]; Cin = 3, Cout = 32                          */
+                           | [32][9][16] level1; bias = fp32 [16 | 16 | 32]; Cin = 3, Cout = 32.
+                           in2 != NULL (round 4): ALSO level2's residual branch, project(max_pool2x2(level1)) (Tree.downsample + Tree.project,
+                           model.py:200-207): in2 = that OUTPUT map [B,Ho/2,Wo/2,in2_cs] (64 channels, no ReLU); w continues with the 1x1
+                           filters [64][32], bias with their 64 values; Ho, Wo even                                            */
     H3D_OP_DCN_V1 = 8,  /* first-generation DCN kernel (global gather, bf16 weights): kept as an A/B reference */
     H3D_OP_UPDCN_F16 = 14, /* IDAUp's node(up(x) + skip) in one launch (model.py:384-390): depthwise ConvTranspose2d (k = 2f,
                            stride f in {2, 4}) + skip add evaluated while the DeformConv's input tile is staged, then

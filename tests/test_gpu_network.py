@@ -576,6 +576,23 @@ def test_fused_stem_levels_match_three_launches():
         assert e <= 3e-2, (k, e)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(3, 96, 160), (1, 32, 224), (2, 128, 128)])
+def test_stem_launch_with_pool_and_project_is_bit_identical(dtype, shape):
+    # engine.fuse_stem_proj (round 4): the fused stem launch also max-pools its level1 tile and applies level2's `project` 1x1 conv
+    # (model.py:200-207, 211-212) -- against the plan with the max-pool and the 1x1 conv as their own launches: every head bit for
+    # bit (max of packed non-negative values == float max; the 1x1 conv uses the stand-alone kernel's MFMA shape and K order)
+    from h3d_amd import _lib
+    m, _ = _net(True, dtype)
+    B, H, W = shape
+    xs = torch.from_numpy(synth.synth_images(B, H, W, seed=43)).to(DEV)
+    on, off = _ab(m, xs, "fuse_stem_proj")
+    ops = m.engine(xs.device).plan(B, H, W).ops
+    assert ops[0].kind == _lib.OP_STEM3 and ops[0].in2 and sum(op.kind == _lib.OP_MAXPOOL for op in ops) == 3
+    for k in HEADS:
+        assert torch.equal(on[k], off[k]), k
+
+
 @pytest.mark.parametrize("offset_scale", [0.5, 6.0])
 def test_forward_is_deterministic_and_batch_position_independent(offset_scale):
     # a race in one of the LDS pipelines (counted vmcnt / lgkmcnt waits, DMA rings, wave-private staging areas) shows up
