@@ -209,7 +209,7 @@ class PackedWeights:
             flat, bias = self.stem3(False)
             wp, bp = self._fold(self.sd["base.level2.project.0.weight"], None, "base.level2.project.1")      # [64,32,1,1]
             assert tuple(wp.shape) == (64, 32, 1, 1)
-            self.t[key] = (torch.cat([flat.cpu(), wp.reshape(64, 32).to(_TORCH_DT[self.dtype])]).contiguous().to(self.device),
+            self.t[key] = (torch.cat([flat.cpu(), wp.reshape(-1).to(_TORCH_DT[self.dtype])]).contiguous().to(self.device),
                            torch.cat([bias.cpu(), bp.float()]).contiguous().to(self.device))
         if key not in self.t:
             w0, b0 = self.stem()
