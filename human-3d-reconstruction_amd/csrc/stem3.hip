@@ -43,9 +43,8 @@ constexpr int S3K_ROWB = 1792, S3K_PXB = 48;         // S and L0 tiles: 48 B per
 constexpr int S3K_SH = 19, S3K_LH = 17, S3K_LW = 33;    // (the stem region is 19 x 35)
 constexpr int S3K_LDS_I = S3K_IH * S3K_IW * 8, S3K_LDS_S = S3K_SH * S3K_ROWB, S3K_LDS_L = S3K_LH * S3K_ROWB;
 constexpr int S3K_LDS = S3K_LDS_I + S3K_LDS_S + S3K_LDS_L + 4096;     // + slack: masked lanes of the last groups read past a row
-// PROJ: waves 0-3 each keep 8 pooled level1 pixels x 32 channels (512 B) inside the 4 KB slack above (nothing is ever WRITTEN there
-// by P1 / P2, and what their masked lanes read from it is unused); the 32-pixel B fragments of the `project` MFMAs read 2 KB from a
-// wave's base: stale bytes for pixels 8..31, results unused
+// PROJ: the 4 KB slack above doubles as two buffers (tile parity) of 4 pooled level1 rows x 8 pixels x 32 channels (512 B per row):
+// nothing is ever WRITTEN there by P1 / P2, and what their masked lanes read from it is unused
 constexpr int S3K_POOL_OFF = S3K_LDS - 4096;
 
 // bias + ReLU + bf16 rounding of one accumulator quad, zero outside the image -- branch free: the ReLU runs on the packed
@@ -131,6 +130,46 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     float b0[4], b1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { b0[i] = a.bias[4 * q + i]; b1[i] = a.bias[16 + 4 * q + i]; }
+
+    // PROJ: the 1x1 `project` conv on the pooled rows of tile `tj` (written by waves 0-3 in that tile's P3, at least one workgroup
+    // barrier ago), by wave wv - 4 for pooled row wv - 4: 64 output channels, K = 32 -- two accumulating 32x32x16 MFMAs per 32
+    // channels, the instruction and K order of csrc/conv.hip's 1x1 kernel (bit-identical to it); the 32 pixel columns of the MFMA
+    // carry the row's 8 pooled pixels four times over (columns 8..31 are not stored)
+    [[maybe_unused]] auto proj_tile = [&](int tj) {
+        if constexpr (PROJ) {
+            const int r = l & 31, h = l >> 5, w4 = wv - 4;
+            const int pb = tj / tiles, pt = tj - pb * tiles;
+            const int pty = pt / a.tiles_x, ptx = pt - pty * a.tiles_x;
+            const char *lp = smem + S3K_POOL_OFF + ((tj & 1) * 4 + w4) * 512;
+            const int qy = pty * 4 + w4, qx = ptx * 8 + r;
+            const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
+            const bool st_ok = r < 8 && qy < Hp && qx < Wp;
+            T *rp = reinterpret_cast<T *>(a.res_out) + (((size_t)pb * Hp + qy) * Wp + qx) * a.res_cs + 4 * h;
+            const float ninf = -__builtin_inff();
+#pragma unroll 1
+            for (int m = 0; m < 2; ++m) {                    // (one 32-channel tile at a time: 16 accumulator registers, the kernel sits at its 128-VGPR cap)
+                f32x16 pacc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    typename ET<T>::frag fa_, fb_;           // lane (r = output channel within the tile, h) holds K = 16 ks + 8 h .. + 7
+                    fb_.v = *reinterpret_cast<const u32x4 *>(lp + (r & 7) * 64 + (16 * ks + 8 * h) * 2);
+                    fa_.v = *reinterpret_cast<const u32x4 *>(a.wproj + (m * 32 + r) * 32 + 16 * ks + 8 * h);
+                    ET<T>::mma(pacc, fa_, fb_);
+                }
+                if (st_ok) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bv = *reinterpret_cast<const float4 *>(a.bproj + m * 32 + 8 * g + 4 * h);
+                        const u32x2 pk = {EP<T>::pack2(EP<T>::clamp(pacc[4 * g + 0] + bv.x, ninf), EP<T>::clamp(pacc[4 * g + 1] + bv.y, ninf)),
+                                          EP<T>::pack2(EP<T>::clamp(pacc[4 * g + 2] + bv.z, ninf), EP<T>::clamp(pacc[4 * g + 3] + bv.w, ninf))};
+                        *reinterpret_cast<u32x2 *>(rp + m * 32 + 8 * g) = pk;
+                    }
+                }
+            }
+        }
+    };
 
     for (int ti = t_first; ti < min(t_first + S3K_TPB, ntile); ++ti) {
     const int b = ti / tiles;
@@ -265,21 +304,13 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
         } else {
             // level1 output as tile_epilogue's FAST path writes it, then: 2x2 max-pool of the wave's 2 x 16 pixels by two cross-lane
             // exchanges on the PACKED values (after the ReLU every value is >= +0, so the integer maximum of the bit patterns is the
-            // floating-point maximum, bf16 and fp16 alike) -> 8 pooled pixels x 32 channels in a wave-private LDS tile -> the 1x1
-            // `project` conv on them (64 output channels, K = 32: two accumulating 32x32x16 MFMAs per 32 channels, the instruction
-            // and K order of csrc/conv.hip's 1x1 kernel: bit-identical to the three launches this replaces) -> residual map.
+            // floating-point maximum, bf16 and fp16 alike) -> 8 pooled pixels x 32 channels into this tile's buffer of pooled rows;
+            // waves 4-7 (idle in P3) turn the PREVIOUS tile's buffer into the residual map meanwhile (proj_tile below)
             typedef short s16x2_p __attribute__((ext_vector_type(2)));
-            char *lp = smem + S3K_POOL_OFF + wv * 512;
-            static_assert(S3K_POOL_OFF + 3 * 512 + 31 * 64 + 64 <= S3K_LDS, "pooled tiles + fragment over-read inside the slack");
+            char *lp = smem + S3K_POOL_OFF + ((ti & 1) * 4 + wv) * 512;
             const int oy = oy1 + py, ox = ox1 + px;
             const bool in = oy < a.Ho && ox < a.Wo;
             T *op = reinterpret_cast<T *>(a.out) + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.out_cs + 4 * h;
-            // project filters: lane (r = output channel within a 32-row tile, h) holds K = 16 ks + 8 h .. + 7
-            u32x4 fp[2][2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) fp[m][ks] = *reinterpret_cast<const u32x4 *>(a.wproj + (m * 32 + r) * 32 + 16 * ks + 8 * h);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 bv = *reinterpret_cast<const float4 *>(a.bias + 32 + 8 * g + 4 * h);
@@ -299,43 +330,16 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
                 }
                 if ((r & 17) == 0) *reinterpret_cast<u32x2 *>(lp + (r >> 1) * 64 + (8 * g + 4 * h) * 2) = pk;      // pooled pixel r / 2 of this wave's row
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the wave's LDS writes are done
-            __builtin_amdgcn_wave_barrier();
-            f32x16 pacc[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pacc[m][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                typename ET<T>::frag fb_;
-                fb_.v = *reinterpret_cast<const u32x4 *>(lp + r * 64 + (16 * ks + 8 * h) * 2);      // (pixels 8..31 of the tile: stale bytes, results unused)
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    typename ET<T>::frag fa_;
-                    fa_.v = fp[m][ks];
-                    ET<T>::mma(pacc[m], fa_, fb_);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();             // (the tile is rewritten by the next tile's epilogue: reads first)
-            const int qy = (oy1 >> 1) + wv, qx = (ox1 >> 1) + r;
-            const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
-            if (r < 8 && qy < Hp && qx < Wp) {
-                T *rp = reinterpret_cast<T *>(a.res_out) + (((size_t)b * Hp + qy) * Wp + qx) * a.res_cs + 4 * h;
-                const float ninf = -__builtin_inff();
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(a.bproj + m * 32 + 8 * g + 4 * h);
-                        const u32x2 pk = {EP<T>::pack2(EP<T>::clamp(pacc[m][4 * g + 0] + bv.x, ninf), EP<T>::clamp(pacc[m][4 * g + 1] + bv.y, ninf)),
-                                          EP<T>::pack2(EP<T>::clamp(pacc[m][4 * g + 2] + bv.z, ninf), EP<T>::clamp(pacc[m][4 * g + 3] + bv.w, ninf))};
-                        *reinterpret_cast<u32x2 *>(rp + m * 32 + 8 * g) = pk;
-                    }
-            }
         }
+    } else if constexpr (PROJ) {
+        if (ti > t_first) proj_tile(ti - 1);
     }
     }   // tiles of this workgroup
+    if constexpr (PROJ) {                                    // the last tile's pooled rows
+        const int t_last = min(t_first + S3K_TPB, ntile) - 1;
+        __syncthreads();
+        if (wv >= 4 && t_last >= t_first) proj_tile(t_last);
+    }
 }
 
 int h3d_launch_stem3(const h3d_op &op, hipStream_t st)
