@@ -131,41 +131,45 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
 #pragma unroll
     for (int i = 0; i < 4; ++i) { b0[i] = a.bias[4 * q + i]; b1[i] = a.bias[16 + 4 * q + i]; }
 
-    // PROJ: the 1x1 `project` conv on the pooled rows of tile `tj` (written by waves 0-3 in that tile's P3, at least one workgroup
-    // barrier ago), by wave wv - 4 for pooled row wv - 4: 64 output channels, K = 32 -- two accumulating 32x32x16 MFMAs per 32
-    // channels, the instruction and K order of csrc/conv.hip's 1x1 kernel (bit-identical to it); the 32 pixel columns of the MFMA
-    // carry the row's 8 pooled pixels four times over (columns 8..31 are not stored)
+    // PROJ: the 1x1 `project` conv on the 4 x 8 pooled pixels of tile `tj` (written by waves 0-3 in that tile's P3, at least one
+    // workgroup barrier ago) by waves 4 and 5 (idle in P3): wave 4 + m computes output channels 32 m .. 32 m + 31 of all 32 pixels
+    // (one full N tile), K = 32 as two accumulating 32x32x16 MFMAs -- the instruction and K order of csrc/conv.hip's 1x1 kernel:
+    // bit-identical to it.  Its two filter fragments stay in registers for the whole launch (fetched per tile they put two
+    // dependent memory round trips into every tile: 0.71 ms instead of 0.48)
+    [[maybe_unused]] u32x4 fpw[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if constexpr (PROJ) {
+        if (wv == 4 || wv == 5) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fpw[ks] = *reinterpret_cast<const u32x4 *>(a.wproj + ((wv - 4) * 32 + (l & 31)) * 32 + 16 * ks + 8 * (l >> 5));
+        }
+    }
     [[maybe_unused]] auto proj_tile = [&](int tj) {
         if constexpr (PROJ) {
-            const int r = l & 31, h = l >> 5, w4 = wv - 4;
+            const int r = l & 31, h = l >> 5, m = wv - 4;
             const int pb = tj / tiles, pt = tj - pb * tiles;
             const int pty = pt / a.tiles_x, ptx = pt - pty * a.tiles_x;
-            const char *lp = smem + S3K_POOL_OFF + ((tj & 1) * 4 + w4) * 512;
-            const int qy = pty * 4 + w4, qx = ptx * 8 + r;
+            const char *lp = smem + S3K_POOL_OFF + ((tj & 1) * 4 + (r >> 3)) * 512 + (r & 7) * 64 + 16 * h;      // pooled pixel (row r / 8, column r % 8)
+            f32x16 pacc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typename ET<T>::frag fa_, fb_;
+                fb_.v = *reinterpret_cast<const u32x4 *>(lp + 32 * ks);
+                fa_.v = fpw[ks];
+                ET<T>::mma(pacc, fa_, fb_);
+            }
+            const int qy = pty * 4 + (r >> 3), qx = ptx * 8 + (r & 7);
             const int Hp = a.Ho >> 1, Wp = a.Wo >> 1;
-            const bool st_ok = r < 8 && qy < Hp && qx < Wp;
-            T *rp = reinterpret_cast<T *>(a.res_out) + (((size_t)pb * Hp + qy) * Wp + qx) * a.res_cs + 4 * h;
-            const float ninf = -__builtin_inff();
-#pragma unroll 1
-            for (int m = 0; m < 2; ++m) {                    // (one 32-channel tile at a time: 16 accumulator registers, the kernel sits at its 128-VGPR cap)
-                f32x16 pacc;
+            if (qy < Hp && qx < Wp) {
+                T *rp = reinterpret_cast<T *>(a.res_out) + (((size_t)pb * Hp + qy) * Wp + qx) * a.res_cs + m * 32 + 4 * h;
+                const float ninf = -__builtin_inff();
 #pragma unroll
-                for (int i = 0; i < 16; ++i) pacc[i] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    typename ET<T>::frag fa_, fb_;           // lane (r = output channel within the tile, h) holds K = 16 ks + 8 h .. + 7
-                    fb_.v = *reinterpret_cast<const u32x4 *>(lp + (r & 7) * 64 + (16 * ks + 8 * h) * 2);
-                    fa_.v = *reinterpret_cast<const u32x4 *>(a.wproj + (m * 32 + r) * 32 + 16 * ks + 8 * h);
-                    ET<T>::mma(pacc, fa_, fb_);
-                }
-                if (st_ok) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(a.bproj + m * 32 + 8 * g + 4 * h);
-                        const u32x2 pk = {EP<T>::pack2(EP<T>::clamp(pacc[4 * g + 0] + bv.x, ninf), EP<T>::clamp(pacc[4 * g + 1] + bv.y, ninf)),
-                                          EP<T>::pack2(EP<T>::clamp(pacc[4 * g + 2] + bv.z, ninf), EP<T>::clamp(pacc[4 * g + 3] + bv.w, ninf))};
-                        *reinterpret_cast<u32x2 *>(rp + m * 32 + 8 * g) = pk;
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(a.bproj + m * 32 + 8 * g + 4 * h);
+                    const u32x2 pk = {EP<T>::pack2(EP<T>::clamp(pacc[4 * g + 0] + bv.x, ninf), EP<T>::clamp(pacc[4 * g + 1] + bv.y, ninf)),
+                                      EP<T>::pack2(EP<T>::clamp(pacc[4 * g + 2] + bv.z, ninf), EP<T>::clamp(pacc[4 * g + 3] + bv.w, ninf))};
+                    *reinterpret_cast<u32x2 *>(rp + 8 * g) = pk;
                 }
             }
         }
@@ -332,13 +336,13 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
             }
         }
     } else if constexpr (PROJ) {
-        if (ti > t_first) proj_tile(ti - 1);
+        if (wv < 6 && ti > t_first) proj_tile(ti - 1);
     }
     }   // tiles of this workgroup
     if constexpr (PROJ) {                                    // the last tile's pooled rows
         const int t_last = min(t_first + S3K_TPB, ntile) - 1;
         __syncthreads();
-        if (wv >= 4 && t_last >= t_first) proj_tile(t_last);
+        if ((wv == 4 || wv == 5) && t_last >= t_first) proj_tile(t_last);
     }
 }
 
