@@ -353,8 +353,12 @@ class Plan:
                                # DeformConvs run csrc/dcn3.hip's fp16-input variants (no conversion while the apron is staged)
         share_pool=True,       # False: level3/level4 max-pool their input twice (outer and inner tree), as the reference does
         fuse_stem=True,        # False: base_layer, level0 and level1 as three launches
-        fuse_stem_proj=True,   # the fused stem launch also max-pools its output and applies level2's `project` conv (the residual branch of
-                               # level2's first block: nothing else reads the pooled map): two HBM-bound launches and a 67 MB map less
+        fuse_stem_proj=False,  # True: the fused stem launch also max-pools its output and applies level2's `project` conv (the residual branch
+                               # of level2's first block: nothing else reads the pooled map): two HBM-bound launches and a 67 MB map less,
+                               # bit-identical -- and measured a wash (round 4, same process, batch 64): the stem launch goes from 0.455 to
+                               # 0.622 ms for the 0.113 ms of the two launches it absorbs (0.912 with the 1x1 conv on the waves that pool,
+                               # 0.710 with its filters fetched per tile): the kernel sits at its 128-VGPR cap (52 more bytes of scratch)
+                               # and its P3 phase, which every wave of the workgroup waits for, gets 16 cross-lane exchanges longer
         mixed_heads=0,         # 1: all heads in ONE launch (the kernel picks the 1 / 2 / 3-tile body per head; the halo tile is staged once).
                                # Measured (batch 64, same process / same box): the heads take 1.838 instead of 1.913 ms, but the STEP with
                                # three steps in flight gets 0.4 % slower (8424 / 8465 vs 8461 / 8499 images/s): the merged kernel

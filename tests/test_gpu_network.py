@@ -586,7 +586,7 @@ def test_stem_launch_with_pool_and_project_is_bit_identical(dtype, shape):
     m, _ = _net(True, dtype)
     B, H, W = shape
     xs = torch.from_numpy(synth.synth_images(B, H, W, seed=43)).to(DEV)
-    on, off = _ab(m, xs, "fuse_stem_proj")
+    on, off = _ab(m, xs, "fuse_stem_proj")          # (leaves the flag on: the plan below is the fused one; off by default, see engine.Plan.FLAGS)
     ops = m.engine(xs.device).plan(B, H, W).ops
     assert ops[0].kind == _lib.OP_STEM3 and ops[0].in2 and sum(op.kind == _lib.OP_MAXPOOL for op in ops) == 3
     for k in HEADS:
