@@ -48,7 +48,7 @@ from h3d_amd.detector import MultiPoseDetector, Opt, gather_detections, shard_ba
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_MFMA_TFLOPS = {"bf16": PEAK_BF16_MFMA_TFLOPS, "f16": PEAK_BF16_MFMA_TFLOPS, "f32": 157.3}
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # this round's counter passes; a kernel that is not in it reports traffic: null
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # this round's counter passes; a kernel that is not in it reports traffic: null
 
 
 def op_flops(op):
