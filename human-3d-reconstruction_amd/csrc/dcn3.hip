@@ -116,7 +116,9 @@ __device__ __forceinline__ u32x4 dcn3_patch_corner(const char *img, int bytes, i
 // kernel writes it as fp16 (H3D_OUT_NHWC_F16) and the bf16 -> fp16 conversion of every staged apron vector (3 VALU per pair, between
 // the two barriers of a stage where all eight waves do the same thing) disappears; the sample is also more precise (11 significand
 // bits instead of 8).  Selected by h3d_op.reserved & 0x40000.
-template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false, int NP = 0, bool PK = false, bool F16IN = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
+// STATS: the statistics launch of h3d_dcn_far_samples -- its own instantiation (phase A + geometry only; everything behind the
+// slot count is compiled out), so that a profiler lists it under its own name and the production kernel carries no switch for it.
+template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false, int NP = 0, bool PK = false, bool F16IN = false, bool STATS = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
 __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dcn3Args a)
 {
     using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP, PK>;
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             for (int w8 = 0; w8 < 8; ++w8) nwant += s_cnt[w8];
         }
         overflow = nwant > NP;                                           // workgroup-uniform: some sample found no slot
-        if (a.dbg & 0x20000) {
+        if constexpr (STATS) {
             // statistics launch (h3d_dcn_far_samples): `out` is an int32 array with one entry per 16x16 tile; the tile's number of
             // samples whose corners leave THIS variant's apron is all that is produced (what DLAEngine.calibrate_dcn_margins
             // chooses the per-layer variant from -- a deterministic function of the layer's input, not a stopwatch)
@@ -815,6 +817,13 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
                               : PK ? "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d, true>" : "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", h3d_tname<T>(), MT, CK, MARGIN, epi,
                         WDMA ? "true" : "false", NP))
         return H3D_OK;
+    if constexpr (NP > 0) {
+        if (a.dbg & 0x20000) {                  // h3d_dcn_far_samples
+            hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1, WDMA, NP, PK, F16IN, true>), dim3(grid.x), dim3(C::THREADS), 0, st, a);
+            H3D_CHECK_LAUNCH("dcn3_kernel<stats>");
+            return H3D_OK;
+        }
+    }
     if constexpr (sizeof(T) == 2 && MT >= 2) {
         if (epi == 2) {
             hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 2, WDMA, NP, PK, F16IN>), grid, dim3(C::THREADS), 0, st, a);
