@@ -17,9 +17,10 @@ n = len(plan.ops)
 ms = (ctypes.c_float * n)()
 KIND = {'dcn': _lib.OP_DCN, 'heads': _lib.OP_HEADS, 'dcnf': _lib.OP_DCN_FUSED, 'dcns': _lib.OP_DCN_FUSED_STREAM, 'dcn4': _lib.OP_DCN_FUSED_F16, 'updcn': _lib.OP_UPDCN_F16}[sys.argv[2] if len(sys.argv) > 2 else 'dcn']
 idx = [i for i, op in enumerate(plan.ops) if op.kind == KIND]
+keep = {i: plan.ops[i].reserved & 0x58600 for i in idx}      # variant bits (margin / slots / workgroup width / fp16 input) stay: only the low ablation bits change
 for dbg in ((0, 1) if KIND == _lib.OP_HEADS else (0, 1, 2, 3, 4) if KIND == _lib.OP_UPDCN_F16 else (0, 0x100, 1, 2, 3, 4, 0x101, 0x102, 0x103, 0x104) if KIND == _lib.OP_DCN_FUSED_F16 else (0, 1, 2, 4, 6, 7, 8, 15, 16, 31)):
     for i in idx:
-        plan.op_array[i].reserved = dbg
+        plan.op_array[i].reserved = dbg | (keep[i] if KIND == _lib.OP_DCN_FUSED_STREAM else 0)
     tot = np.zeros(n)
     for _ in range(3):
         _lib.check(_lib.lib().h3d_run_ops_timed(plan.op_array, n, _lib.stream_ptr(), ms), "timed")

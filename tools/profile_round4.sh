@@ -7,9 +7,9 @@ O=gpurun_out/r4prof
 mkdir -p $O
 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --pipeline 1 > $O/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o s -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --pipeline 1 > $O/prof_stats.log 2>&1
 echo stats1 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_p3 -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/prof_stats_p3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_p3 -o s -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/prof_stats_p3.log 2>&1
 echo stats3 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --pipeline 1 > $O/pmc_f.log 2>&1
 echo fetch done
