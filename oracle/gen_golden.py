@@ -17,6 +17,8 @@ What is recorded
                        `dla_net(heads, not_use_dcn=True)` on synth_images(2, 512, 512, seed=317) with gain-1.25 weights;
                        records the raw `hm` / `hm_hp` logits, every 4th pixel of the other heads, `dets`, `_topk` and
                        `_topk_channel` outputs, and the NMS survivor counts.
+  e2e_ctdet_256.npz    the `ctdet` task the same way (trainer.py:444-455): 80-class `hm`, `wh`, `reg` heads on 2 x 256 x 256 ->
+                       `_sigmoid` -> `ctdet_decode(K=100)`: `dets`, `_topk` outputs, `wh` / `reg`, every 2nd pixel of `hm`.
   decode_*.npz         reference `_nms/_topk/_topk_channel/multi_pose_decode/ctdet_decode`
                        (models/decode.py) outputs on synthetic post-sigmoid heads.
   sigmoid.npz          reference `_sigmoid` (models/utils.py:8-10) on a logit ramp.
@@ -123,6 +125,32 @@ def gen_e2e():
           "survivors", rec["nms_hm_nonzero"], "top score", s[:, 0].numpy(), "100th", s[:, -1].numpy())
 
 
+def gen_e2e_ctdet():
+    """The `ctdet` task end to end by the imported reference (trains/trainer.py:444-455): `dla_net({'hm': 80, 'wh': 2, 'reg': 2},
+    not_use_dcn=True)` on synth_images(2, 256, 256, seed=317), gain-1.1 weights (at 1.15 and above the 80-class map saturates the
+    1 - 1e-4 clamp on more than 100 pixels: every top score equal) -> `_sigmoid(hm)` (trainer.py:93) ->
+    `ctdet_decode(hm, wh, reg=reg, K=100)` (decode.py:44-75)."""
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    m = ref_model.dla_net(heads, not_use_dcn=True).eval()
+    shapes = {k: list(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes, seed=0, gain=1.1)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    x = synth.synth_images(2, 256, 256, seed=317)
+    with torch.no_grad():
+        out = m(torch.from_numpy(x))[0]
+        rec = {"hm_s2": out["hm"][:, :, ::2, ::2].contiguous().numpy().copy(), "wh": out["wh"].numpy().copy(), "reg": out["reg"].numpy().copy()}
+        hm = ref_utils._sigmoid(out["hm"])
+        heat = ref_decode._nms(hm)
+        s, inds, clses, ys, xs = ref_decode._topk(heat, K=100)
+        rec.update(topk_scores=s.numpy(), topk_inds=inds.numpy(), topk_clses=clses.numpy())
+        dets = ref_decode.ctdet_decode(hm, out["wh"], reg=out["reg"], K=100)
+        rec["dets"] = dets.numpy()
+    np.savez_compressed(os.path.join(OUT, "e2e_ctdet_256.npz"), **rec)
+    print("e2e_ctdet_256: top score", s[:, 0].numpy(), "100th", s[:, -1].numpy(), "classes used", len(set(clses.numpy().ravel().tolist())))
+
+
 def gen_decode():
     for name, (B, H, W, K, seed, use_reg, use_hm_hp, use_off) in DECODE_CASES.items():
         h = {k: torch.from_numpy(v) for k, v in synth.synth_heads(B, H, W, 17, seed).items()}
@@ -194,6 +222,10 @@ if __name__ == "__main__":
     if "--e2e-only" in sys.argv:
         gen_dla_gain()
         gen_e2e()
+        gen_e2e_ctdet()
+        raise SystemExit(0)
+    if "--ctdet-only" in sys.argv:
+        gen_e2e_ctdet()
         raise SystemExit(0)
     gen_sigmoid()
     gen_utils()
@@ -201,4 +233,5 @@ if __name__ == "__main__":
     gen_dla()
     gen_dla_gain()
     gen_e2e()
+    gen_e2e_ctdet()
     print("golden vectors written to", OUT)

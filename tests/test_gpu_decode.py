@@ -267,3 +267,30 @@ def test_single_class_topk_shortcut_equals_the_merge_kernel(golden_dir):
             outs.append([x.clone() for x in t] + [d.clone()])
         for a, b in zip(*outs):
             assert a.dtype == b.dtype and torch.equal(a, b), name
+
+
+def test_ctdet_end_to_end_f32_vs_reference_output(golden_dir):
+    """The `ctdet` task entry against reference OUTPUT (tests/golden/e2e_ctdet_256.npz: the imported reference's plain-conv
+    `dla_net` with the ctdet heads -> `_sigmoid` -> `ctdet_decode(K=100)`, trainer.py:444-455): the product's `CtdetDetector`
+    (f32 plan, `not_use_dcn=True`) returns the reference's top-100 indices and classes on both images and its `dets` within
+    2e-3 px / 2e-6 of score."""
+    import os
+    from h3d_amd import arch
+    from h3d_amd.detector import Opt, make_detector
+    g = np.load(os.path.join(golden_dir, "e2e_ctdet_256.npz"))
+    opt = Opt(task="ctdet", input_h=256, input_w=256, dtype="f32", K=100, num_classes=80, not_use_dcn=True)
+    sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, False), seed=0, gain=1.1)
+    det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
+    res = det.run(torch.from_numpy(synth.synth_images(2, 256, 256, seed=317)).to(DEV))
+    heads = {k: v.cpu().numpy() for k, v in res["heads"].items()}
+    assert float(np.abs(heads["hm"][:, :, ::2, ::2] - g["hm_s2"]).max()) <= 2e-4
+    for k in ("wh", "reg"):
+        assert float(np.abs(heads[k] - g[k]).max()) <= 2e-4, k
+    from h3d_amd import decode as dec
+    s, inds, clses, ys, xs = dec._topk(dec._nms(utils._sigmoid(res["heads"]["hm"].clone())), K=100)
+    np.testing.assert_array_equal(inds.cpu().numpy(), g["topk_inds"])
+    np.testing.assert_array_equal(clses.cpu().numpy(), g["topk_clses"])
+    np.testing.assert_allclose(s.cpu().numpy(), g["topk_scores"], rtol=0, atol=2e-6)
+    d = res["dets"].cpu().numpy()
+    np.testing.assert_allclose(d, g["dets"], rtol=0, atol=2e-3)
+    np.testing.assert_array_equal(d[..., 5], g["dets"][..., 5])

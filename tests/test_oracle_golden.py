@@ -200,3 +200,29 @@ def test_end_to_end_images_to_indices_matches_reference(golden_dir):
             checked += q
             assert q == 0 or eq.mean() >= 0.97, (b, j, q, eq.mean())
     assert checked >= 500, checked
+
+
+def test_ctdet_end_to_end_matches_reference(golden_dir):
+    """The `ctdet` task (trainer.py:444-455) against reference OUTPUT: e2e_ctdet_256.npz = the imported reference's
+    `dla_net({'hm': 80, 'wh': 2, 'reg': 2}, not_use_dcn=True)` -> `_sigmoid` -> `ctdet_decode(K=100)` on two 256x256 images.
+    The oracle network reproduces the heads; its decode ON THE REFERENCE'S HEADS reproduces `_topk` (indices, classes) and `dets`
+    bit for bit (all 200 top scores are distinct)."""
+    g = np.load(os.path.join(golden_dir, "e2e_ctdet_256.npz"))
+    heads = {"hm": 80, "wh": 2, "reg": 2}
+    sd = synth.synth_state_dict(odla.state_dict_shapes(heads, use_dcn=False), seed=0, gain=1.1)
+    torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+    with torch.no_grad():
+        out = {k: v.numpy() for k, v in odla.DLAOracle(sd, heads, use_dcn=False)(torch.from_numpy(synth.synth_images(2, 256, 256, seed=317)))[0].items()}
+    np.testing.assert_allclose(out["hm"][:, :, ::2, ::2], g["hm_s2"], rtol=0, atol=2e-5 * float(np.abs(g["hm_s2"]).max()))
+    for k in ("wh", "reg"):
+        np.testing.assert_allclose(out[k], g[k], rtol=0, atol=2e-5 * float(np.abs(g[k]).max()), err_msg=k)
+    assert len(np.unique(g["topk_scores"])) == 200
+    # decode on the oracle's own heads: same peaks (the head difference is 1e-5 of a logit, the score gaps are larger)
+    hm = odec.sigmoid_clamp(out["hm"])
+    s, inds, clses, ys, xs = odec.topk(odec.nms(hm), 100)
+    np.testing.assert_array_equal(inds, g["topk_inds"])
+    np.testing.assert_array_equal(clses, g["topk_clses"])
+    np.testing.assert_allclose(s, g["topk_scores"], rtol=0, atol=2e-6)
+    dets = odec.ctdet_decode(hm, out["wh"], reg=out["reg"], K=100)
+    np.testing.assert_allclose(dets, g["dets"], rtol=0, atol=2e-3)
+    np.testing.assert_array_equal(dets[..., 5], g["dets"][..., 5])
