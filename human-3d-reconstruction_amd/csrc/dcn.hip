@@ -485,7 +485,7 @@ extern "C" int h3d_dcn_v2_pack_weights(const float *weight, const float *bias, i
 // does not bump `_version`, and an address can be reused.  Asking the device "did the bytes change?" from the host would cost a
 // synchronisation per call, so the question is asked AND answered on the device: every call hashes the parameter bytes into
 // state[1] (order-independent 64-bit sum of mixed words), the pack kernels return at once when it equals state[0] -- the hash of
-// what the packed image was built from -- and a one-thread kernel then commits state[1] to state[0].  Everything is stream
+// what the packed image was built from -- and a one-thread kernel then commits state[1] to state[0] (and re-zeroes state[1]).  Everything is stream
 // ordered on the caller's stream: a consumer on another stream re-validates itself before it reads, and if it finds the pack
 // stale it re-packs the SAME bytes (a benign overlap).  state = 2 x uint64 on the device, zero-initialised by the host.
 __device__ __forceinline__ unsigned long long sig_mix(unsigned long long x)
@@ -494,27 +494,42 @@ __device__ __forceinline__ unsigned long long sig_mix(unsigned long long x)
     x ^= x >> 27; x *= 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
-__global__ void sig_kernel(const uint32_t *__restrict__ p, size_t nwords, unsigned long long salt, unsigned long long *acc)
+struct SigBufs {
+    const uint32_t *p[4];
+    unsigned long long nwords[4];
+    int n;
+};
+// one launch hashes every parameter buffer of the pack (the launch, not the bytes, is what a call pays for: two launches + a
+// memset per call showed up as 9 us each in the round-4 kernel trace); state[1] is zero on entry: the host zeroes it once,
+// sig_commit_kernel re-zeroes it after every call
+__global__ void sig_kernel(SigBufs b, unsigned long long *acc)
 {
     unsigned long long h = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
-        h += sig_mix(((unsigned long long)p[i] << 32 | (unsigned long long)(uint32_t)i) + salt + (i >> 32));
+    for (int k = 0; k < b.n; ++k) {
+        const uint32_t *__restrict__ p = b.p[k];
+        const unsigned long long salt = 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.nwords[k]; i += (size_t)gridDim.x * blockDim.x)
+            h += sig_mix(((unsigned long long)p[i] << 32 | (unsigned long long)(uint32_t)i) + salt + (i >> 32));
+    }
 #pragma unroll
     for (int d = 32; d; d >>= 1) h += __shfl_xor(h, d);
-    if ((threadIdx.x & 63) == 0) atomicAdd(acc, h);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(acc, h);
 }
-__global__ void sig_commit_kernel(unsigned long long *state) { state[0] = state[1]; }
+__global__ void sig_commit_kernel(unsigned long long *state) { state[0] = state[1]; state[1] = 0ull; }
 
 static int sig_begin(unsigned long long *state, const void *const *bufs, const size_t *nbytes, int n, hipStream_t st)
 {
-    if (hipMemsetAsync(state + 1, 0, 8, st) != hipSuccess) H3D_FAIL(H3D_ERR_LAUNCH, "pack signature: hipMemsetAsync failed");
-    for (int k = 0; k < n; ++k) {
-        const size_t nw = nbytes[k] / 4;
-        if (!nw) continue;
-        const unsigned blocks = (unsigned)std::min<size_t>((nw + 1023) / 1024, 512);
-        hipLaunchKernelGGL(sig_kernel, dim3(blocks), dim3(256), 0, st, (const uint32_t *)bufs[k], nw, 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1), state + 1);
-        H3D_CHECK_LAUNCH("sig_kernel");
+    SigBufs b;
+    size_t most = 0;
+    b.n = n;
+    for (int k = 0; k < 4; ++k) {
+        b.p[k] = k < n ? (const uint32_t *)bufs[k] : nullptr;
+        b.nwords[k] = k < n ? nbytes[k] / 4 : 0;
+        most = std::max<size_t>(most, (size_t)b.nwords[k]);
     }
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((most + 1023) / 1024, 1), 512);
+    hipLaunchKernelGGL(sig_kernel, dim3(blocks), dim3(256), 0, st, b, state + 1);
+    H3D_CHECK_LAUNCH("sig_kernel");
     return H3D_OK;
 }
 
