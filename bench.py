@@ -489,13 +489,14 @@ def steps_in_flight_default(arch_name, batch):
     return 4 if batch <= 16 else 3
 
 
-def make_step(det, images, nslot, world, n_global, dev, graph=False):
+def make_step(det, images, nslot, world, n_global, dev, graph=False, rehearse=False):
     """-> (step(), per-image dets shape).  step() issues one batch: consecutive calls alternate between `nslot` HIP streams, each
     with its own copy of the plan's buffers; for world > 1 the single collective (all-gather of dets) follows on the
     default stream, in step order."""
     slot_streams = _streams(nslot, dev) if nslot > 1 else [None]
     counter = [0]
     dets_shape = (det.opt.K, 6 if det.opt.task == "ctdet" else 40)
+    collective = world > 1 or rehearse          # rehearse: the N > 1 code path with a group of one rank (RCCL on a one-GPU box)
 
     def step():
         k = counter[0] % nslot
@@ -503,10 +504,10 @@ def make_step(det, images, nslot, world, n_global, dev, graph=False):
         kw = {"graph": True} if graph else {}
         if slot_streams[k] is None:
             res = det.run(images, slot=0, **kw)
-            return gather_detections(res["dets"], n_images=n_global) if world > 1 else res["dets"]
+            return gather_detections(res["dets"], n_images=n_global, force=rehearse) if collective else res["dets"]
         with torch.cuda.stream(slot_streams[k]):
             res = det.run(images, slot=k, **kw)
-            if world == 1:
+            if not collective:
                 return res["dets"]
             done = torch.cuda.Event()
             done.record()
@@ -514,7 +515,7 @@ def make_step(det, images, nslot, world, n_global, dev, graph=False):
         cur = torch.cuda.current_stream()
         cur.wait_event(done)
         res["dets"].record_stream(cur)
-        return gather_detections(res["dets"], n_images=n_global)
+        return gather_detections(res["dets"], n_images=n_global, force=rehearse)
 
     return step, dets_shape
 
@@ -645,6 +646,10 @@ def main():
                          "DLA-34 plans) = per layer, by a deterministic rule on the kernels' own per-tile far-sample counts of the job's batch, outside the timed region "
                          "(DLAEngine.calibrate_dcn_margins).  Same box, images/s at --offset-scale 0.5 / 1.0 / 2.0: narrow "
                          "8310 / 6831 / 5768, wide 7880 / 7143 / 6095, auto 8301 / 7340 / 6082")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="one GPU only: run the step exactly as a multi-GPU rank does -- RCCL process group (of one rank), the per-step "
+                         "all_gather_into_tensor of dets issued from the default stream behind an event of the slot stream, barrier + "
+                         "max-over-ranks timing -- so that the N > 1 code path meets the device before the driver's 8-GPU run does")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the records measured after the timed region (shard_sweep, parity_mode, other_archs)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
@@ -686,8 +691,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.rehearse_collective:
         import torch.distributed as dist
+        if world == 1:                                      # a group of one rank, started without torchrun
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
 
     dla = args.arch == "dla_34"
@@ -724,7 +734,7 @@ def main():
     if args.streams > 1 and args.pipeline is None:
         nslot = 1              # sub-batch streams and plan slots are two uses of the same idea: combined only on request
     use_graph = dla and args.graph == 1 and args.streams <= 1
-    step, dets_shape = make_step(det, images, nslot, world, n_global, dev, graph=use_graph)
+    step, dets_shape = make_step(det, images, nslot, world, n_global, dev, graph=use_graph, rehearse=args.rehearse_collective and world == 1)
 
     # one-time setup outside both warm-up and the timed region: weight packing + plan lowering (host work and uploads,
     # no network launches) and the SMPL model upload.  The first launch of every kernel still pays its code-object
@@ -781,6 +791,8 @@ def main():
                        "batch_per_gpu": batch, "global_batch": n_global, "K": 100,
                        "smpl_people_per_image": args.people if dla else 0, "conv_gflop_per_image": round(gflop_img, 2),
                        "parallelism": "dp%d (image shards, one all-gather of dets)" % world,
+                       "collective": ("rehearsed: RCCL group of one rank, all_gather_into_tensor issued every step" if (args.rehearse_collective and world == 1)
+                                      else "all_gather_into_tensor of dets, every step" if world > 1 else "none (one rank)"),
                        "steps_in_flight": nslot, "hip_graph": bool(use_graph), "dcn_margin": args.dcn_margin,
                        "dcn_variants": dcn_variants,
                        "images": "%d distinct synthetic images (h3d_amd.synth.synth_image_batch, seed 317)" % n_global,

@@ -283,7 +283,7 @@ def multi_pose_post_process(dets, c, s, h, w):
     return out
 
 
-def gather_detections(dets, group=None, n_images=None):
+def gather_detections(dets, group=None, n_images=None, force=False):
     """All ranks' [B_rank,K,40] -> [sum B_rank,K,40] with ONE all-gather (RCCL over xGMI when the backend is
     nccl; gloo in the CPU tests).  Nothing else crosses ranks: images are independent, weights are replicated
     (the reference's DataParallel scatter of dim 0, trainer.py:176).
@@ -291,9 +291,11 @@ def gather_detections(dets, group=None, n_images=None):
     n_images: the global batch that `shard_batch` split.  None = every rank holds the same number of images.
     When the split is uneven (n_images % world != 0: the lowest ranks hold one image more) every rank pads its
     shard to ceil(n_images / world) rows, so the collective stays ONE fixed-size all_gather_into_tensor, and the
-    pad rows are dropped afterwards."""
+    pad rows are dropped afterwards.
+    force: issue the collective even in a group of ONE rank (a rehearsal of the RCCL path on a one-GPU box: communicator
+    set-up and the all-gather itself run on the device; `bench.py --rehearse-collective`)."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return dets
     world = dist.get_world_size(group)
     dets = dets.contiguous()

@@ -752,3 +752,23 @@ def test_fused_tail_is_bit_identical_to_the_separate_launches():
     assert set(a) == set(b) == {"dets", "inds", "verts", "joints"}
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_bench_step_with_the_rccl_collective_on_one_gpu():
+    """`bench.py --rehearse-collective`: the multi-GPU rank's code path on the one GPU a test box has -- `init_process_group("nccl")`
+    (RCCL, a group of one rank), every step's `all_gather_into_tensor` of `dets` issued from the default stream behind an event of
+    the slot stream, barrier + all-reduce(MAX) timing.  The N > 1 path is otherwise covered by gloo on the CPU only
+    (tests/test_cpu_host.py); here the same calls meet RCCL and the device (trainer.py:176 is the reference's scatter)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-collective", "--batch", "8", "--steps", "6", "--warmup", "2",
+                        "--no-extras", "--no-cpu-baseline", "--no-roofline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["config"]["collective"].startswith("rehearsed"), line["config"]
+    assert line["value"] > 100 and line["config"]["steps_in_flight"] == 4
