@@ -623,6 +623,36 @@ def other_archs(args, dev, steps=5):
     return out
 
 
+def offset_robustness(args, size, batch, dev, nslot, value, steps=10):
+    """The headline workload with LARGER DeformConv offsets than the synthetic default (`--offset-scale` 0.5: mean |offset| 2.0 px):
+    scale 1.0 (3.8 px: a quarter of the tiles have more far samples than the default variant's 256 slots) and 2.0 (6.5 px: most
+    do).  Trained networks' offsets are routinely larger than 2 px, so the headline alone would be an optimistic point.  Same
+    step, same batch, the per-layer variant rule applied to the new weights; measured after the timed region."""
+    import copy
+    out = {}
+    for sc in (1.0, 2.0):
+        try:
+            a2 = copy.copy(args)
+            a2.offset_scale = sc
+            det, opt, _, _ = build_detector("dla_34", args.dtype, size, a2, dev)
+            images = torch.from_numpy(synth.synth_image_batch(batch, size, size, seed=317)).to(dev)
+            eng = det.model.engine(dev)
+            rep = eng.calibrate_dcn_margins(images) if args.dcn_margin == "auto" else {}
+            step, _ = make_step(det, images, nslot, 1, batch, dev)
+            dt = time_steps(step, steps, nslot + 1)
+            names = {v: k for k, v in eng.DCN_VARIANTS.items()}
+            choice = [names[v] for v in eng.pw.dcn_variant.values()]
+            out["%.1f" % sc] = {"images_per_s": round(batch * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3),
+                                "frac_of_headline": round(batch * steps / dt / value, 3), "steps": steps,
+                                "layers_on_slots512": choice.count("slots512"), "layers_on_wide": choice.count("wide"),
+                                "tiles_over_256_mean": round(float(np.mean([r["tiles_over_256"] for r in rep.values()])), 3) if rep else None}
+            del det, eng, images
+            torch.cuda.empty_cache()
+        except Exception as e:          # a record measured AFTER the headline number must not take the line down with it
+            out["%.1f" % sc] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 METRIC = "images/sec whole-node, DLA-34+SMPL batch-64 512x512; top-k index bit-match"
 
 
@@ -896,6 +926,8 @@ def main():
         if extras:
             del det, eng, images
             torch.cuda.empty_cache()
+            line["offset_robustness"] = offset_robustness(args, size, batch, dev, nslot, line["value"])
+            print("[bench] offset_robustness %s" % json.dumps(line["offset_robustness"]), file=sys.stderr, flush=True)
             line["other_archs"] = other_archs(args, dev)
             print("[bench] other_archs %s" % json.dumps(line["other_archs"]), file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
