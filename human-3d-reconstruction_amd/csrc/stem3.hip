@@ -29,6 +29,7 @@ struct Stem3Args {
     int B, H, W, Ho, Wo, out_cs;
     int tiles_x, tiles_y;
     int dbg;               // ABLATE builds: stop after phase dbg (1..3)
+    int tpb;               // consecutive tiles per workgroup
     // PROJ (round 4): level2's residual branch in the same launch -- project(max_pool2x2(level1)) (Tree.downsample + Tree.project,
     // model.py:200-207, 211-212: level2 is not a level_root, so nothing else reads the pooled map)
     const uint16_t *wproj;   // [64][32] T: 1x1 filters (BatchNorm folded)
@@ -37,7 +38,12 @@ struct Stem3Args {
     int res_cs;
 };
 
-constexpr int S3K_TPB = 8;                           // consecutive tiles per workgroup (image patch prefetched one tile ahead)
+// consecutive tiles per workgroup (image patch prefetched one tile ahead; the 12 filter fragments are fetched once per workgroup): a
+// launch-time choice (Stem3Args::tpb).  Round 4, same process (tools/ab_lib.py), batch 64 (32768 tiles on 512 workgroup slots): 4 / 8 /
+// 16 / 32 / 64 tiles per workgroup -> 0.496 / 0.467 / 0.447 / 0.443 / 0.431 ms; batch 8 (4096 tiles): 4 / 8 / 16 -> 0.071 / 0.068 / 0.092
+#ifndef S3K_TPB_FORCE
+#define S3K_TPB_FORCE 0
+#endif
 constexpr int S3K_IW = 56, S3K_IH = 25;              // image patch (uint2 per pixel)
 constexpr int S3K_ROWB = 1792, S3K_PXB = 48;         // S and L0 tiles: 48 B per pixel, rows 0 mod 256 B
 constexpr int S3K_SH = 19, S3K_LH = 17, S3K_LW = 33;    // (the stem region is 19 x 35)
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform for the compiler too: the group index arithmetic of P1 / P2 runs on the scalar unit
     const int tiles = a.tiles_x * a.tiles_y;
     const int ntile = a.B * tiles;
-    const int t_first = blockIdx.x * S3K_TPB;
+    const int t_first = blockIdx.x * a.tpb;
     const size_t plane = (size_t)a.H * a.W;
 
     // ---- P0 (software pipelined over the S3K_TPB tiles of this workgroup): the image patch of tile i+1 is fetched into
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
         }
     };
 
-    for (int ti = t_first; ti < min(t_first + S3K_TPB, ntile); ++ti) {
+    for (int ti = t_first; ti < min(t_first + a.tpb, ntile); ++ti) {
     const int b = ti / tiles;
     const int t = ti - b * tiles;
     const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     const int sy0 = ly0 - 1, sx0 = lx0 - 1;                  // stem region origin
     __syncthreads();                                         // this tile's patch is in LDS; the previous tile is done with S / L0
     if (H3D_DBG(a) == 1) return;
-    if (ti + 1 < t_first + S3K_TPB) load_patch(ti + 1);      // (zeros past the last tile)
+    if (ti + 1 < t_first + a.tpb) load_patch(ti + 1);        // (zeros past the last tile)
 
     // ---- P1: stem -> S.  The kernel is bound by the LDS array (SQ_LDS_IDX_ACTIVE 0.75 per CU cycle, profiles/r03_pmc_sq_summary):
     //      a flat pixel list (rounds 2-3: 42 groups of 16 pixels, one 1-KB patch read per MFMA) re-reads every patch row for each
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     }
     }   // tiles of this workgroup
     if constexpr (PROJ) {                                    // the last tile's pooled rows
-        const int t_last = min(t_first + S3K_TPB, ntile) - 1;
+        const int t_last = min(t_first + a.tpb, ntile) - 1;
         __syncthreads();
         if ((wv == 4 || wv == 5) && t_last >= t_first) proj_tile(t_last);
     }
@@ -369,7 +375,14 @@ int h3d_launch_stem3(const h3d_op &op, hipStream_t st)
     a.tiles_x = cdiv(op.Wo, 16); a.tiles_y = cdiv(op.Ho, 8);
     a.dbg = op.reserved;
     if (h3d_note_kernel(proj ? "stem3_kernel<%s, true>" : "stem3_kernel<%s>", op.dtype == H3D_F16 ? "f16_t" : "unsigned short")) return H3D_OK;
-    const dim3 grid(cdiv(op.B * a.tiles_x * a.tiles_y, S3K_TPB));
+    // as many tiles per workgroup as still give every one of the 512 workgroup slots (two per CU) a workgroup: batch 64 at 512 x 512 =
+    // 32768 tiles -> 64 per workgroup (one round of equal workgroups: no tail, one prologue per slot); an 8-image shard (4096) -> 8
+    const int ntiles = op.B * a.tiles_x * a.tiles_y;
+    int tpb = 4;
+    while (tpb < 64 && cdiv(ntiles, 2 * tpb) >= 512) tpb *= 2;
+    if (S3K_TPB_FORCE) tpb = S3K_TPB_FORCE;
+    a.tpb = tpb;
+    const dim3 grid(cdiv(ntiles, tpb));
     if (proj) {
         if (op.dtype == H3D_F16) hipLaunchKernelGGL((stem3_kernel<f16_t, true>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((stem3_kernel<bf16_t, true>), grid, dim3(512), 0, st, a);
