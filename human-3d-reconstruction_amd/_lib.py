@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libh3d_hip.so")
 
-H3D_F32, H3D_BF16, H3D_F16 = 0, 1, 2
+H3D_F32, H3D_BF16, H3D_F16, H3D_F16X3 = 0, 1, 2, 3
 OP_STEM, OP_CONV, OP_DCN, OP_MAXPOOL, OP_UPADD, OP_COPY, OP_HEADS, OP_DCN_V1, OP_DCN_FUSED = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OP_CONV_STREAM, OP_DCN_FUSED_F16, OP_DCN_FUSED_STREAM, OP_STEM3, OP_UPDCN_F16 = 10, 11, 12, 13, 14
 OP_IM2COL, OP_MAXPOOL3, OP_DEPTH2SPACE = 15, 16, 17
@@ -58,6 +58,7 @@ SIGNATURES = {
     "h3d_dcn_v2_pack_weights_cached": [c_vp, c_vp, c_i, c_i, c_i, c_vp, c_vp, c_vp],
     "h3d_dcn_fused_pack_f32_cached": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp],
     "h3d_dcn_v2_forward_packed": [c_vp] * 5 + [c_i] * 7 + [c_vp, ctypes.c_size_t, c_vp],
+    "h3d_dcn_offset_mask": [c_vp] * 5 + [c_i] * 11 + [c_vp],
     "h3d_dcn_fused_ck": [c_i, c_i],
     "h3d_dcn_far_samples": [ctypes.POINTER(H3dOp), c_vp, c_vp],
     "h3d_smpl_pose_heads": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp],

@@ -15,9 +15,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 // element-type name as it appears in the kernel symbols rocprofv3 prints
-template <typename T> constexpr const char *h3d_tname() { return std::is_same_v<T, float> ? "float" : std::is_same_v<T, f16_t> ? "f16_t" : "unsigned short"; }
+struct x3_t;                       // fp32 storage, fp16 x 3 contraction (below)
+template <typename T> constexpr const char *h3d_tname() { return std::is_same_v<T, float> ? "float" : std::is_same_v<T, f16_t> ? "f16_t" : std::is_same_v<T, x3_t> ? "x3_t" : "unsigned short"; }
 // host side: element size of an h3d_op dtype (0 = unknown)
-static inline int h3d_dtype_bytes(int dtype) { return dtype == H3D_F32 ? 4 : (dtype == H3D_BF16 || dtype == H3D_F16) ? 2 : 0; }
+static inline int h3d_dtype_bytes(int dtype) { return (dtype == H3D_F32 || dtype == H3D_F16X3) ? 4 : (dtype == H3D_BF16 || dtype == H3D_F16) ? 2 : 0; }
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -160,6 +161,83 @@ template <> struct ET<f16_t> {
         return o;
     }
 };
+
+// "f16x3" plans (H3D_F16X3, round 5): fp32 STORAGE everywhere (activations, residuals, head maps: the layout, the launches and the
+// elementwise kernels of the f32 plan), but every contraction runs on the fp16 matrix cores with both fp32 operands split into two
+// fp16 terms, x = hi + lo with hi = fp16(x) and lo = fp16(x - hi) (round to nearest even: |x - hi - lo| <= 2^-24 |x| while lo is a
+// normal fp16, <= 3e-8 absolute below that), and THREE products per fp32 product -- hi.hi + hi.lo + lo.hi, the dropped lo.lo is
+// 2^-22 relative -- accumulated in fp32 by the MFMA: 3 x v_mfma_f32_32x32x16_f16 (96 cycles) per 16-channel step instead of
+// 8 x v_mfma_f32_32x32x2_f32 (512 cycles).  This is the parity arithmetic on the 2.5 PFLOP/s matrix cores: the reference computes
+// in fp32 throughout (dcn_v2_cuda.cu:59 `using scalar_t = float`; model.py modules are fp32), and "bit-exact top-k indices" only
+// survives fp32-level head errors.  A fragment is the SAME 32 bytes per lane as ET<float>'s (8 K elements), holding the 8 hi halves
+// in the first 16 bytes and the 8 lo halves in the second: the LDS geometry of every kernel is the f32 one, filters are pre-split
+// by the host (engine.PackedWeights), activations are split by the thread that stages them into LDS.
+// CONTRACT: |activation| <= 65504 (fp16's range; larger values saturate, finite) -- three orders of magnitude above anything a
+// DLA-34 / Hourglass / ResNet feature map holds.
+struct x3_t { float v; };          // element type tag: 4 bytes of fp32 in memory
+// 4 fp32 (16 raw bytes) -> their 4 hi and 4 lo fp16 terms
+__device__ __forceinline__ void x3_split4(const u32x4 raw, u32x2 &hi, u32x2 &lo)
+{
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float a = __builtin_amdgcn_fmed3f(__uint_as_float(raw[2 * p]), -65504.f, 65504.f);
+        const float b = __builtin_amdgcn_fmed3f(__uint_as_float(raw[2 * p + 1]), -65504.f, 65504.f);
+        const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+        const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+        hi[p] = __builtin_bit_cast(uint32_t, f16x2_t{ha, hb});
+        lo[p] = __builtin_bit_cast(uint32_t, f16x2_t{la, lb});
+    }
+}
+// the staging store of one 16-byte vector (4 fp32) of a 32-byte K group at LDS address `grp`: sub = 0 | 1 = which half of the group's
+// 8 elements the vector holds.  hi terms land in bytes [8 sub, 8 sub + 8), lo terms 16 bytes further on.
+__device__ __forceinline__ void x3_store4(char *grp, int sub, const u32x4 raw)
+{
+    u32x2 hi, lo;
+    x3_split4(raw, hi, lo);
+    *reinterpret_cast<u32x2 *>(grp + 8 * sub) = hi;
+    *reinterpret_cast<u32x2 *>(grp + 16 + 8 * sub) = lo;
+}
+template <> struct ET<x3_t> {
+    static constexpr int BYTES = 4;
+    struct frag { u32x4 hi, lo; };
+    static __device__ __forceinline__ frag lds_frag(const char *p)
+    {
+        frag f;
+        f.hi = *reinterpret_cast<const u32x4 *>(p);
+        f.lo = *reinterpret_cast<const u32x4 *>(p + 16);
+        return f;
+    }
+    static __device__ __forceinline__ frag lds_frag2(const char *first, const char *second)
+    {
+        frag f;
+        f.hi = *reinterpret_cast<const u32x4 *>(first);
+        f.lo = *reinterpret_cast<const u32x4 *>(second);
+        return f;
+    }
+    // 8 fp32 values held in registers (a blended DeformConv sample, a ReLU-ed accumulator slab) -> operand fragment
+    static __device__ __forceinline__ frag split8(const float (&x)[8])
+    {
+        frag f;
+        u32x2 h0, l0, h1, l1;
+        x3_split4(u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])}, h0, l0);
+        x3_split4(u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])}, h1, l1);
+        f.hi = u32x4{h0[0], h0[1], h1[0], h1[1]};
+        f.lo = u32x4{l0[0], l0[1], l1[0], l1[1]};
+        return f;
+    }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
+    {
+        // small terms first: they meet an accumulator that is not yet large
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.lo), __builtin_bit_cast(f16x8_t, b.hi), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.hi), __builtin_bit_cast(f16x8_t, b.lo), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a.hi), __builtin_bit_cast(f16x8_t, b.hi), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float to_f32(x3_t v) { return v.v; }
+    static __device__ __forceinline__ x3_t from_f32(float f) { x3_t o; o.v = f; return o; }
+};
+// storage type of a plan's activations: the element type itself, fp32 for f16x3 plans
+template <typename T> struct StoreT { using type = T; };
+template <> struct StoreT<x3_t> { using type = float; };
 
 // Per-type pieces of the epilogues: two packed elements <-> floats, and the store clamp.  clamp(v, lo): lo = 0 (ReLU) or
 // -inf; fp16 also bounds the value by +-65504 in the same v_med3_f32 (no extra instruction).

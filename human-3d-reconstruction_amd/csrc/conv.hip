@@ -126,7 +126,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
             if (i < NH) {
                 const int v = i % C::VPP, pix = i / C::VPP;
                 const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
-                *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = stg[j];
+                if constexpr (std::is_same_v<T, x3_t>)      // f16x3 plans: fp32 in memory, (hi | lo) fp16 terms per 8-channel group in LDS
+                    x3_store4(s_in + iy * C::RB + ix * C::SB + (v >> 1) * 32, v & 1, stg[j]);
+                else
+                    *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = stg[j];
             } else if (i < NH + NW) {
                 const int q0 = i - NH;
                 const int row = q0 / WV, q = q0 - row * WV;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
         __syncthreads();                          // halo and filters are no longer read
         tile_epilogue_lds<T, MT, C::NT>(acc, e, b, oy0, ox0, cout0, __builtin_amdgcn_readfirstlane(wv), l, smem + wv * epi_lds_stride<MT, C::NT>());
     } else {
-        tile_epilogue<T, MT, C::NT, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+        tile_epilogue<typename StoreT<T>::type, MT, C::NT, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }
 }
 
@@ -286,6 +289,43 @@ template <> int launch_conv_t<float>(const h3d_op &op, const ConvArgs &a, hipStr
              op.ksize, op.stride);
 }
 
+// f16x3 plans: the f32 plan's layouts (4-byte elements, 16-channel chunks) on 3 fp16 MFMAs per step instead of 8 fp32 ones.
+// (tuning override, tools/ab_conv.py --dtype f16x3: reserved = 0x1000 | MT << 8 | WAVES << 4 | TH >> 3)
+template <> int launch_conv_t<x3_t>(const h3d_op &op, const ConvArgs &a, hipStream_t st)
+{
+    const int co = op.Cout;
+    auto nblk = [&](int th, int bn) { return (long)op.B * cdiv(op.Wo, 16) * cdiv(op.Ho, th) * cdiv(co, bn); };
+    if (op.ksize == 3 && op.stride == 1) {
+        if (op.reserved & 0x1000) {
+            switch (op.reserved & 0xfff) {
+            case 0x242: return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16>(a, st);
+            case 0x282: return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16, 8>(a, st);
+            case 0x482: return launch_conv_cfg<x3_t, 3, 1, 4, 16, 16, 8>(a, st);
+            case 0x441: return launch_conv_cfg<x3_t, 3, 1, 4, 16, 8>(a, st);
+            case 0x241: return launch_conv_cfg<x3_t, 3, 1, 2, 16, 8>(a, st);
+            default: H3D_FAIL(H3D_ERR_ARG, "conv (f16x3): unknown tuning override %#x", op.reserved);
+            }
+        }
+        if (co <= 32) return launch_conv_cfg<x3_t, 3, 1, 1, 16, 16>(a, st);
+        if (co <= 64 || nblk(16, 128) < 512) return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16>(a, st);
+        return launch_conv_cfg<x3_t, 3, 1, 4, 16, 16, 8>(a, st);
+    }
+    if (op.ksize == 3 && op.stride == 2) {
+        if (co <= 32) return launch_conv_cfg<x3_t, 3, 2, 1, 16, 8>(a, st);
+        return launch_conv_cfg<x3_t, 3, 2, 2, 16, 8>(a, st);
+    }
+    if (op.ksize == 1 && op.stride == 1) {
+        if (co <= 32) return launch_conv_cfg<x3_t, 1, 1, 1, 16, 16>(a, st);
+        return launch_conv_cfg<x3_t, 1, 1, 2, 16, 16>(a, st);
+    }
+    if (op.ksize == 1 && op.stride == 2) {
+        if (co <= 32) return launch_conv_cfg<x3_t, 1, 2, 1, 16, 8>(a, st);
+        return launch_conv_cfg<x3_t, 1, 2, 2, 16, 8>(a, st);
+    }
+    H3D_FAIL(H3D_ERR_UNSUPPORTED, "conv: ksize=%d stride=%d not covered (k in {1,3}, stride in {1,2})",
+             op.ksize, op.stride);
+}
+
 bool h3d_gemm1_takes(const h3d_op &op);
 int h3d_launch_gemm1(const h3d_op &op, hipStream_t st);
 
@@ -316,6 +356,7 @@ int h3d_launch_conv(const h3d_op &op, hipStream_t st)
     if (op.dtype == H3D_BF16) return launch_conv_t<bf16_t>(op, a, st);
     if (op.dtype == H3D_F16) return launch_conv_t<f16_t>(op, a, st);
     if (op.dtype == H3D_F32) return launch_conv_t<float>(op, a, st);
+    if (op.dtype == H3D_F16X3) return launch_conv_t<x3_t>(op, a, st);
     H3D_FAIL(H3D_ERR_DTYPE, "conv: dtype %d", op.dtype);
 }
 
@@ -455,7 +496,7 @@ int h3d_launch_stem(const h3d_op &op, hipStream_t st)
     if (op.dtype == H3D_BF16)
         hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, st, (const float *)op.in, (const float *)op.w,
                            op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.out_cs, tx, ty);
-    else if (op.dtype == H3D_F32)
+    else if (op.dtype == H3D_F32 || op.dtype == H3D_F16X3)      // (3 input channels: nothing for the matrix cores to split)
         hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, st, (const float *)op.in, (const float *)op.w,
                            op.bias, (float *)op.out, op.B, op.H, op.W, op.out_cs, tx, ty);
     else

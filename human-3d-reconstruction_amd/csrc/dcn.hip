@@ -244,8 +244,10 @@ int h3d_launch_dcn(const h3d_op &op, hipStream_t st)
 // Operator boundary: general NCHW fp32 kernel.  Block = 64 output pixels x 64 output channels,
 // K = C*kh*kw walked in chunks of 16: sampled columns and the weight slab meet in LDS.
 struct DcnNchwArgs {
-    const float *in, *w, *bias, *off, *mask;
+    const float *in, *w, *bias, *off, *mask;   // off == nullptr: zero offsets and a unit mask, i.e. a plain zero-padded convolution
     float *out;
+    float *out2;   // split > 0 (h3d_dcn_offset_mask): channels >= split go to out2 [B, Cout - split, Ho, Wo] through a sigmoid
+    int split;
     int B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg, Ho, Wo;
 };
 
@@ -277,11 +279,17 @@ __global__ __launch_bounds__(256) void dcn_nchw_kernel(DcnNchwArgs a)
                 const int c = k / khw, t = k - c * khw;
                 const int i = t / a.kw, jj = t - i * a.kw;
                 const int g = c / cpg;
-                const float *offp = a.off + ((size_t)(b * a.dg + g) * 2 * khw) * HoWo;
-                const float *mp = a.mask + ((size_t)(b * a.dg + g) * khw) * HoWo;
-                const float h_im = (float)(oh * a.sh - a.ph + i * a.dh) + offp[(size_t)(2 * t) * HoWo + n];
-                const float w_im = (float)(ow * a.sw - a.pw + jj * a.dw) + offp[(size_t)(2 * t + 1) * HoWo + n];
-                const Sample s = make_sample(h_im, w_im, mp[(size_t)t * HoWo + n], a.H, a.W);
+                float d_h = 0.f, d_w = 0.f, m = 1.f;
+                if (a.off) {
+                    const float *offp = a.off + ((size_t)(b * a.dg + g) * 2 * khw) * HoWo;
+                    const float *mp = a.mask + ((size_t)(b * a.dg + g) * khw) * HoWo;
+                    d_h = offp[(size_t)(2 * t) * HoWo + n];
+                    d_w = offp[(size_t)(2 * t + 1) * HoWo + n];
+                    m = mp[(size_t)t * HoWo + n];
+                }
+                const float h_im = (float)(oh * a.sh - a.ph + i * a.dh) + d_h;
+                const float w_im = (float)(ow * a.sw - a.pw + jj * a.dw) + d_w;
+                const Sample s = make_sample(h_im, w_im, m, a.H, a.W);
                 if (s.inside) {
                     const float *im = a.in + ((size_t)b * a.C + c) * a.H * a.W;
                     const float v1 = s.off[0] >= 0 ? im[s.off[0]] : 0.f;
@@ -320,9 +328,38 @@ __global__ __launch_bounds__(256) void dcn_nchw_kernel(DcnNchwArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nn = n0 + tp * 4 + j;
-            if (nn < HoWo) a.out[((size_t)b * a.Cout + co) * HoWo + nn] = acc[i][j] + a.bias[co];
+            if (nn >= HoWo) continue;
+            const float v = acc[i][j] + a.bias[co];
+            if (a.split <= 0) a.out[((size_t)b * a.Cout + co) * HoWo + nn] = v;
+            else if (co < a.split) a.out[((size_t)b * a.split + co) * HoWo + nn] = v;
+            else a.out2[((size_t)b * (a.Cout - a.split) + co - a.split) * HoWo + nn] = 1.0f / (1.0f + expf(-v));
         }
     }
+}
+
+// DCN.forward's own convolution (dcn_v2.py:119-124) for ANY module configuration, on this library's kernel: the general operator kernel
+// with zero offsets and a unit mask IS nn.Conv2d(C, 3 dg kh kw, (kh, kw), stride, padding) (bilinear weights (1, 0, 0, 0) at integer
+// positions, zero outside the image); its epilogue splits the channels as `torch.chunk(out, 3, dim=1)` / `cat((o1, o2))` / `sigmoid(mask)` do.
+extern "C" int h3d_dcn_offset_mask(const float *input, const float *off_weight, const float *off_bias, float *offset, float *mask, int B, int C,
+                                   int H, int W, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                                   int deformable_group, void *stream)
+{
+    if (!input || !off_weight || !off_bias || !offset || !mask) H3D_FAIL(H3D_ERR_ARG, "dcn_offset_mask: null pointer");
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || kernel_h <= 0 || kernel_w <= 0 || stride_h <= 0 || stride_w <= 0 || pad_h < 0 || pad_w < 0 ||
+        deformable_group <= 0)
+        H3D_FAIL(H3D_ERR_SHAPE, "dcn_offset_mask: non-positive dimension");
+    const int k = deformable_group * kernel_h * kernel_w;
+    DcnNchwArgs a;
+    a.in = input; a.w = off_weight; a.bias = off_bias; a.off = nullptr; a.mask = nullptr; a.out = offset; a.out2 = mask; a.split = 2 * k;
+    a.B = B; a.C = C; a.H = H; a.W = W; a.Cout = 3 * k; a.kh = kernel_h; a.kw = kernel_w; a.sh = stride_h; a.sw = stride_w;
+    a.ph = pad_h; a.pw = pad_w; a.dh = 1; a.dw = 1; a.dg = 1;      // (nn.Conv2d of dcn_v2.py:107-111: no dilation, no groups)
+    a.Ho = (H + 2 * pad_h - kernel_h) / stride_h + 1;
+    a.Wo = (W + 2 * pad_w - kernel_w) / stride_w + 1;
+    if (a.Ho <= 0 || a.Wo <= 0) H3D_FAIL(H3D_ERR_SHAPE, "dcn_offset_mask: empty output %dx%d", a.Ho, a.Wo);
+    dim3 grid(cdiv(a.Ho * a.Wo, 64), cdiv(a.Cout, 64), B);
+    hipLaunchKernelGGL(dcn_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    H3D_CHECK_LAUNCH("dcn_nchw_kernel");
+    return H3D_OK;
 }
 
 extern "C" int h3d_dcn_v2_forward(const float *input, const float *weight, const float *bias, const float *offset,
@@ -337,7 +374,7 @@ extern "C" int h3d_dcn_v2_forward(const float *input, const float *weight, const
     if (deformable_group <= 0 || C % deformable_group)
         H3D_FAIL(H3D_ERR_SHAPE, "dcn_v2_forward: channels %d not divisible by deformable_group %d", C, deformable_group);
     DcnNchwArgs a;
-    a.in = input; a.w = weight; a.bias = bias; a.off = offset; a.mask = mask; a.out = output;
+    a.in = input; a.w = weight; a.bias = bias; a.off = offset; a.mask = mask; a.out = output; a.out2 = nullptr; a.split = 0;
     a.B = B; a.C = C; a.H = H; a.W = W; a.Cout = Cout; a.kh = kernel_h; a.kw = kernel_w; a.sh = stride_h; a.sw = stride_w;
     a.ph = pad_h; a.pw = pad_w; a.dh = dilation_h; a.dw = dilation_w; a.dg = deformable_group;
     a.Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) / stride_h + 1;

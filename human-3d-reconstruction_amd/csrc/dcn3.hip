@@ -278,9 +278,9 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
-                const typename X::frag fa = X::lds(s_w + aoff + (tap * CK + kk * 16) * SS);
+                const typename X::wfrag fa = X::lds_w(s_w + aoff + (tap * CK + kk * 16) * SS);
                 const typename X::frag fb = X::lds(s_h + ((PK && dy == 1) ? bconv1 : bconv + dy * C::RBH) + dx * C::SBH + kk * 16 * SS);
-                if (H3D_DBG(a) & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, fb);
+                if (H3D_DBG(a) & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, X::prep(fb));
             }
         }
     };
@@ -535,9 +535,9 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             for (int tap = 0; tap < 9; ++tap) {
                 // LDS returns in order: tap t's filter fragments first (they arrive while tap t is blended), then the
                 // corners of tap t+1 (they arrive while tap t is multiplied)
-                typename X::frag fa[MT];
+                typename X::wfrag fa[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + tap * CK * SS);
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + tap * CK * SS);
                 if (tap + 1 < 9) gather(tap + 1, (tap + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);            // (hipcc sinks the reads back in front of their first use otherwise)
                 const typename X::frag fb = X::blend(v[tap & 1], geo[tap]);
@@ -563,16 +563,17 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             }
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
-                typename X::frag fa[MT];
+                typename X::wfrag fa[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
                 if (H3D_DBG(a) & 4) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) { X::keep(fa[m]); X::keep(fb[kk]); }
                     continue;
                 }
+                const typename X::bfrag pb = X::prep(fb[kk]);       // (f16x3 plans: the fp32 sample split into fp16 terms, once for all M-tiles)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb[kk]);
+                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], pb);
             }
         }
     };
@@ -701,9 +702,9 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
 #pragma unroll
                     for (int j = 0; j < TB; ++j) {
                         if (!((wmask >> (t0 + j)) & 1)) continue;
-                        typename X::frag fa[MT];
+                        typename X::wfrag fa[MT];
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + ((t0 + j) * CK) * SS);
+                        for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + ((t0 + j) * CK) * SS);
 #pragma unroll
                         for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fbs[j]);
                     }
@@ -762,11 +763,12 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                 if (!__any(any)) continue;
 #pragma unroll
                 for (int kk = 0; kk < CK / 16; ++kk) {
-                    typename X::frag fa[MT];
+                    typename X::wfrag fa[MT];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+                    for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+                    const typename X::bfrag pb = X::prep(fb[kk]);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], fb[kk]);
+                    for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], pb);
                 }
             }
         }
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         __syncthreads();                          // the apron and the filters are no longer read
         tile_epilogue_lds<T, MT>(acc, e, b, oy0, ox0, cout0, wv, l, smem + wv * epi_lds_stride<MT>());
     } else {
-        tile_epilogue<T, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+        tile_epilogue<typename StoreT<T>::type, MT, 1, EPI == 1>(acc, e, b, oy0, ox0, cout0, wv, r, h);
     }
     };
     // (only where registers allow: under the 128-VGPR cap of the two-workgroups-per-CU variants the second copy of
@@ -944,6 +946,10 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     if (op.dtype == H3D_F32) {
         if (op.Cout <= 32) return launch_dcn3_cfg<float, 1, 16, 2>(a, st);
         return launch_dcn3_cfg<float, 2, 16, 2>(a, st);
+    }
+    if (op.dtype == H3D_F16X3) {            // the f32 plan's tiles (fp32 apron, register-staged pre-split filters) on 3 fp16 MFMAs per step
+        if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 2>(a, st);
+        return launch_dcn3_cfg<x3_t, 2, 16, 2>(a, st);
     }
     H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused: dtype %d", op.dtype);
 }

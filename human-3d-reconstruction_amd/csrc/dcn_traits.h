@@ -22,6 +22,12 @@ template <> struct SE<float> {
     static __device__ __forceinline__ frag zero() { frag f; f.lo = f32x4{0, 0, 0, 0}; f.hi = f.lo; return f; }
     static __device__ __forceinline__ void keep(const frag &f) { asm volatile("" ::"v"(f.lo), "v"(f.hi)); }
     static __device__ __forceinline__ frag global8(const char *p) { return lds(p); }   // 8 floats
+    // filter fragments (`wfrag`, read by lds_w) and prepared sample fragments (`bfrag` = prep(frag)) are the sample type itself
+    // here and in the 2-byte plans; f16x3 plans (SE<x3_t> below) split them into fp16 terms
+    using wfrag = frag;
+    using bfrag = frag;
+    static __device__ __forceinline__ wfrag lds_w(const char *p) { return lds(p); }
+    static __device__ __forceinline__ bfrag prep(const frag &f) { return f; }
     static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
     {
         ET<float>::frag fa, fb;
@@ -86,6 +92,10 @@ template <> struct SE<bf16_t> {
         return f;
     }
     static __device__ __forceinline__ void keep(const frag &f) { asm volatile("" ::"v"(f.v)); }
+    using wfrag = frag;
+    using bfrag = frag;
+    static __device__ __forceinline__ wfrag lds_w(const char *p) { return lds(p); }
+    static __device__ __forceinline__ bfrag prep(const frag &f) { return f; }
     static __device__ __forceinline__ _Float16 cvt(uint32_t bits_hi)   // bf16 in the high half of an f32 pattern
     {
         const float x = __uint_as_float(bits_hi);
@@ -166,6 +176,23 @@ template <> struct SE<bf16_t> {
 template <> struct SE<f16_t> : SE<bf16_t> {
     static __device__ __forceinline__ u32x4 convert16(u32x4 raw) { return raw; }
     static __device__ __forceinline__ frag global8(const char *p) { return lds(p); }
+};
+
+// f16x3 plans (common.h ET<x3_t>): the apron in LDS, the sampling geometry and the bilinear blend are the fp32 ones of SE<float>
+// (reference operation order, dcn_v2_im2col_cuda.cu:25-54); the filters arrive pre-split into (hi | lo) fp16 terms, the blended
+// sample (and, for the offset convolution, the apron fragment) is split in registers, and each fp32 product becomes three fp16 MFMAs
+template <> struct SE<x3_t> : SE<float> {
+    using wfrag = ET<x3_t>::frag;
+    using bfrag = ET<x3_t>::frag;
+    static __device__ __forceinline__ wfrag lds_w(const char *p) { return ET<x3_t>::lds_frag(p); }
+    static __device__ __forceinline__ bfrag prep(const frag &f)
+    {
+        const float x[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
+        return ET<x3_t>::split8(x);
+    }
+    using SE<float>::keep;
+    static __device__ __forceinline__ void keep(const wfrag &f) { asm volatile("" ::"v"(f.hi), "v"(f.lo)); }
+    static __device__ __forceinline__ void mma(f32x16 &acc, const wfrag &a, const bfrag &b) { ET<x3_t>::mma(acc, a, b); }
 };
 
 __device__ __forceinline__ float dcn2_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }   // v_exp + v_rcp (1 ulp each)

@@ -143,8 +143,12 @@ __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][N
 #pragma unroll
                         for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
                     }
-                    fb[n].lo = f32x4{x[0], x[1], x[2], x[3]};
-                    fb[n].hi = f32x4{x[4], x[5], x[6], x[7]};
+                    if constexpr (std::is_same_v<T, x3_t>) {        // f16x3: the fp32 slab values split into (hi | lo) fp16 terms
+                        fb[n] = E::split8(x);
+                    } else {
+                        fb[n].lo = f32x4{x[0], x[1], x[2], x[3]};
+                        fb[n].hi = f32x4{x[4], x[5], x[6], x[7]};
+                    }
                 } else {
                     if constexpr (std::is_same_v<T, f16_t>) {       // fp16: ReLU and the saturation at 65504 in one v_med3_f32 each
 #pragma unroll
@@ -279,7 +283,8 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                     if (i < NHV) {
                         const int v = i % C::VPR, pix = i / C::VPR;
                         const int iy = pix / C::IN_W, ix = pix - iy * C::IN_W;
-                        *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = val;
+                        if constexpr (std::is_same_v<T, x3_t>) x3_store4(s_in + iy * C::RB + ix * C::SB + (v >> 1) * 32, v & 1, val);
+                        else *reinterpret_cast<u32x4 *>(s_in + iy * C::RB + ix * C::SB + v * 16) = val;
                     }
                 });
         }
@@ -543,7 +548,7 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
     const dim3 grid(op.B * a.tiles_x * a.tiles_y), blk(512);
     const bool biasc = !(op.reserved & 0x200);    // tuning override (tools/ab_heads.py): 0x200 = separate bias / zeroing pass
     if (h3d_note_kernel(mixed ? "heads_kernel<%s, %d, %d, %s, true>" : "heads_kernel<%s, %d, %d, %s>",
-                        op.dtype == H3D_BF16 ? "unsigned short" : op.dtype == H3D_F16 ? "f16_t" : "float", th, m2, biasc ? "true" : "false"))
+                        op.dtype == H3D_BF16 ? "unsigned short" : op.dtype == H3D_F16 ? "f16_t" : op.dtype == H3D_F16X3 ? "x3_t" : "float", th, m2, biasc ? "true" : "false"))
         return H3D_OK;
     if (mixed) {
         if (!biasc) H3D_FAIL(H3D_ERR_UNSUPPORTED, "heads: the separate-bias tuning override applies to launches of equal-width heads");
@@ -570,6 +575,10 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
         if (m2 == 1) H3D_HEADS_LAUNCH(f16_t, 16, 1);
         else if (m2 == 2) H3D_HEADS_LAUNCH(f16_t, 16, 2);
         else H3D_HEADS_LAUNCH(f16_t, 16, 3);
+    } else if (op.dtype == H3D_F16X3) {
+        if (m2 == 1) H3D_HEADS_LAUNCH(x3_t, 8, 1);
+        else if (m2 == 2) H3D_HEADS_LAUNCH(x3_t, 8, 2);
+        else H3D_HEADS_LAUNCH(x3_t, 8, 3);
     } else {
         if (m2 == 1) H3D_HEADS_LAUNCH(float, 8, 1);
         else if (m2 == 2) H3D_HEADS_LAUNCH(float, 8, 2);

@@ -24,15 +24,26 @@ def _packed_weights(weight, bias, dtype):
     only when the hash differs from the one the image was built from -- no host synchronisation.  Neither `tensor._version` (an
     edit through `.data`, as the reference does in dcn_v2.py:80-81 and DCNv2/test.py:21, does not bump it) nor the address (it can
     be reused) is taken as proof that the filters are unchanged; the host key only finds the buffer.  All of it is stream ordered
-    on the CALLER's stream, so a second stream validates (and if need be re-packs the same bytes) before it reads; the cache holds
-    no reference to the parameters."""
+    on the stream that OWNS the entry (the stream of the call that created it): the 16-byte validation state is one accumulator, so
+    two streams hashing the same layer at once would add into it together (spurious re-packs into a buffer another stream is still
+    reading).  A call on any other stream therefore does not touch the cached image: it packs into a buffer of its own
+    (`h3d_dcn_v2_pack_weights`, the reference contract's per-call work) -- correct on every stream, cached on one.  The cache holds
+    no reference to the parameters.  Call with the tensor's device current (`dcn_v2_forward` does)."""
     key = (weight.data_ptr(), bias.data_ptr(), tuple(weight.shape), dtype, str(weight.device))
-    ent = _PACKED.pop(key, None)
     Cout, C = weight.shape[0], weight.shape[1]
     L = _lib.lib()
+    stream = torch.cuda.current_stream(weight.device).cuda_stream
+    ent = _PACKED.pop(key, None)
+    if ent is not None and ent[2] != stream:
+        _PACKED[key] = ent
+        n = int(L.h3d_dcn_v2_packed_weight_bytes(Cout, C, dtype))
+        own = torch.empty(n, dtype=torch.uint8, device=weight.device)
+        _lib.check(L.h3d_dcn_v2_pack_weights(_lib.ptr(weight), _lib.ptr(bias), Cout, C, dtype, _lib.ptr(own), _lib.stream_ptr()),
+                   "dcn_v2_pack_weights")
+        return own
     if ent is None:
         n = int(L.h3d_dcn_v2_packed_weight_bytes(Cout, C, dtype))
-        ent = (torch.empty(n, dtype=torch.uint8, device=weight.device), torch.zeros(2, dtype=torch.int64, device=weight.device))
+        ent = (torch.empty(n, dtype=torch.uint8, device=weight.device), torch.zeros(2, dtype=torch.int64, device=weight.device), stream)
         while len(_PACKED) >= _PACKED_MAX:
             _PACKED.pop(next(iter(_PACKED)))
     _PACKED[key] = ent                                     # (re-inserted: most recently used last)
@@ -127,6 +138,20 @@ def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, de
         return dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_groups)
 
 
+class _InferenceOnly(torch.autograd.Function):
+    """Identity whose backward raises: a module in training mode returns its forward result (the reference's plain usage
+    `DCN(...).cuda()(x)`, DCNv2/test.py:169-180, is forward-only), and a training loop that calls .backward() through it learns at
+    once that dcn_v2_backward (dcn_v2_cuda.cu:175-336) is out of scope instead of silently getting no gradients."""
+
+    @staticmethod
+    def forward(ctx, out, *params):
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): call .eval() or run under torch.no_grad()")
+
+
 class DCNv2(nn.Module):
     """Parameters + forward(input, offset, mask) (dcn_v2.py:57-94)."""
 
@@ -147,13 +172,14 @@ class DCNv2(nn.Module):
             self.bias.zero_()
 
     def forward(self, input, offset, mask):
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): call .eval() or run under torch.no_grad()")
         k = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
         assert 2 * k == offset.shape[1]
         assert k == mask.shape[1]
-        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
-                           self.dilation, self.deformable_groups)
+        out = dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
+                          self.dilation, self.deformable_groups)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _InferenceOnly.apply(out, *[p for p in self.parameters() if p.requires_grad])    # forward works, backward raises
+        return out
 
 
 class DCN(DCNv2):
@@ -178,14 +204,22 @@ class DCN(DCNv2):
         """Weights in the layout of the fused DeformConv kernel (csrc/dcn3.hip, fp32), kept on the module and validated on the
         device at every forward (`h3d_dcn_fused_pack_f32_cached`: a hash of the four parameters' bytes decides, on the stream,
         whether the pack kernel has anything to do) -- so `dcn.weight.data.zero_()` between two forwards (DCNv2/test.py:21) is
-        seen although no version counter moves.  `.to(device)` / `load_state_dict` need no hook: new bytes, new hash."""
+        seen although no version counter moves.  `.to(device)` / `load_state_dict` need no hook: new bytes, new hash.
+        Called with `device` current.  The kept pack belongs to the stream that created it (one validation accumulator: see
+        `_packed_weights`); a forward on another stream packs into buffers of its own."""
         rows = (self.out_channels + 127) // 128 * 128
         C = self.in_channels
+        stream = torch.cuda.current_stream(device).cuda_stream
+
+        def fresh():
+            return (torch.empty(rows * 9 * C, dtype=torch.float32, device=device), torch.empty(128 * 9 * C, dtype=torch.float32, device=device),
+                    torch.empty(rows + 32, dtype=torch.float32, device=device), torch.zeros(2, dtype=torch.int64, device=device), (rows, C), stream)
         ent = getattr(self, "_pack", None)
         if ent is None or ent[0].device != device or ent[4] != (rows, C):
-            ent = (torch.empty(rows * 9 * C, dtype=torch.float32, device=device), torch.empty(128 * 9 * C, dtype=torch.float32, device=device),
-                   torch.empty(rows + 32, dtype=torch.float32, device=device), torch.zeros(2, dtype=torch.int64, device=device), (rows, C))
+            ent = fresh()
             object.__setattr__(self, "_pack", ent)
+        elif ent[5] != stream:
+            ent = fresh()               # (a zeroed state never matches: the pack kernel runs; nothing is kept)
         ps = [p.detach().contiguous() for p in (self.weight, self.bias, self.conv_offset_mask.weight, self.conv_offset_mask.bias)]
         if any(p.dtype != torch.float32 for p in ps):
             raise RuntimeError("DCN: expected float32 parameters (reference uses .data<float>())")
@@ -196,26 +230,29 @@ class DCN(DCNv2):
     def forward(self, input):
         """conv_offset_mask -> chunk/cat/sigmoid -> dcn_v2_conv (dcn_v2.py:118-128).  In the configuration the model uses
         (model.py:355) all of it is ONE launch of the fused DeformConv kernel in fp32 parity mode (offsets and mask never
-        reach memory); other configurations compute the offset conv with torch and call the operator."""
+        reach memory); other configurations run conv_offset_mask + chunk / cat / sigmoid as one launch of the library's general
+        kernel (`h3d_dcn_offset_mask`) and then the operator: no nn.Conv2d / vendor library call on any path."""
         if torch.is_grad_enabled() and input.requires_grad:
             raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): the input requires grad")
         if not input.is_cuda:
             raise RuntimeError("Not implemented on the CPU")
-        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # a fine-tuning loop must not silently get no gradients (the reference implements dcn_v2_backward, out of scope here)
-            raise RuntimeError("h3d_amd DCNv2 is inference-only (dcn_v2_backward is out of scope): call .eval() or run under torch.no_grad()")
-        # (parameters require grad by default: `model.eval(); dcn(x)` outside no_grad must work as it does in the reference;
-        #  the result is computed without a graph and returned detached)
+        # (parameters require grad by default: `dcn(x)` outside no_grad must return the forward result as it does in the reference,
+        #  DCNv2/test.py:17-30, 169-180)
         with torch.no_grad():
-            return self._forward(input)
+            out = self._forward(input)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # a fine-tuning loop must not silently get no gradients (the reference implements dcn_v2_backward, out of scope here):
+            # the result carries a graph node whose backward raises
+            return _InferenceOnly.apply(out, *[p for p in self.parameters() if p.requires_grad])
+        return out
 
     def _forward(self, input):
         if self._fused_ok(input):
             from ._lib import H3dOp
             x = input.contiguous()
             B, C, H, W = x.shape
-            wp, wo, bias, rows = self._packed(x.device)
-            with torch.cuda.device(x.device):
+            with torch.cuda.device(x.device):       # (the pack's launches go to x.device's current stream, like the forward's)
+                wp, wo, bias, rows = self._packed(x.device)
                 xn = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
                 out = torch.empty(B, self.out_channels, H, W, dtype=torch.float32, device=x.device)
                 L = _lib.lib()
@@ -228,9 +265,26 @@ class DCN(DCNv2):
                 arr = (H3dOp * 1)(op)
                 _lib.check(L.h3d_run_ops(arr, 1, _lib.stream_ptr()), "DCN.forward")
             return out
-        out = self.conv_offset_mask(input)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
-        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding,
+        # any other configuration (stride / dilation / deformable_groups / kernel size / channel count): conv_offset_mask -> chunk /
+        # cat / sigmoid (dcn_v2.py:119-124) in ONE launch of this library's general kernel (`h3d_dcn_offset_mask`: no nn.Conv2d, i.e.
+        # no vendor convolution library anywhere in the module), then the operator
+        if input.dtype != torch.float32 or input.dim() != 4:
+            raise RuntimeError("DCN: expected a float32 [B,C,H,W] input (reference uses .data<float>())")
+        x = input.contiguous()
+        B, C, H, W = x.shape
+        kh, kw = self.kernel_size
+        k = self.deformable_groups * kh * kw
+        ow, ob = self.conv_offset_mask.weight.detach().contiguous(), self.conv_offset_mask.bias.detach().contiguous()
+        if tuple(ow.shape) != (3 * k, C, kh, kw) or ow.dtype != torch.float32 or ob.dtype != torch.float32:
+            raise RuntimeError("DCN: conv_offset_mask.weight %s does not match [3*dg*kh*kw, C, kh, kw] = %s (float32)"
+                               % (tuple(ow.shape), (3 * k, C, kh, kw)))
+        Ho = (H + 2 * self.padding[0] - kh) // self.stride[0] + 1
+        Wo = (W + 2 * self.padding[1] - kw) // self.stride[1] + 1
+        with torch.cuda.device(x.device):
+            offset = torch.empty(B, 2 * k, Ho, Wo, dtype=torch.float32, device=x.device)
+            mask = torch.empty(B, k, Ho, Wo, dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().h3d_dcn_offset_mask(_lib.ptr(x), _lib.ptr(ow), _lib.ptr(ob), _lib.ptr(offset), _lib.ptr(mask), B, C, H, W,
+                                                      kh, kw, self.stride[0], self.stride[1], self.padding[0], self.padding[1],
+                                                      self.deformable_groups, _lib.stream_ptr()), "DCN: conv_offset_mask")
+        return dcn_v2_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding,
                            self.dilation, self.deformable_groups)

@@ -75,13 +75,16 @@ def _merge(s, i, y, x, K):
         # stage 2 of `_topk` (decode.py:34-39) over ONE class is the identity: the K stage-1 candidates already come sorted by
         # (score descending, flat index ascending) and the merge orders equal scores by position -- the multi_pose task has one
         # class (opts.py:248), so its `_topk` is one launch less (64 workgroups of a bitonic sort that moved nothing)
-        key = (B, K, str(dev))
-        if key not in _ZERO_CLS:
-            if len(_ZERO_CLS) >= 16:
-                _ZERO_CLS.pop(next(iter(_ZERO_CLS)))
-            _ZERO_CLS[key] = torch.zeros(B, K, dtype=torch.int32, device=dev)
+        # class ids: ONE read-only zero buffer per device for the life of the process (never evicted: captured hipGraphs hold its
+        # address), handed out as views -- the public `_topk` clones it (callers may edit their result in place)
+        n = B * K
+        z = _ZERO_CLS.get(str(dev))
+        if z is None or z.numel() < n:
+            z = torch.zeros(max(n, 1 << 16), dtype=torch.int32, device=dev)
             torch.cuda.current_stream(dev).synchronize()         # (filled before any other stream reads it; read-only afterwards)
-        return s.view(B, K), i.view(B, K), _ZERO_CLS[key], y.view(B, K), x.view(B, K)
+            _ZERO_CLS.setdefault("keep", []).append(z)           # (an outgrown buffer stays alive for the graphs that captured it)
+            _ZERO_CLS[str(dev)] = z
+        return s.view(B, K), i.view(B, K), z[:n].view(B, K), y.view(B, K), x.view(B, K)
     o_s = torch.empty(B, K, dtype=torch.float32, device=dev)
     o_i = torch.empty(B, K, dtype=torch.int64, device=dev)
     o_c = torch.empty(B, K, dtype=torch.int32, device=dev)
@@ -102,7 +105,10 @@ def _topk_channel(scores, K=40):
 def _topk(scores, K=40):
     """Two-stage top-K (reference decode.py:26-41): returns
     (topk_score [B,K], topk_inds [B,K] int64, topk_clses [B,K] int32, topk_ys, topk_xs)."""
-    return _merge(*_map_topk(scores, K, NMS_SKIP), K)
+    s, i, c, y, x = _merge(*_map_topk(scores, K, NMS_SKIP), K)
+    if scores.shape[1] == 1 and SINGLE_CLASS_SHORTCUT:
+        c = c.clone()          # (the shortcut's class ids are a shared read-only buffer; a public result must be the caller's own)
+    return s, i, c, y, x
 
 
 def ctdet_decode(heat, wh, reg=None, cat_spec_wh=False, K=100):
@@ -142,7 +148,7 @@ def _multi_pose(heat, wh, kps, reg, hm_hp, hp_offset, K, logits, return_aux=Fals
         _lib.ptr(hs), _lib.ptr(hi), _lib.ptr(hy), _lib.ptr(hx),
         _lib.ptr(wh), _lib.ptr(kps), _lib.ptr(reg), _lib.ptr(hp_offset),
         B, J, H, W, K, _lib.ptr(dets), _lib.stream_ptr()), "multi_pose_decode")
-    if return_aux:
+    if return_aux:     # ("clses" of a one-class map is a view of a shared read-only zero buffer: see _merge)
         return dets, {"scores": s, "inds": i, "clses": c, "ys": y, "xs": x, "hm_score": hs, "hm_inds": hi}
     return dets
 

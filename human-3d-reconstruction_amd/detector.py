@@ -31,7 +31,10 @@ class Opt:
       "f16"   fp16 activations and filters at the same MFMA rate, saturating epilogues: ~2 % slower, head error 7x smaller
               (0.10), set overlap 0.945, agreement 0.40 -- run this when the ranking matters more than 2 % of throughput.
       "f32"   parity mode: exact fmaf chains on v_mfma_f32_32x32x2_f32, 1/8 of the throughput; heads within 2e-4 of the
-              reference's own output, top-k indices identical to it (tests/test_gpu_fullsize.py, tests/golden/e2e_plain_512.npz)."""
+              reference's own output, top-k indices identical to it (tests/test_gpu_fullsize.py, tests/golden/e2e_plain_512.npz).
+      "f16x3" the parity arithmetic on the fp16 matrix cores (round 5): fp32 activations in memory, every fp32 product of a
+              contraction as three fp16 MFMAs on split operands (x = hi + lo; hi.hi + hi.lo + lo.hi, fp32 accumulation) -- fp32-level
+              heads and the same top-k indices as "f32" at ~3x its rate (csrc/common.h ET<x3_t>)."""
 
     def __init__(self, **kw):
         self.task = "multi_pose"
@@ -113,18 +116,19 @@ class MultiPoseDetector:
         if opt.smpl:
             n = opt.smpl_people or opt.K
             B = aux["inds"].shape[0]
-            if B * n >= 64 and self.fused_tail:
+            fusable = all(out[k].dtype == torch.float32 and out[k].is_contiguous() for k in ("pose", "shape"))   # (else: the gather path, any strides)
+            if B * n >= 64 and self.fused_tail and fusable:
                 # per-detection pose / shape read from the two extra heads at the detection centres INSIDE the SMPL pose kernel, which
                 # also writes the blend-shape operand: two launches instead of six (gathers x 2, index copy, pose, pack, verts)
                 verts, joints = _smpl.lbs_from_heads(self.smpl_model, out["pose"], out["shape"], aux["inds"], n, return_joints=True,
-                                                     exact=opt.dtype == "f32")
+                                                     exact=opt.dtype in ("f32", "f16x3"))
             else:
                 inds = aux["inds"][:, :n].contiguous()
                 thetas = _transpose_and_gather_feat(out["pose"], inds).view(B * n, 72)
                 betas = _transpose_and_gather_feat(out["shape"], inds).view(B * n, 10)
                 # f32 (parity-mode) detectors keep all six products of the blend-shape split (fp32-level accuracy end to end)
                 verts, joints = _smpl.lbs(self.smpl_model, betas, thetas, return_joints=True,
-                                          kernel="auto_exact" if opt.dtype == "f32" else "auto")
+                                          kernel="auto_exact" if opt.dtype in ("f32", "f16x3") else "auto")
             res["verts"] = verts.view(B, n, -1, 3)
             res["joints"] = joints.view(B, n, 24, 3)
         if meta is not None:

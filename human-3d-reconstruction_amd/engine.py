@@ -24,14 +24,28 @@ import torch
 from . import _lib, arch, arch_hg, arch_res
 from ._lib import H3dOp
 
-_TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
-_H3D_DT = {"bf16": _lib.H3D_BF16, "f16": _lib.H3D_F16, "f32": _lib.H3D_F32}
+_TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f16x3": torch.float32}
+_H3D_DT = {"bf16": _lib.H3D_BF16, "f16": _lib.H3D_F16, "f32": _lib.H3D_F32, "f16x3": _lib.H3D_F16X3}
 DCN_F16IN = 0x40000         # h3d_op.reserved of a fused DeformConv in a bf16 plan: its input tensor holds fp16 values (csrc/dcn3.hip F16IN)
 LOWP = ("bf16", "f16")      # the 2-byte plans: same kernels, lowering and tile choices; "f16" = BASELINE configs[4]'s arithmetic
 
 
 def _t(v):
     return v.detach().float().cpu() if torch.is_tensor(v) else torch.from_numpy(np.asarray(v)).float()
+
+
+def x3_split(w):
+    """fp32 filters [..., K] (K % 8 == 0: the contraction index, 8 consecutive elements = one MFMA fragment of a lane) -> the
+    operand format of the "f16x3" plans (csrc/common.h ET<x3_t>): per group of 8 elements the 8 fp16 high terms hi = fp16(x)
+    followed by the 8 fp16 low terms lo = fp16(x - hi) (round to nearest even), in the 32 bytes the 8 fp32 values occupied --
+    returned as a float32-typed tensor of the same shape (raw bytes, not numbers)."""
+    w = w.float().contiguous()
+    K = w.shape[-1]
+    assert K % 8 == 0, K
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+    g = torch.stack([hi.reshape(-1, K // 8, 8), lo.reshape(-1, K // 8, 8)], dim=2)            # [rows, K/8, 2, 8]
+    return g.reshape(-1, 2 * K).contiguous().view(torch.float32).reshape(w.shape)
 
 
 class View:
@@ -122,7 +136,8 @@ class PackedWeights:
             bp = torch.zeros(rows)
             bp[:co] = b
             td = torch.float16 if (as_half and self.dtype in LOWP) else _TORCH_DT[self.dtype]
-            self.t[key] = (wp.to(td).contiguous().to(self.device),
+            wp = x3_split(wp) if self.dtype == "f16x3" else wp.to(td)
+            self.t[key] = (wp.contiguous().to(self.device),
                            bp.contiguous().to(self.device), cout, ci, kh, rows)
         return self.t[key]
 
@@ -244,7 +259,7 @@ class PackedWeights:
                     wp[row] = w[ch].permute(1, 2, 0).reshape(9, ci)
                     bp[row] = b[ch]
             td = torch.float16 if self.dtype in LOWP else torch.float32
-            self.t[key] = (wp.to(td).contiguous().to(self.device), bp)
+            self.t[key] = ((x3_split(wp) if self.dtype == "f16x3" else wp.to(td)).contiguous().to(self.device), bp)
         return self.t[key]
 
     def fused_heads(self, names=None):
@@ -269,8 +284,9 @@ class PackedWeights:
                 w2[:c] = self.sd[head + ".2.weight"].reshape(c, hc)[:, perm]
                 b2 = torch.zeros(96)
                 b2[:c] = self.sd[head + ".2.bias"]
-                per.append((head, c, w2.to(td).contiguous().to(self.device), b2.to(self.device)))
-            self.t[key] = (torch.cat(w1).to(td).contiguous().to(self.device),
+                per.append((head, c, (x3_split(w2) if self.dtype == "f16x3" else w2.to(td)).contiguous().to(self.device), b2.to(self.device)))
+            w1 = torch.cat(w1)
+            self.t[key] = ((x3_split(w1) if self.dtype == "f16x3" else w1.to(td)).contiguous().to(self.device),
                            torch.cat(b1).float().contiguous().to(self.device), per)
         return self.t[key]
 
@@ -817,7 +833,7 @@ class DLAEngine:
 
     def __init__(self, state_dict, heads, use_dcn, dtype="bf16", device="cuda", head_conv=256, arch_name="dla34"):
         if dtype not in _TORCH_DT:
-            raise ValueError("dtype must be 'bf16', 'f16' or 'f32'")
+            raise ValueError("dtype must be 'bf16', 'f16', 'f32' or 'f16x3'")
         _lib.lib()                                     # fail loudly now if the HIP library is missing
         self.device = torch.device(device)
         if self.device.type != "cuda":

@@ -141,13 +141,14 @@ def lbs(model, betas, thetas, return_joints=False, kernel="auto"):
     A = torch.empty(P, NUM_JOINTS, 12, dtype=torch.float32, device=dev)
     joints = torch.empty(P, NUM_JOINTS, 3, dtype=torch.float32, device=dev)
     verts = torch.empty(P, d["V"], 3, dtype=torch.float32, device=dev)
-    L, st = _lib.lib(), _lib.stream_ptr()
+    L = _lib.lib()
     gen3 = kernel in ("gen3", "gen3x") or (kernel in ("auto", "auto_exact") and d["nnz"] <= 4 and P >= 64)
     exact = kernel in ("gen3x", "auto_exact")
     gen2 = kernel == "gen2"
     Ppad = ((P + 127) // 128) * 128
     coefT = torch.zeros(NUM_BETAS + NUM_POSE_FEAT, Ppad, dtype=torch.float32, device=dev) if gen2 else None
     with torch.cuda.device(dev):
+        st = _lib.stream_ptr()              # the current stream of `dev` (not of whatever device was current at the call)
         _lib.check(L.h3d_smpl_pose(_lib.ptr(betas), _lib.ptr(thetas), _lib.ptr(d["j_template"]),
                                    _lib.ptr(d["j_shapedirs"]), _lib.ptr(d["parents"]), P, _lib.ptr(pf),
                                    _lib.ptr(A), _lib.ptr(joints), _lib.ptr(coefT), Ppad, st), "smpl_pose")
@@ -200,8 +201,9 @@ def lbs_from_heads(model, pose_map, shape_map, inds, n, return_joints=False, exa
     joints = torch.empty(P, NUM_JOINTS, 3, dtype=torch.float32, device=dev)
     verts = torch.empty(P, d["V"], 3, dtype=torch.float32, device=dev)
     coefK = torch.empty(Ppad, 14, 3, 16, dtype=torch.bfloat16, device=dev)
-    L, st = _lib.lib(), _lib.stream_ptr()
+    L = _lib.lib()
     with torch.cuda.device(dev):
+        st = _lib.stream_ptr()              # the current stream of `dev`
         _lib.check(L.h3d_smpl_pose_heads(_lib.ptr(pose_map), _lib.ptr(shape_map), _lib.ptr(inds), B, K, n, HW, _lib.ptr(d["j_template"]),
                                          _lib.ptr(d["j_shapedirs"]), _lib.ptr(d["parents"]), None, _lib.ptr(pf), _lib.ptr(A), _lib.ptr(joints),
                                          _lib.ptr(coefK), Ppad, st), "smpl_pose_heads")

@@ -33,6 +33,11 @@ extern "C" {
 #define H3D_BF16 1
 #define H3D_F16 2 /* IEEE fp16 activations and weights, fp32 accumulation (BASELINE configs[4]: `--arch resdcn_101` runs in fp16,
                      experiments/ctdet_coco_resdcn101.sh:3); stored values saturate at +-65504 */
+#define H3D_F16X3 3 /* the parity arithmetic on the fp16 matrix cores (round 5): fp32 activations in memory exactly as H3D_F32 (same ops,
+                       same layouts), every contraction with both fp32 operands split into two fp16 terms x = hi + lo and three products
+                       hi.hi + hi.lo + lo.hi accumulated in fp32 (the dropped lo.lo is 2^-22 relative): fp32-level results at ~3x the
+                       H3D_F32 plan's rate.  Packed filters hold, per 8 consecutive input channels, 8 fp16 hi terms then 8 fp16 lo terms
+                       in the 32 bytes the 8 fp32 values would occupy (engine.PackedWeights / h3d_x3_split).  |activation| <= 65504. */
 
 /* Last error text of the calling thread (thread_local), for the Python shim's RuntimeError. */
 const char *h3d_last_error(void);
@@ -58,6 +63,15 @@ int h3d_dcn_v2_forward(const float *input, const float *weight, const float *bia
                        int kernel_h, int kernel_w, int stride_h, int stride_w,
                        int pad_h, int pad_w, int dilation_h, int dilation_w,
                        int deformable_group, void *stream);
+
+/* The convolution in front of the operator inside the `DCN` module (dcn_v2.py:107-111, 119-124), for ANY module configuration:
+ *   out = Conv2d(C, 3*dg*kh*kw, (kh,kw), stride, padding)(input);  o1, o2, m = chunk(out, 3, dim=1)
+ *   offset [B,2*dg*kh*kw,Ho,Wo] = cat(o1, o2)    mask [B,dg*kh*kw,Ho,Wo] = sigmoid(m)
+ * off_weight [3*dg*kh*kw, C, kh, kw], off_bias [3*dg*kh*kw]; Ho = (H + 2*pad_h - kh) / stride_h + 1 (the reference passes no dilation to
+ * this convolution).  Runs the general operator kernel with zero offsets and a unit mask -- no vendor library on any DCN path. */
+int h3d_dcn_offset_mask(const float *input, const float *off_weight, const float *off_bias, float *offset, float *mask,
+                        int B, int C, int H, int W, int kernel_h, int kernel_w, int stride_h, int stride_w,
+                        int pad_h, int pad_w, int deformable_group, void *stream);
 
 /* The same operator with a caller-provided device workspace of h3d_dcn_v2_workspace_bytes(...) bytes (the reference
  * callee allocates its own scratch: `columns`, `ones`, pointer tables, dcn_v2_cuda.cu:90-103).  For the configuration the

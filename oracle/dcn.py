@@ -16,11 +16,18 @@ import numpy as np
 import torch
 
 
+def _r16(t):
+    return t.half().to(t.dtype)
+
+
 def dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg,
-                   acc_dtype=None):
+                   acc_dtype=None, blend=None):
     """input [B,C,H,W], weight [Co,C,kh,kw], bias [Co], offset [B,2*dg*kh*kw,Ho,Wo],
     mask [B,dg*kh*kw,Ho,Wo] -> [B,Co,Ho,Wo].  acc_dtype=torch.float64 gives the
-    order-independent GEMM value."""
+    order-independent GEMM value.
+    blend='f16': the bilinear blend as the 2-byte GPU plans evaluate it (csrc/dcn_traits.h SE<bf16_t>::blend): the four weights
+    times the mask rounded to fp16, then x = fp16(v1 w1); x = fp16(fma(v_k, w_k, x)) for k = 2..4 -- four fp16 roundings per sample
+    (the inputs must hold fp16-representable values)."""
     B, C, H, W = input.shape
     Co = weight.shape[0]
     Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
@@ -69,6 +76,14 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh
                 w2 = (hh * lw).view(B, 1, -1)
                 w3 = (lh * hw).view(B, 1, -1)
                 w4 = (lh * lw).view(B, 1, -1)
+                if blend == "f16":
+                    mm = (m * inside.to(dt)).reshape(B, 1, -1)
+                    q1, q2, q3, q4 = [_r16(wk * mm).double() for wk in (w1, w2, w3, w4)]      # make_geo: (w * mask) -> fp16
+                    xv = _r16(v1.double() * q1)                                                   # v_pk_mul_f16
+                    for vk, qk in ((v2, q2), (v3, q3), (v4, q4)):
+                        xv = _r16(vk.double() * qk + xv)                                          # v_pk_fma_f16 (one rounding: the fp64 sum is exact)
+                    cols[:, g * cpg:(g + 1) * cpg, t] = xv.to(dt)
+                    continue
                 val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4
                 val = val * inside.view(B, 1, -1).to(dt)
                 cols[:, g * cpg:(g + 1) * cpg, t] = val * m.reshape(B, 1, -1)
@@ -83,7 +98,7 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh
 
 
 def dcn_module_forward(x, weight, bias, om_weight, om_bias, stride=1, padding=1, dilation=1, dg=1,
-                       acc_dtype=None):
+                       acc_dtype=None, blend=None):
     """DCN.forward (dcn_v2.py:118-128): conv_offset_mask -> chunk(3) -> cat(o1,o2), sigmoid(mask)."""
     kh, kw = weight.shape[2:]
     out = torch.nn.functional.conv2d(x, om_weight, om_bias, stride, padding)
@@ -91,7 +106,7 @@ def dcn_module_forward(x, weight, bias, om_weight, om_bias, stride=1, padding=1,
     offset = torch.cat((o1, o2), dim=1)
     mask = torch.sigmoid(mask)
     return dcn_v2_forward(x, weight, bias, offset, mask, kh, kw, stride, stride, padding, padding,
-                          dilation, dilation, dg, acc_dtype=acc_dtype)
+                          dilation, dilation, dg, acc_dtype=acc_dtype, blend=blend)
 
 
 # ---------------------------------------------------------------------------------------------

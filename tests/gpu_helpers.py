@@ -8,9 +8,9 @@ import h3d_amd  # noqa: F401
 from h3d_amd import _lib
 from h3d_amd._lib import H3dOp
 
-TD = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
-HD = {"f32": _lib.H3D_F32, "bf16": _lib.H3D_BF16, "f16": _lib.H3D_F16}
-TN = {"f32": "float", "bf16": "unsigned short", "f16": "f16_t"}      # element-type names inside the kernel symbols
+TD = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f16x3": torch.float32}      # storage type of a plan's activations
+HD = {"f32": _lib.H3D_F32, "bf16": _lib.H3D_BF16, "f16": _lib.H3D_F16, "f16x3": _lib.H3D_F16X3}
+TN = {"f32": "float", "bf16": "unsigned short", "f16": "f16_t", "f16x3": "x3_t"}      # element-type names inside the kernel symbols
 DEV = "cuda:0"
 
 
@@ -23,6 +23,9 @@ def pack_conv(w, b, dtype, pad_cout_to=None):
     bp = torch.zeros(rows)
     if b is not None:
         bp[:co] = b
+    if dtype == "f16x3":          # fp32 filters as (hi | lo) fp16 terms per 8 input channels (engine.x3_split)
+        from h3d_amd import engine
+        return engine.x3_split(wp).contiguous().to(DEV), bp.to(DEV), cout, rows
     return wp.to(TD[dtype]).contiguous().to(DEV), bp.to(DEV), cout, rows
 
 
@@ -104,8 +107,8 @@ def bf16_round(t):
 
 
 def lowp_round(t, dtype):
-    """Round to the plan's storage type (f32: unchanged)."""
-    return t if dtype == "f32" else t.to(TD[dtype]).float()
+    """Round to the plan's storage type (f32 / f16x3: unchanged)."""
+    return t if dtype in ("f32", "f16x3") else t.to(TD[dtype]).float()
 
 
 def rnd(key, shape, lo=-1.0, hi=1.0, seed=0):

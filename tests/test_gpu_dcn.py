@@ -237,12 +237,111 @@ def test_dcn_module_runs_outside_no_grad_like_the_reference_module():
     # the general (non-fused) configuration goes through the operator: same rule
     mod2 = dcn_v2.DCN(16, 8, kernel_size=(3, 3), stride=2, padding=1).to(DEV).eval()
     assert not mod2(rnd("x2", (1, 16, 12, 12)).to(DEV)).requires_grad
-    # training mode with grad enabled: a fine-tuning loop must not silently get no gradients
+    # training mode with grad enabled (a freshly constructed module: the reference's plain usage `DCN(...).cuda()(x)`, DCNv2/test.py:169-180):
+    # the forward result comes back; a fine-tuning loop must not silently get no gradients: its backward raises
+    yt = mod.train()(x)
+    assert torch.equal(yt.detach(), y) and yt.requires_grad
     with pytest.raises(RuntimeError, match="inference-only"):
-        mod.train()(x)
+        yt.sum().backward()
     with torch.no_grad():
         assert torch.equal(mod.train()(x), y)
     mod.eval()
+
+
+@pytest.mark.parametrize("cfg", [dict(dg=2), dict(stride=2), dict(dg=4, cin=48, cout=20), dict(k=1, padding=0), dict(dilation=2, padding=1)])
+def test_dcn_module_outside_the_model_configuration_vs_oracle_without_any_vendor_conv(cfg, monkeypatch):
+    """The reference's own example `DCN(64, 64, 3x3, dg=2)` on [2,64,128,128] (DCNv2/test.py:169-180) and other module
+    configurations the fused launch does not cover: conv_offset_mask -> chunk / cat / sigmoid runs on this library's general
+    kernel (`h3d_dcn_offset_mask`), then the operator -- nn.Conv2d.forward and F.conv2d are patched to raise while the product
+    runs (round 4 called nn.Conv2d, i.e. MIOpen, here)."""
+    torch.manual_seed(0)
+    k, dg, cin, cout = cfg.get("k", 3), cfg.get("dg", 1), cfg.get("cin", 64), cfg.get("cout", 64)
+    stride, padding, dilation = cfg.get("stride", 1), cfg.get("padding", 1), cfg.get("dilation", 1)
+    mod = dcn_v2.DCN(cin, cout, kernel_size=(k, k), stride=stride, padding=padding, dilation=dilation, deformable_groups=dg).to(DEV)
+    if dilation != 1:
+        # the reference's conv_offset_mask takes no dilation (dcn_v2.py:107-111): its output only matches the operator's grid when
+        # (H + 2p - k) / s == (H + 2p - d(k-1) - 1) / s, which no 3x3 d=2 module satisfies -- the operator's shape check must say so
+        with pytest.raises(RuntimeError, match="offset shape"):
+            mod(rnd("x", (1, cin, 12, 12)).to(DEV))
+        return
+    with torch.no_grad():
+        mod.conv_offset_mask.weight.copy_(rnd("ow", tuple(mod.conv_offset_mask.weight.shape)).to(DEV) * 0.08)
+        mod.conv_offset_mask.bias.copy_(rnd("ob", tuple(mod.conv_offset_mask.bias.shape)).to(DEV) * 0.3)
+        mod.bias.copy_(rnd("b", (cout,)).to(DEV))
+    shape = (2, 64, 128, 128) if cfg == dict(dg=2) else (2, cin, 21, 26)
+    x = rnd("x", shape)
+    assert not mod._fused_ok(x.to(DEV))
+    sd = {n: v.detach().cpu() for n, v in mod.state_dict().items()}
+    ref = odcn.dcn_module_forward(x, sd["weight"], sd["bias"], sd["conv_offset_mask.weight"], sd["conv_offset_mask.bias"], stride=stride,
+                                  padding=padding, dilation=dilation, dg=dg, acc_dtype=torch.float64)
+
+    def boom(*a, **kw):
+        raise AssertionError("a torch convolution was called inside h3d_amd.dcn_v2.DCN.forward")
+    monkeypatch.setattr(torch.nn.Conv2d, "forward", boom)
+    monkeypatch.setattr(torch.nn.functional, "conv2d", boom)
+    y = mod(x.to(DEV))           # (training mode, grad enabled: the reference's plain usage)
+    monkeypatch.undo()
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=0, atol=3e-4)
+
+
+def test_dcn_offset_mask_entry_point_vs_torch():
+    """`h3d_dcn_offset_mask` alone: offset = the first 2k channels of Conv2d(x), mask = sigmoid of the last k (dcn_v2.py:119-124), ragged
+    sizes, stride 2, a 5x3 kernel."""
+    for (C, kh, kw, sh, sw, ph, pw, dg, H, W) in [(16, 3, 3, 1, 1, 1, 1, 1, 9, 13), (7, 5, 3, 2, 1, 2, 0, 2, 17, 11), (32, 1, 1, 1, 1, 0, 0, 3, 6, 6)]:
+        k = dg * kh * kw
+        x, w, b = rnd("x", (2, C, H, W)), rnd("w", (3 * k, C, kh, kw), -0.2, 0.2), rnd("b", (3 * k,))
+        ref = F.conv2d(x.double(), w.double(), b.double(), (sh, sw), (ph, pw))
+        Ho, Wo = ref.shape[2:]
+        off = torch.empty(2, 2 * k, Ho, Wo, device=DEV)
+        m = torch.empty(2, k, Ho, Wo, device=DEV)
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)          # (kept alive across the launch)
+        _lib.check(_lib.lib().h3d_dcn_offset_mask(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(off), _lib.ptr(m), 2, C, H, W,
+                                                  kh, kw, sh, sw, ph, pw, dg, _lib.stream_ptr()), "dcn_offset_mask")
+        np.testing.assert_allclose(off.cpu().numpy(), ref[:, :2 * k].float().numpy(), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(m.cpu().numpy(), torch.sigmoid(ref[:, 2 * k:]).float().numpy(), rtol=0, atol=2e-6)
+
+
+def test_dcn_module_and_operator_on_a_second_stream_do_not_touch_the_owner_streams_pack():
+    """the kept packs are validated through ONE 16-byte accumulator, so they belong to the stream that created them; a call
+    on any other stream packs into buffers of its own.  Interleaved forwards on two streams (with a parameter edit in between) must both
+    see the current parameters and agree bit for bit."""
+    torch.manual_seed(3)
+    mod = dcn_v2.DCN(32, 24, kernel_size=(3, 3), stride=1, padding=1).to(DEV).eval()
+    with torch.no_grad():
+        mod.conv_offset_mask.weight.copy_(rnd("ow", (27, 32, 3, 3)) * 0.05)
+    x = rnd("x", (2, 32, 14, 18)).to(DEV)
+    off, m = (rnd("off", (2, 18, 14, 18), -2, 2).to(DEV), rnd("m", (2, 9, 14, 18), 0, 1).to(DEV))
+    y0 = mod(x)
+    z0 = dcn_v2.dcn_v2_conv(x, off, m, mod.weight, mod.bias, 1, 1, 1, 1)
+    owner = mod._pack[0].data_ptr()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        y1 = mod(x)
+        z1 = dcn_v2.dcn_v2_conv(x, off, m, mod.weight, mod.bias, 1, 1, 1, 1)
+        mod.weight.data.mul_(2.0)
+        y2 = mod(x)
+        z2 = dcn_v2.dcn_v2_conv(x, off, m, mod.weight, mod.bias, 1, 1, 1, 1)
+    side.synchronize()
+    assert mod._pack[0].data_ptr() == owner            # the kept pack still belongs to the first stream
+    assert torch.equal(y0, y1) and torch.equal(z0, z1)
+    y3 = mod(x)
+    z3 = dcn_v2.dcn_v2_conv(x, off, m, mod.weight, mod.bias, 1, 1, 1, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y3) and torch.equal(z2, z3) and not torch.equal(y0, y3)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_dcn_module_on_a_non_current_device():
+    """the pack kernels must run on the input's device and stream, not on the current device's."""
+    torch.manual_seed(4)
+    mod = dcn_v2.DCN(32, 24, kernel_size=(3, 3), stride=1, padding=1).to("cuda:1").eval()
+    x = rnd("x", (1, 32, 10, 10))
+    with torch.cuda.device(0):
+        y = mod(x.to("cuda:1"))
+    ref = mod.to(DEV)(x.to(DEV))
+    assert torch.equal(y.cpu(), ref.cpu())
 
 
 def test_dcn_module_sees_parameter_edits_through_data():

@@ -5,9 +5,15 @@ configurations and grid sizes as the benchmark); then
   * the heads of the two images are compared with the fp32 oracle network (oracle/dla.py, pinned to the reference's
     own model output by tests/test_oracle_golden.py).  The tolerance is not a constant: the synthetic weights with
     gain 1.25 keep the signal alive through DLA-34 (head maps with std 1-2.5), which also amplifies rounding noise,
-    so the yardstick is an INDEPENDENT bf16 evaluation of the same graph on the CPU (DLAOracle(emulate_bf16=True)):
-    the GPU's distance from the fp32 result may be at most 1.5x that evaluation's, in max-norm and in rms, per head
-    (measured: GPU 0.41-0.73 max / emulation 0.39-0.70 max on heads of std 0.8-2.5);
+    so the yardstick is a CPU evaluation of the same graph that rounds WHERE THE PLAN ROUNDS (DLAOracle(emulate="bf16_plan"),
+    round 5: BatchNorm folded into the filters before they are rounded, every stored activation rounded -- residual and skip
+    operands included --, fp16 DeformConv filters / samples / blend, fp16 node inputs).  Per head, the GPU's distance from
+    the fp32 result may be at most 1.5x that evaluation's in max-norm and in rms and 1.25x in the 99.99 % quantile of |error|.
+    (Rounds 3-4 compared with emulate="bf16", which rounds conv inputs and raw filters only: it has a lighter error tail than
+    any plan that stores 2-byte activations -- `hm`: max 0.38 / q99.99 0.36 against 0.52 / 0.47 for the plan's rounding points and
+    0.52-0.62 / 0.46-0.57 on the GPU -- and in round 4 the max-norm bound was widened to the maximum over all heads to let that
+    pass; tools/hm_tail.py + DESIGN.md section 9.2 have the bisection: stored residual / skip operands make the tail, the folded
+    filters make the GPU's error correlate with the emulation's (0.20 -> 0.66) and reproduce its mean shift on `hm`.);
   * every repeat must be BIT-identical to the first occurrence, and a second forward to the first forward -- a race in
     a DMA ring / counted wait of the 8- and 16-wave variants shows up here;
   * the decoded top-k peak indices are compared with the oracle's (oracle/index_match.py): bit-identical on the
@@ -26,7 +32,14 @@ from oracle import index_match as oim
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BF16_RATIO = 1.5  # GPU bf16 error / CPU bf16-emulation error (both vs the fp32 oracle), max-norm and rms
+Q_RATIO = 1.25    # ... and in the 99.99 % quantile of |error| (per head, against the plan-faithful emulation)
 GAIN = 1.25       # signal-preserving synthetic weights (h3d_amd.synth): head maps with O(1) variation and separated peaks
+
+
+def _err_stats(got, ref):
+    """(max, rms, 99.99 % quantile) of |got - ref|"""
+    e = np.abs(got - ref).ravel()
+    return float(e.max()), float(np.sqrt(np.mean(e ** 2))), float(np.quantile(e, 0.9999))
 
 
 @pytest.fixture(scope="module")
@@ -38,8 +51,8 @@ def setup():
     torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
     with torch.no_grad():
         ref = {k: v.numpy() for k, v in odla.DLAOracle(sd, opt.heads, use_dcn=True)(torch.from_numpy(two))[0].items()}
-        emu = {k: v.numpy() for k, v in odla.DLAOracle(sd, opt.heads, use_dcn=True, emulate_bf16=True)(torch.from_numpy(two))[0].items()}
-    tol = {k: (float(np.abs(emu[k] - ref[k]).max()), float(np.sqrt(np.mean((emu[k] - ref[k]) ** 2)))) for k in ref}
+        emu = {k: v.numpy() for k, v in odla.DLAOracle(sd, opt.heads, use_dcn=True, emulate="bf16_plan")(torch.from_numpy(two))[0].items()}
+    tol = {k: _err_stats(emu[k], ref[k]) for k in ref}
     return opt, det, two, ref, tol, sd
 
 
@@ -53,16 +66,14 @@ def test_full_size_bf16_plan_vs_oracle(setup, batch):
     dets = res["dets"].clone()
     # (1) parity of the first two images
     got = {k: v[:2].cpu().numpy() for k, v in heads.items()}
-    worst = {k: (float(np.abs(got[k] - ref[k]).max()), float(np.sqrt(np.mean((got[k] - ref[k]) ** 2)))) for k in opt.heads}
-    print("batch %d: head error vs fp32 oracle (max, rms): %s" % (batch, {k: (round(a, 4), round(b, 4)) for k, (a, b) in worst.items()}))
-    print("          CPU bf16 emulation         (max, rms): %s" % {k: (round(a, 4), round(b, 4)) for k, (a, b) in tol.items()})
-    # rms per head against the emulation's rms of THAT head; the max-norm against the emulation's max-norm over ALL heads: the
-    # maximum of a noise field over the 32768 samples of a one-channel head is itself a noisy number (round 4, `hm`: emulation
-    # max 0.394 / 99.99 % quantile 0.365, GPU 0.58-0.62 / 0.55-0.57 with and without fp16 node inputs, while the rms ratio is
-    # 1.03 -- the emulation's own max over the eight heads is 0.705)
-    emu_max_all = max(t[0] for t in tol.values())
-    for k, (emax, erms) in worst.items():
-        assert emax <= BF16_RATIO * emu_max_all + 1e-3 and erms <= BF16_RATIO * tol[k][1] + 1e-4, (k, emax, erms, tol[k], emu_max_all)
+    worst = {k: _err_stats(got[k], ref[k]) for k in opt.heads}
+    print("batch %d: head error vs fp32 oracle (max, rms, q99.99): %s" % (batch, {k: tuple(round(a, 4) for a in t) for k, t in worst.items()}))
+    print("          CPU emulation of the plan  (max, rms, q99.99): %s" % {k: tuple(round(a, 4) for a in t) for k, t in tol.items()})
+    print("          ratios                     (max, rms, q99.99): %s" % {k: tuple(round(a / b, 3) for a, b in zip(worst[k], tol[k])) for k in worst})
+    # every bound is per head, against the emulation's figure of THAT head
+    for k, (emax, erms, eq) in worst.items():
+        tmax, trms, tq = tol[k]
+        assert emax <= BF16_RATIO * tmax + 1e-3 and erms <= BF16_RATIO * trms + 1e-4 and eq <= Q_RATIO * tq + 1e-3, (k, worst[k], tol[k])
     # (2) every repeat bit-identical, run-to-run bit-identical
     for k, v in heads.items():
         r = v.view(batch // 2, 2, *v.shape[1:])
@@ -84,12 +95,14 @@ def test_full_size_bf16_plan_vs_oracle(setup, batch):
     torch.cuda.empty_cache()
 
 
-def test_full_size_f32_mode_indices_match_oracle(setup):
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_full_size_f32_mode_indices_match_oracle(setup, dtype):
     """Parity mode (fp32 activations, exact fmaf chains on v_mfma_f32_32x32x2_f32) at 512x512: here the metric's
     "top-k index bit-match" is attainable end to end -- heads within 2e-3 of the oracle (max |head| ~ 10) and the decoded
-    peak indices identical to the oracle's wherever the score gap exceeds that error."""
+    peak indices identical to the oracle's wherever the score gap exceeds that error.  "f16x3" (round 5) is the same contract on
+    the fp16 matrix cores: fp32 storage, three fp16 MFMAs on split operands per fp32 product."""
     opt, _, two, ref, _, sd = setup
-    o32 = Opt(input_h=512, input_w=512, smpl=True, dtype="f32", K=100)
+    o32 = Opt(input_h=512, input_w=512, smpl=True, dtype=dtype, K=100)
     det = MultiPoseDetector(o32, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
     res = det.run(torch.from_numpy(two).to(DEV))
     got = {k: v.cpu().numpy() for k, v in res["heads"].items()}
@@ -97,8 +110,8 @@ def test_full_size_f32_mode_indices_match_oracle(setup):
         e = float(np.abs(got[k] - ref[k]).max())
         assert e <= 2e-3, (k, e)
     m = oim.index_match(got, res["inds"].cpu().numpy(), ref, K=100)
-    print("f32 mode: index_match %s" % m)
-    assert m["robust_prefix_equal"] and m["agreement"] >= 0.95 and m["set_overlap"] >= 0.98, m
+    print("%s mode: max head error %.3g, index_match %s" % (dtype, max(float(np.abs(got[k] - ref[k]).max()) for k in o32.heads), m))
+    assert m["robust_prefix_equal"] and m["agreement"] >= (0.99 if dtype == "f16x3" else 0.95) and m["set_overlap"] >= 0.98, m
     # ... and the bit-match clause is not vacuous here: some ranks are provably stable under the measured score error
     # (bench.py's parity_mode record on the same weights: robust_prefix 5, equal_prefix 100)
     assert m["robust_prefix"] > 0, m
@@ -177,7 +190,8 @@ def test_full_size_resdcn_shard_vs_oracle(dtype):
     torch.cuda.empty_cache()
 
 
-def test_end_to_end_f32_plain_plan_vs_reference_output(golden_dir):
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_end_to_end_f32_plain_plan_vs_reference_output(golden_dir, dtype):
     """The metric's second clause ("bit-exact top-k peak indices vs the reference's own CPU path") against reference
     OUTPUT, images -> indices: tests/golden/e2e_plain_512.npz is what the imported reference returns for
     `dla_net(heads, not_use_dcn=True)` (model.py:501-516) -> `_sigmoid` (utils.py:8-10; trainer.py:93,127) ->
@@ -193,7 +207,7 @@ def test_end_to_end_f32_plain_plan_vs_reference_output(golden_dir):
     g = np.load(os.path.join(golden_dir, "e2e_plain_512.npz"))
     heads = {"hm": 1, "wh": 2, "hps": 34, "reg": 2, "hm_hp": 17, "hp_offset": 2}
     sd = synth.synth_state_dict(arch.state_dict_shapes(heads, False), seed=0, gain=GAIN)
-    m = model.dla_net(heads, not_use_dcn=True, dtype="f32")
+    m = model.dla_net(heads, not_use_dcn=True, dtype=dtype)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to(DEV).eval()
     out = m(torch.from_numpy(synth.synth_images(2, 512, 512, seed=317)).to(DEV))[0]

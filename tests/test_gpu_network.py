@@ -31,9 +31,10 @@ def _net(use_dcn, dtype, heads=HEADS):
     return m.to(DEV).eval(), sd
 
 
-def test_plain_f32_matches_reference_golden(golden_dir):
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])     # f16x3: the same fp32 parity bound on split-operand fp16 MFMAs (csrc/common.h ET<x3_t>)
+def test_plain_f32_matches_reference_golden(golden_dir, dtype):
     g = np.load(os.path.join(golden_dir, "dla34_plain.npz"))
-    m, _ = _net(False, "f32")
+    m, _ = _net(False, dtype)
     x = torch.from_numpy(synth.synth_images(2, 96, 128, seed=317)).to(DEV)
     out = m(x)[0]
     assert set(out) == set(HEADS)
@@ -43,8 +44,9 @@ def test_plain_f32_matches_reference_golden(golden_dir):
         np.testing.assert_allclose(got, g[k], rtol=0, atol=F32_TOL, err_msg=k)
 
 
-def test_dcn_f32_matches_oracle():
-    m, sd = _net(True, "f32")
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_dcn_f32_matches_oracle(dtype):
+    m, sd = _net(True, dtype)
     xs = synth.synth_images(2, 64, 96, seed=5)
     out = m(torch.from_numpy(xs).to(DEV))[0]
     with torch.no_grad():

@@ -117,6 +117,10 @@ DCN_CASES = [
     ("fused", "bf16", 0, 1, 48, 32, 16, 16, 0.5),          # dcn3<bf16,1,16,2>
     ("fused", "f32", 0, 1, 64, 64, 20, 24, 3.0),           # parity mode
     ("fused", "f32", 0, 1, 32, 32, 16, 16, 12.0),
+    ("fused", "f16x3", 0, 1, 64, 64, 20, 24, 3.0),         # parity arithmetic on the fp16 matrix cores: dcn3<x3_t,2,16,2>
+    ("fused", "f16x3", 0, 2, 128, 64, 24, 40, 0.5),
+    ("fused", "f16x3", 0, 1, 32, 32, 16, 16, 12.0),        # dcn3<x3_t,1,16,2>, most samples through pass 2
+    ("fused", "f16x3", 0, 1, 256, 128, 16, 16, 3.0),       #   two channel groups
     ("stream", "bf16", 0, 2, 128, 64, 24, 40, 0.5),        # dcn3<bf16,2,16,2,WDMA,256>: two workgroups per CU, patch slots
     ("stream", "bf16", 0, 1, 256, 64, 16, 32, 3.0),        #   ... 4-13 % of the samples in patches
     ("stream", "bf16", 0, 2, 64, 64, 40, 24, 6.0),         #   ... more samples leave the apron than a tile has slots: patches AND pass 2
@@ -231,7 +235,8 @@ def test_dcn_fused_variant_matches_oracle(case):
     # f32: exact fmaf chains, offsets from an fp32 conv (sampling positions move by ~1e-6 px).
     # bf16: fp16 blend (2^-11 per sample) + f16 MFMA with fp32 accumulation + one bf16 rounding of the output (2^-9)
     # fp16: the same blend and MFMA, fp16 rounding of the output (2^-12)
-    tol = 2e-4 * scale if dtype == "f32" else (1.2e-2 if dtype == "bf16" else 4e-3) * scale
+    # f16x3: the fp32 blend and geometry, every product as three fp16 MFMAs on split operands: the f32 bound
+    tol = 2e-4 * scale if dtype in ("f32", "f16x3") else (1.2e-2 if dtype == "bf16" else 4e-3) * scale
     frac_far = float((om[:, :18].abs() > 1.0).float().mean())
     assert err <= tol, "%s: max err %.3g > %.3g (scale %.2f, |offset|>1 for %.0f%%)" % (built.name, err, tol, scale, 100 * frac_far)
     assert torch.equal(got, built.run()), built.name
