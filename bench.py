@@ -46,9 +46,106 @@ from h3d_amd import _lib, arch, synth  # noqa: E402
 from h3d_amd.detector import MultiPoseDetector, Opt, gather_detections, shard_batch  # noqa: E402
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X dense bf16 / fp16 (MI355X_MICROARCH.md, chip-level parameters)
-PEAK_MFMA_TFLOPS = {"bf16": PEAK_BF16_MFMA_TFLOPS, "f16": PEAK_BF16_MFMA_TFLOPS, "f32": 157.3}
+# f16x3: every algorithmic FLOP costs three fp16 MFMA FLOP (hi.hi + hi.lo + lo.hi), so the plan's ceiling on ALGORITHMIC FLOP is a third
+PEAK_MFMA_TFLOPS = {"bf16": PEAK_BF16_MFMA_TFLOPS, "f16": PEAK_BF16_MFMA_TFLOPS, "f32": 157.3, "f16x3": round(PEAK_BF16_MFMA_TFLOPS / 3, 1)}
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # this round's counter passes; a kernel that is not in it reports traffic: null
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # this round's counter passes; a kernel that is not in it reports traffic: null
+PMC_SQ_FILE = "r05_pmc_sq_summary.json"     # ... SQ counters per kernel (mfma_util, gpu_cycles, ...)
+KERNEL_STATS_FILE = "r05_v1_kernel_stats.csv"   # ... rocprofv3 --kernel-trace --stats summary of `bench.py --pipeline 1`
+
+
+class ClockSampler:
+    """Shader clock during the timed region, as the kernel driver reports it (sysfs pp_dpm_sclk of this process's GPU: the entry
+    marked `*`), sampled from a host thread every few milliseconds.  Best effort: a box that hides the file gives null.  The
+    2.5 PFLOP/s peak assumes 2.4 GHz; under MFMA + LDS load on real data the boxes of this pool hold 1.9-2.2 GHz, and a reader of
+    the roofline fractions needs to know which."""
+
+    def __init__(self, dev_index):
+        import glob
+        import threading
+        self.path = None
+        try:
+            pci = torch.cuda.get_device_properties(dev_index)
+            want = getattr(pci, "pci_bus_id", None)
+        except Exception:
+            want = None
+        cands = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        for c in cands:
+            try:
+                if want is not None:
+                    bus = os.path.basename(os.path.realpath(os.path.dirname(c)))         # e.g. 0000:05:00.0
+                    if int(bus.split(":")[1], 16) != int(want):
+                        continue
+                open(c).read()
+                self.path = c
+                break
+            except Exception:
+                continue
+        if self.path is None and len(cands) == 1:
+            self.path = cands[0]
+        self.samples = []
+        self._stop = threading.Event()
+        self._thr = None
+
+    def _read(self):
+        try:
+            for ln in open(self.path).read().splitlines():
+                if "*" in ln:
+                    return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+        except Exception:
+            return None
+        return None
+
+    def __enter__(self):
+        import threading
+        if self.path is not None:
+            def loop():
+                while not self._stop.is_set():
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                    time.sleep(0.004)
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thr is not None:
+            self._thr.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        a = np.asarray(self.samples)
+        return {"min": int(a.min()), "median": int(np.median(a)), "max": int(a.max()), "samples": int(a.size), "source": self.path}
+
+
+def profile_figures(name):
+    """What the committed profile of THIS round says about kernel `name` (rocprofv3 --kernel-trace --stats average duration; SQ
+    counters from the separate --pmc passes): -> dict (missing files / kernels give nulls)."""
+    out = {"avg_launch_ms_rocprof": None, "mfma_util": None, "clock_mhz_under_rocprof": None}
+    try:
+        import csv
+        with open(os.path.join(ROOT, "profiles", KERNEL_STATS_FILE)) as f:
+            for row in csv.DictReader(f):
+                import re
+                nm = re.sub(r"\(.*\)$", "", re.sub(r"^void ", "", row.get("Name", ""))).strip()
+                nm = re.sub(r"(, false)+>$", ">", nm)        # trailing defaulted template arguments (tools/pmc_summary.py norm)
+                if nm == name:
+                    out["avg_launch_ms_rocprof"] = round(float(row["AverageNs"]) / 1e6, 4)
+                    break
+    except Exception:
+        pass
+    try:
+        k = json.load(open(os.path.join(ROOT, "profiles", PMC_SQ_FILE)))["kernels"].get(name)
+        if k:
+            out["mfma_util"] = k.get("mfma_util")
+            if out["avg_launch_ms_rocprof"] and k.get("gpu_cycles"):
+                out["clock_mhz_under_rocprof"] = int(round(k["gpu_cycles"] / (out["avg_launch_ms_rocprof"] * 1e3)))
+    except Exception:
+        pass
+    return out
 
 
 def op_flops(op):
@@ -73,7 +170,7 @@ def op_flops(op):
 def op_bytes(op):
     """Algorithmic HBM bytes of one plan op: every operand read once, every result written once (weights excluded: they
     stay in L2 / the Infinity Cache across the batch)."""
-    es = 4 if op.dtype == _lib.H3D_F32 else 2
+    es = 4 if op.dtype in (_lib.H3D_F32, _lib.H3D_F16X3) else 2
     pin, pout = op.B * op.H * op.W, op.B * op.Ho * op.Wo
     if op.kind in (_lib.OP_STEM, _lib.OP_STEM3, _lib.OP_IM2COL):
         return 4.0 * pin * op.Cin + es * pout * op.Cout + (es * (pout // 4) * 64 if op.kind == _lib.OP_STEM3 and op.in2 else 0)
@@ -566,19 +663,28 @@ def annotate_index_match(m, dtype):
     return m
 
 
-def parity_mode(args, size, images, keep, dev, steps=3):
-    """The metric's second clause on the SAME workload: the f32 plan (exact fmaf chains on v_mfma_f32_32x32x2_f32) timed on the
-    same 64 images, and its top-k peak indices on the cpu_baseline's 2 images against the fp32 oracle."""
+def parity_mode(args, size, images, keep, dev, dtype="f32", steps=3, nslot=1):
+    """The metric's second clause on the SAME workload: a parity plan timed on the same 64 images, and its top-k peak indices on the
+    cpu_baseline's 2 images against the fp32 oracle.  dtype "f32" = exact fmaf chains on v_mfma_f32_32x32x2_f32; "f16x3" (round 5) =
+    the same fp32 storage and launches with every fp32 product as three fp16 MFMAs on split operands (csrc/common.h ET<x3_t>).
+    `verts_vs` (f16x3): max |vertex difference| against the f32 plan's meshes on the oracle's two images."""
     from oracle import index_match as oim
-    det32, opt32, _, gflop = build_detector("dla_34", "f32", size, args, dev)
-    step, _ = make_step(det32, images, 1, 1, images.shape[0], dev)
-    dt = time_steps(step, steps, 1)
+    det32, opt32, _, gflop = build_detector("dla_34", dtype, size, args, dev)
+    step, _ = make_step(det32, images, nslot, 1, images.shape[0], dev)
+    dt = time_steps(step, steps, nslot)
     res = det32.run(keep["images"].to(dev))
     m = annotate_index_match(oim.index_match({k: v.cpu().numpy() for k, v in res["heads"].items()}, res["inds"].cpu().numpy(),
-                                             keep["heads"], K=opt32.K), "f32")
-    out = {"dtype": "f32", "images_per_s": round(images.shape[0] * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
-           "batch": int(images.shape[0]), "step_frac_of_f32_mfma_peak": round(gflop * images.shape[0] * steps / dt / 1e3 / PEAK_MFMA_TFLOPS["f32"], 4),
+                                             keep["heads"], K=opt32.K), dtype)
+    out = {"dtype": dtype, "images_per_s": round(images.shape[0] * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "steps_in_flight": nslot, "batch": int(images.shape[0]),
+           "step_frac_of_%s_peak" % ("f32_mfma" if dtype == "f32" else "f16x3"): round(gflop * images.shape[0] * steps / dt / 1e3 / PEAK_MFMA_TFLOPS[dtype], 4),
            "index_match": m}
+    if dtype == "f32":
+        keep["verts_f32"] = res["verts"].clone()
+        keep["inds_f32"] = res["inds"].clone()
+    elif "verts_f32" in keep:
+        out["inds_equal_f32_plan"] = bool(torch.equal(res["inds"], keep["inds_f32"]))
+        out["verts_max_abs_diff_vs_f32_plan"] = float((res["verts"] - keep["verts_f32"]).abs().max()) if out["inds_equal_f32_plan"] else None
     del det32
     torch.cuda.empty_cache()
     return out
@@ -682,7 +788,7 @@ def main():
                          "max-over-ranks timing -- so that the N > 1 code path meets the device before the driver's 8-GPU run does")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the records measured after the timed region (shard_sweep, parity_mode, other_archs)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f16x3"])
     ap.add_argument("--people", type=int, default=100, help="SMPL meshes per image (<= K)")
     ap.add_argument("--streams", type=int, default=1, help="sub-batches run concurrently on their own HIP streams")
     ap.add_argument("--pipeline", type=int, default=None,
@@ -788,15 +894,17 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    t_issued = time.perf_counter() - t0        # host time to ISSUE the K steps (launch-bound when it approaches dt)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    clock = ClockSampler(local)
+    with clock:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        t_issued = time.perf_counter() - t0        # host time to ISSUE the K steps (launch-bound when it approaches dt)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -805,6 +913,23 @@ def main():
     if rank == 0:
         print("[bench] %d GPU(s): %.1f images/s, %.3f ms/step" % (world, n_global * args.steps / dt,
                                                                  1e3 * dt / args.steps), file=sys.stderr, flush=True)
+    # a second, longer measurement of the same step (the driver fixes --steps: 20 steps are 0.15 s, boxes of the pool differ by a few
+    # percent over such a window).  Never `value`.
+    long_steps = max(200, args.steps) if (dla and not args.no_extras) else 0
+    value_long = None
+    if long_steps:
+        clock_long = ClockSampler(local)
+        with clock_long:
+            if dist is not None:
+                dist.barrier()
+            dt_long = time_steps(step, long_steps, 0)
+            if dist is not None:
+                dist.barrier()
+                t = torch.tensor([dt_long], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_long = float(t.item())
+        value_long = {"images_per_s": round(n_global * long_steps / dt_long, 2), "steps": long_steps, "ms_per_step": round(1e3 * dt_long / long_steps, 3),
+                      "shader_clock_mhz": clock_long.summary()}
 
     if rank == 0:
         peak = PEAK_MFMA_TFLOPS[args.dtype]
@@ -814,6 +939,7 @@ def main():
             "n_gpus": world, "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "host_issue_ms_per_step": round(1e3 * t_issued / args.steps, 3),
+            "value_long": value_long, "shader_clock_mhz": clock.summary(),
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -829,8 +955,9 @@ def main():
                        "weights": "synthetic (h3d_amd.synth, seed 0, gain %s, offset_scale %g)"
                                   % ("%g" % args.weight_gain if dla else "per arch", args.offset_scale)},
             # what the metric's second clause ("top-k index bit-match") can mean per arithmetic: see index_match / parity_mode
-            "metric_note": "value = throughput of the %s plan; top-k index bit-match against the fp32 oracle is attainable in the f32 "
-                           "plan only (parity_mode), the %s plan is reported with set overlap / agreement (index_match)" % (args.dtype, args.dtype),
+            "metric_note": "value = throughput of the %s plan; top-k index bit-match against the fp32 oracle is attainable in the fp32-storage "
+                           "plans (parity_mode: f32 = exact fmaf chains, f16x3 = the same on split-operand fp16 MFMAs at ~3x the rate), the %s plan is "
+                           "reported with set overlap / agreement (index_match)" % (args.dtype, args.dtype),
         }
         line["model_tflops"] = round(gflop_img * line["value"] / 1e3 / world, 1)      # per GPU
         if not args.no_roofline:
@@ -872,6 +999,14 @@ def main():
                                           "(independent of steps_in_flight: kernels of two steps sharing the GPU stretch individual launches)",
                                 "network_tflops": round(net_tflops, 1), "network_frac": round(net_tflops / peak, 4),
                                 "step_frac": round(line["model_tflops"] / peak, 4)}
+            # what a reader needs to tell a box difference from a kernel change: the shader clock of the timed region, and this
+            # round's committed profile of the same kernel (rocprofv3 average duration -> frac_rocprof; MFMA pipe utilisation)
+            pf = profile_figures(name)
+            line["roofline"].update(pf)
+            line["roofline"]["frac_rocprof"] = (round(g["flops"] / g["launches"] / (pf["avg_launch_ms_rocprof"] * 1e-3) / 1e12 / peak, 4)
+                                                if pf["avg_launch_ms_rocprof"] else None)
+            line["roofline"]["shader_clock_mhz_timed_region"] = line["shader_clock_mhz"]
+            line["roofline"]["peak_assumes_mhz"] = 2400
             print("[bench] roofline %s" % json.dumps(line["roofline"]), file=sys.stderr, flush=True)
             line["kernels"] = {k: {"ms": round(v["ms"], 3), "ms_min": round(v["ms_min"], 3), "ms_max": round(v["ms_max"], 3), "n": v["launches"],
                                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
@@ -905,6 +1040,12 @@ def main():
                 print("[bench] frames_uint8 %s" % json.dumps(line["frames_uint8"]), file=sys.stderr, flush=True)
                 line["parity_mode"] = parity_mode(args, size, images, keep, dev)
                 print("[bench] parity_mode %s" % json.dumps(line["parity_mode"]), file=sys.stderr, flush=True)
+                try:        # the same contract on the fp16 matrix cores (three steps in flight like the headline; 20 steps)
+                    line["parity_mode"]["f16x3"] = parity_mode(args, size, images, keep, dev, dtype="f16x3", steps=20, nslot=nslot)
+                except Exception as e:          # a record measured AFTER the headline number must not take the line down with it
+                    line["parity_mode"]["f16x3"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                keep.pop("verts_f32", None)
+                print("[bench] parity_mode f16x3 %s" % json.dumps(line["parity_mode"]["f16x3"]), file=sys.stderr, flush=True)
                 if args.dtype == "bf16":
                     try:
                         line["fp16_plan"] = fp16_plan(args, size, images, keep, dev, nslot)
@@ -930,6 +1071,10 @@ def main():
             print("[bench] offset_robustness %s" % json.dumps(line["offset_robustness"]), file=sys.stderr, flush=True)
             line["other_archs"] = other_archs(args, dev)
             print("[bench] other_archs %s" % json.dumps(line["other_archs"]), file=sys.stderr, flush=True)
+        if "index_match" in line:      # LAST on stderr: a 2000-character tail of this log shows the HEADLINE plan's parity, not only the co-plans'
+            print("[bench] headline plan (%s) index_match %s" % (args.dtype, json.dumps(line["index_match"])), file=sys.stderr, flush=True)
+            print("[bench] headline %.1f images/s (%s), value_long %s, shader clock %s" % (line["value"], args.dtype, json.dumps(value_long), json.dumps(line["shader_clock_mhz"])),
+                  file=sys.stderr, flush=True)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -17,7 +17,7 @@ OP_IM2COL, OP_MAXPOOL3, OP_DEPTH2SPACE = 15, 16, 17
 HEADS_MAX = 16
 OUT_NHWC, OUT_NCHW_F32, OUT_NHWC_F32, OUT_NHWC_F16 = 0, 1, 2, 3
 DCN_INPUT_NHWC, DCN_OUTPUT_NHWC = 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_vp, c_i, c_fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
 
@@ -33,16 +33,17 @@ class H3dOp(ctypes.Structure):
         ("Cout", ctypes.c_int32), ("out_cs", ctypes.c_int32),
         ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32), ("relu", ctypes.c_int32),
         ("out_mode", ctypes.c_int32), ("wrows", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("wexp", ctypes.c_int32), ("wexp2", ctypes.c_int32),
     ]
 
 
 class _HeadEntry(ctypes.Structure):
-    _fields_ = [("w2", c_vp), ("b2", c_vp), ("out", c_vp), ("C", ctypes.c_int32), ("pad", ctypes.c_int32)]
+    _fields_ = [("w2", c_vp), ("b2", c_vp), ("out", c_vp), ("C", ctypes.c_int32), ("wexp2", ctypes.c_int32)]
 
 
 class H3dHeadsDesc(ctypes.Structure):
     """Mirror of `struct h3d_heads_desc` (host-side descriptor behind H3D_OP_HEADS)."""
-    _fields_ = [("nheads", ctypes.c_int32), ("reserved", ctypes.c_int32), ("head", _HeadEntry * HEADS_MAX)]
+    _fields_ = [("nheads", ctypes.c_int32), ("wexp", ctypes.c_int32), ("head", _HeadEntry * HEADS_MAX)]
 
 
 class H3dUpdcnDesc(ctypes.Structure):
@@ -59,6 +60,7 @@ SIGNATURES = {
     "h3d_dcn_fused_pack_f32_cached": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp],
     "h3d_dcn_v2_forward_packed": [c_vp] * 5 + [c_i] * 7 + [c_vp, ctypes.c_size_t, c_vp],
     "h3d_dcn_offset_mask": [c_vp] * 5 + [c_i] * 11 + [c_vp],
+    "h3d_build_flags": [],
     "h3d_dcn_fused_ck": [c_i, c_i],
     "h3d_dcn_far_samples": [ctypes.POINTER(H3dOp), c_vp, c_vp],
     "h3d_smpl_pose_heads": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_vp],
@@ -123,6 +125,11 @@ def lib():
         L.h3d_nms_topk_large_workspace_bytes.restype = ctypes.c_size_t
         _lib = L
     return _lib
+
+
+def has_extra():
+    """True when libh3d_hip.so was built with `make EXTRA=1` (the superseded kernel generations are in: csrc/Makefile)."""
+    return bool(lib().h3d_build_flags() & 1)
 
 
 _ERR_NAMES = {-1: "shape", -2: "dtype", -3: "launch", -4: "unsupported", -5: "argument"}

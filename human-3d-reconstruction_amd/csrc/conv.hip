@@ -28,6 +28,7 @@ struct ConvArgs {
     int Ho, Wo, Cout, out_cs, res_cs;
     int relu, out_mode;
     int tiles_x, tiles_y;
+    float wscale;      // f16x3 plans: 2^-wexp, the packed filters are 2^wexp times the layer's (h3d_op.wexp); 1 otherwise
 };
 
 template <typename T, int KS, int STRIDE, int MT, int CK, int TH, int WAVES = 4>
@@ -166,6 +167,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
         }
     }
 
+    if constexpr (std::is_same_v<T, x3_t>) {      // the filters were packed times 2^wexp (normal fp16 lo terms): an exact power-of-two unscale
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][n][i] *= a.wscale;
+    }
     EpiArgs e;
     e.bias = a.bias; e.res = a.res; e.out = a.out; e.Ho = a.Ho; e.Wo = a.Wo; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = a.res_cs; e.relu = a.relu; e.out_mode = a.out_mode;
@@ -352,6 +361,8 @@ int h3d_launch_conv(const h3d_op &op, hipStream_t st)
     a.B = op.B; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.in_cs = op.in_cs;
     a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout; a.out_cs = op.out_cs; a.res_cs = op.in2_cs;
     a.relu = op.relu; a.out_mode = op.out_mode; a.tiles_x = a.tiles_y = 0;
+    if (op.wexp < -60 || op.wexp > 60 || (op.wexp && op.dtype != H3D_F16X3)) H3D_FAIL(H3D_ERR_ARG, "conv: wexp %d (an H3D_F16X3 filter exponent)", op.wexp);
+    a.wscale = ldexpf(1.f, -op.wexp);
     if (h3d_gemm1_takes(op)) return h3d_launch_gemm1(op, st);      // 1x1 stride 1, bf16: the GEMM kernel (csrc/gemm1.hip)
     if (op.dtype == H3D_BF16) return launch_conv_t<bf16_t>(op, a, st);
     if (op.dtype == H3D_F16) return launch_conv_t<f16_t>(op, a, st);

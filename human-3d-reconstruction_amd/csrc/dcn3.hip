@@ -37,6 +37,7 @@ struct Dcn3Args {
     int tiles_x, tiles_y;
     int dbg;   // profiling ablation (h3d_op.reserved): 1 no phase-A MFMA, 2 no gather/blend, 4 no phase-B MFMA, 8 stage once, 16 no patch fill
     int G;     // WDMA: 32-row groups of the main filter image
+    float wscale, oscale;   // f16x3 plans: 2^-wexp / 2^-wexp2 of the main / offset filters (h3d_op.wexp, wexp2); 1 otherwise
     int xcd;   // h3d_tile_id mode
     unsigned long long *stamps;   // profiling builds: in-kernel phase stamps (common.h H3D_STAMP)
 };
@@ -81,7 +82,12 @@ struct Dcn3Cfg {
     static constexpr int PSLOT = CK * SS;
     static constexpr int PB = NP ? (NP * PSLOT + 255) / 256 * 256 : 0;
     static constexpr int STAGE = PB + LDS_H + WSLOT;                   // one stage buffer (non-WDMA)
-    static constexpr int LDS_MAIN = WDMA ? PB + LDS_H + 2 * WSLOT : 2 * STAGE;
+    // SINGLE (round 5, f16x3 plans): ONE stage buffer for the register-staged path too -- an fp32 apron with margin 4 (26 x 26 pixels of
+    // 80 B: 60 KB) plus its filters is 98 KB, twice that does not exist.  The f32 / f16x3 variants have no patch slots, so every
+    // sample outside the apron goes through pass 2 (serialised global gathers: a third of the margin-2 kernel's time at the default
+    // offsets, tools/ab_lib.py --offset-scale 0.01 vs 0.5); the wider apron keeps 8 of 10 of them inside for a second barrier per stage.
+    static constexpr bool SINGLE = !WDMA && SS == 4 && MARGIN > 2;
+    static constexpr int LDS_MAIN = WDMA ? PB + LDS_H + 2 * WSLOT : SINGLE ? STAGE : 2 * STAGE;
     static constexpr int LDS_DESC = NP ? NP * 16 + 32 : 0;             // sample list (16 B each) + the eight per-wave sample counts
     static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // epilogue.h tile_epilogue_lds regions
     static constexpr int LDS = LDS_MAIN + LDS_DESC > LDS_EPI ? LDS_MAIN + LDS_DESC : LDS_EPI;
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     using X = SE<std::conditional_t<F16IN, f16_t, T>>;
     static_assert(!F16IN || (std::is_same<T, bf16_t>::value && WDMA && NP > 0), "fp16 input: an option of the bf16 patch-slot variants");
     constexpr int ES = C::ES, SS = C::SS;
+    constexpr bool ONEBUF = WDMA || C::SINGLE;     // one apron (and, register-staged, one filter) buffer: a barrier before it is rewritten
     __shared__ __attribute__((aligned(256))) char smem[C::LDS];
     char *s_w = smem + C::PB + C::LDS_H;       // filters of stage buffer 0 (pass 2) / of the WDMA ring
 
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     };
     auto store_stage = [&](int s) {
         if ((H3D_DBG(a) & 8) && s > 0) return;
-        char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
+        char *s_h = smem + C::PB + (ONEBUF ? 0 : (s & 1) * C::STAGE);
         char *s_w = s_h + C::LDS_H;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -198,6 +205,12 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             if (i < NH) {
                 const int v = i % C::VPP, pix = i / C::VPP;
                 const int iy = pix / C::HH, ix = pix - iy * C::HH;
+                if constexpr (X::SPLIT_A) {
+                    if (s < nchunks) {                              // (f16x3, phase A: operand fragments; phase B: the fp32 values the blend reads)
+                        x3_store4(s_h + iy * C::RBH + ix * C::SBH + (v >> 1) * 32, v & 1, stg[j]);
+                        continue;
+                    }
+                }
                 *reinterpret_cast<u32x4 *>(s_h + iy * C::RBH + ix * C::SBH + ((PK ? (v ^ (iy & 1)) : v) * 16)) = X::convert16(stg[j]);
             } else if (i < NH + NW) {
                 const int q0 = i - NH;
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                          : (MARGIN + py) * C::RBH + (MARGIN + px) * C::SBH + 8 * h * SS;
     [[maybe_unused]] const int bconv1 = (bconv ^ 16) + C::RBH;
     auto computeA = [&](int s) {
-        const char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
+        const char *s_h = smem + C::PB + (ONEBUF ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -279,8 +292,8 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
                 const typename X::wfrag fa = X::lds_w(s_w + aoff + (tap * CK + kk * 16) * SS);
-                const typename X::frag fb = X::lds(s_h + ((PK && dy == 1) ? bconv1 : bconv + dy * C::RBH) + dx * C::SBH + kk * 16 * SS);
-                if (H3D_DBG(a) & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, X::prep(fb));
+                const typename X::bfrag fb = X::lds_a(s_h + ((PK && dy == 1) ? bconv1 : bconv + dy * C::RBH) + dx * C::SBH + kk * 16 * SS);
+                if (H3D_DBG(a) & 1) { X::keep(fa); X::keep(fb); } else X::mma(aoffs, fa, fb);
             }
         }
     };
@@ -302,7 +315,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     issue_w(0);
     load_stage(0);
     for (int s = 0; s < nchunks; ++s) {
-        if (WDMA && s) __syncthreads();          // (single apron buffer)
+        if (ONEBUF && s) __syncthreads();        // (single apron buffer)
         store_stage(s);
         if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // the filters of stage s have landed too
         __syncthreads();
@@ -313,8 +326,13 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     }
     {   // + bias (permuted like the rows)
         const float *bo = a.bias + a.wrows;
+        if constexpr (std::is_same_v<T, x3_t>) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
+            for (int i = 0; i < 16; ++i) aoffs[i] = fmaf(aoffs[i], a.oscale, bo[(i & 3) + 8 * (i >> 2) + 4 * h]);     // (exact power-of-two unscale)
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
+        }
     }
 
     H3D_STAMP(blockIdx.x, 1);
@@ -434,6 +452,10 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         nsl2 = nsl;
         const int ps = tid / C::VPP, pv = tid - ps * C::VPP;
         phas = ps < nsl;
+        // (round 5, measured and dropped: a wave-uniform skip of patch_issue / patch_commit for the waves that own no patch unit -- at
+        //  the default offsets a tile has 20-90 far samples, i.e. only the first one to three waves do -- made the 16 launches of the
+        //  batch-64 plan 3.5 % SLOWER (2.205 vs 2.129 ms, tools/ab_lib.py): the scalar branch splits the block the four loads are
+        //  scheduled in, and the loads of an idle thread cost nothing but their issue slot)
         if (phas) {
             const u32x4 d = *reinterpret_cast<const u32x4 *>(smem + C::LDS_MAIN + ps * 16);
             const int hl = (int)d[0] >> 16, wl = (int)(short)(d[0] & 0xffffu);
@@ -513,7 +535,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][0][i] = 0.f;
     auto computeB = [&](int s) {
-        const char *s_h = smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE);
+        const char *s_h = smem + C::PB + (ONEBUF ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
         if constexpr (TAPAHEAD) {
             // one workgroup per CU = two waves per SIMD: they cannot cover the gather -> blend -> MFMA chain of a tap by
@@ -603,9 +625,9 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     } else {
     for (int s = nchunks; s < 2 * nchunks; ++s) {
         patch_issue(s);
-        if (WDMA) __syncthreads();
+        if (ONEBUF) __syncthreads();
         store_stage(s);
-        patch_commit(smem + C::PB + (WDMA ? 0 : (s & 1) * C::STAGE));
+        patch_commit(smem + C::PB + (ONEBUF ? 0 : (s & 1) * C::STAGE));
         if constexpr (WDMA) __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
         if (s + 1 < 2 * nchunks) { issue_w(s + 1); load_stage(s + 1); }
@@ -775,6 +797,12 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     }
 
     H3D_STAMP(blockIdx.x, 4);
+    if constexpr (std::is_same_v<T, x3_t>) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][0][i] *= a.wscale;
+    }
     EpiArgs e;
     e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
@@ -934,6 +962,10 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     a.tiles_x = a.tiles_y = 0;
     a.dbg = op.reserved;
     a.G = op.wrows / 32;
+    if (op.wexp < -60 || op.wexp > 60 || op.wexp2 < -60 || op.wexp2 > 60 || ((op.wexp || op.wexp2) && op.dtype != H3D_F16X3))
+        H3D_FAIL(H3D_ERR_ARG, "dcn_fused: wexp %d / %d (H3D_F16X3 filter exponents)", op.wexp, op.wexp2);
+    a.wscale = ldexpf(1.f, -op.wexp);
+    a.oscale = ldexpf(1.f, -op.wexp2);
     if (wdma && (size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
     if (op.dtype == H3D_BF16 && (op.reserved & 0x40000)) return launch_dcn3_lowp<bf16_t, true>(op, a, wdma, st);
     if (op.dtype == H3D_BF16) return launch_dcn3_lowp<bf16_t>(op, a, wdma, st);
@@ -941,15 +973,25 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     // barrier per phase-A stage): measured 5.7 % SLOWER on the ten <= 64-channel launches of the batch-64 plan (1.519 vs 1.437 ms,
     // tools/ab_dcn5.py: an LDS-DMA piece costs its wave more issue cycles than two global loads + two ds_write_b128, and the
     // kernel is bound by LDS reads and vector issue, not by the staging), so it runs only on request (tuning override 0x4000)
-    if (op.dtype == H3D_F16 && wdma && (op.reserved & 0x4000) && !(op.reserved & 0x3000)) return h3d_launch_dcn5(op, st);
+    if (op.dtype == H3D_F16 && wdma && (op.reserved & 0x4000) && !(op.reserved & 0x3000)) {
+#ifdef H3D_EXTRA
+        return h3d_launch_dcn5(op, st);
+#else
+        H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused_stream: the LDS-DMA apron variant (csrc/dcn5.hip, reserved & 0x4000) is built only by `make EXTRA=1`");
+#endif
+    }
     if (op.dtype == H3D_F16) return launch_dcn3_lowp<f16_t>(op, a, wdma, st);
     if (op.dtype == H3D_F32) {
         if (op.Cout <= 32) return launch_dcn3_cfg<float, 1, 16, 2>(a, st);
         return launch_dcn3_cfg<float, 2, 16, 2>(a, st);
     }
     if (op.dtype == H3D_F16X3) {            // the f32 plan's tiles (fp32 apron, register-staged pre-split filters) on 3 fp16 MFMAs per step
-        if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 2>(a, st);
-        return launch_dcn3_cfg<x3_t, 2, 16, 2>(a, st);
+        if (op.reserved & 0x2000) {         // tuning override (tools/ab_flag.py): the f32 plan's margin-2 double-buffered tile
+            if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 2>(a, st);
+            return launch_dcn3_cfg<x3_t, 2, 16, 2>(a, st);
+        }
+        if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 4>(a, st);      // margin 4, one stage buffer (Dcn3Cfg::SINGLE)
+        return launch_dcn3_cfg<x3_t, 2, 16, 4>(a, st);
     }
     H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused: dtype %d", op.dtype);
 }

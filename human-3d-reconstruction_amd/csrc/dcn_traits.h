@@ -28,6 +28,9 @@ template <> struct SE<float> {
     using bfrag = frag;
     static __device__ __forceinline__ wfrag lds_w(const char *p) { return lds(p); }
     static __device__ __forceinline__ bfrag prep(const frag &f) { return f; }
+    // apron fragment of the OFFSET convolution (phase A of csrc/dcn3.hip), ready for the MFMA
+    static __device__ __forceinline__ bfrag lds_a(const char *p) { return lds(p); }
+    static constexpr bool SPLIT_A = false;
     static __device__ __forceinline__ void mma(f32x16 &acc, const frag &a, const frag &b)
     {
         ET<float>::frag fa, fb;
@@ -96,6 +99,9 @@ template <> struct SE<bf16_t> {
     using bfrag = frag;
     static __device__ __forceinline__ wfrag lds_w(const char *p) { return lds(p); }
     static __device__ __forceinline__ bfrag prep(const frag &f) { return f; }
+    // apron fragment of the OFFSET convolution (phase A of csrc/dcn3.hip), ready for the MFMA
+    static __device__ __forceinline__ bfrag lds_a(const char *p) { return lds(p); }
+    static constexpr bool SPLIT_A = false;
     static __device__ __forceinline__ _Float16 cvt(uint32_t bits_hi)   // bf16 in the high half of an f32 pattern
     {
         const float x = __uint_as_float(bits_hi);
@@ -189,6 +195,53 @@ template <> struct SE<x3_t> : SE<float> {
     {
         const float x[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
         return ET<x3_t>::split8(x);
+    }
+    // phase A only multiplies the apron (no blend), so the thread that stages a phase-A chunk stores it already split (x3_store4:
+    // once per element) and the nine taps read finished operand fragments; phase B stages the same chunk again as plain fp32
+    static __device__ __forceinline__ bfrag lds_a(const char *p) { return ET<x3_t>::lds_frag(p); }
+    static constexpr bool SPLIT_A = true;
+    // blend: the mask folded into the four bilinear weights (as the 2-byte plans do), then sum_k w_k v_k on PAIRS of channels
+    // (v_pk_mul_f32 / v_pk_fma_f32: 16 packed instructions per 8-channel fragment instead of 40 scalar ones).  Differs from the
+    // reference's (w1 v1 + w2 v2 + w3 v3 + w4 v4) * mask by fp32 rounding order only.
+    struct geo { float w[4]; };
+    static __device__ __forceinline__ geo make_geo(const float (&w)[4], float mask)
+    {
+        geo g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g.w[i] = w[i] * mask;
+        return g;
+    }
+    static __device__ __forceinline__ geo zero_geo() { geo g; g.w[0] = g.w[1] = g.w[2] = g.w[3] = 0.f; return g; }
+    static __device__ __forceinline__ geo select_geo(bool keep_, const geo &g)
+    {
+        geo o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.w[i] = keep_ ? g.w[i] : 0.f;
+        return o;
+    }
+    static __device__ __forceinline__ geo shfl_xor32(const geo &g)
+    {
+        geo o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.w[i] = __uint_as_float(h3d_xor32(__float_as_uint(g.w[i])));
+        return o;
+    }
+    static __device__ __forceinline__ frag blend(const frag (&v)[4], const geo &g)
+    {
+        frag o;
+        const f32x2 w0 = {g.w[0], g.w[0]}, w1 = {g.w[1], g.w[1]}, w2 = {g.w[2], g.w[2]}, w3 = {g.w[3], g.w[3]};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f32x2 a0 = {v[0].lo[2 * e], v[0].lo[2 * e + 1]}, a1 = {v[1].lo[2 * e], v[1].lo[2 * e + 1]};
+            const f32x2 a2 = {v[2].lo[2 * e], v[2].lo[2 * e + 1]}, a3 = {v[3].lo[2 * e], v[3].lo[2 * e + 1]};
+            const f32x2 x = __builtin_elementwise_fma(a3, w3, __builtin_elementwise_fma(a2, w2, __builtin_elementwise_fma(a1, w1, a0 * w0)));
+            o.lo[2 * e] = x[0]; o.lo[2 * e + 1] = x[1];
+            const f32x2 b0 = {v[0].hi[2 * e], v[0].hi[2 * e + 1]}, b1 = {v[1].hi[2 * e], v[1].hi[2 * e + 1]};
+            const f32x2 b2 = {v[2].hi[2 * e], v[2].hi[2 * e + 1]}, b3 = {v[3].hi[2 * e], v[3].hi[2 * e + 1]};
+            const f32x2 y = __builtin_elementwise_fma(b3, w3, __builtin_elementwise_fma(b2, w2, __builtin_elementwise_fma(b1, w1, b0 * w0)));
+            o.hi[2 * e] = y[0]; o.hi[2 * e + 1] = y[1];
+        }
+        return o;
     }
     using SE<float>::keep;
     static __device__ __forceinline__ void keep(const wfrag &f) { asm volatile("" ::"v"(f.hi), "v"(f.lo)); }

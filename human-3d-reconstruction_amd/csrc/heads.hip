@@ -45,6 +45,8 @@ struct HeadsArgs {
     int tiles_x, tiles_y;
     int dbg;   // profiling ablation (h3d_op.reserved): 1 = skip the weight loads after the prologue
     int xcd;   // h3d_tile_id mode
+    float s1;                // f16x3 plans: 2^-wexp of the 3x3 filters AND of b1 (h3d_heads_desc.wexp); 1 otherwise
+    float s2[HEADS_MAX];     // ... 2^-wexp2 of a head's 1x1 filters
     unsigned long long *stamps;   // profiling builds: per workgroup {kernel start, end, cycles wave 0 spent in the stage barriers, in gemm2, waiting for its own DMA pieces}
 };
 
@@ -107,7 +109,7 @@ __device__ __forceinline__ void heads_issue_bias(const float *b1, int hc, const 
 // with the MFMA pipe idle.
 template <typename T, int TH, int NT, int M2, bool BIASC>
 __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][NT], const char *s_b1 /* LDS: this slab's 64 b1 */,
-                                      const char *s_w2, int r, int h, int sw)
+                                      const char *s_w2, int r, int h, int sw, float s1 = 1.f)
 {
     using C = HeadsCfg<T, TH>;
     using E = ET<T>;
@@ -143,7 +145,10 @@ __device__ __forceinline__ void gemm2(f32x16 (&acc)[2][NT], f32x16 (&acc2)[M2][N
 #pragma unroll
                         for (int j = 0; j < 8; ++j) x[j] = fmaxf(x[j], 0.f);
                     }
-                    if constexpr (std::is_same_v<T, x3_t>) {        // f16x3: the fp32 slab values split into (hi | lo) fp16 terms
+                    if constexpr (std::is_same_v<T, x3_t>) {
+                        // f16x3: the fp32 slab values, unscaled (the 3x3 filters and b1 were packed times 2^wexp), split into (hi | lo) fp16 terms
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] *= s1;
                         fb[n] = E::split8(x);
                     } else {
                         fb[n].lo = f32x4{x[0], x[1], x[2], x[3]};
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
 #ifdef H3D_ABLATE
             const unsigned long long tg0 = __builtin_readcyclecounter();
 #endif
-            gemm2<T, TH, NT, M2H, BIASC>(acc, acc2, s_b + slab * HC_SLAB * 4, s_w2, r, h, sw);
+            gemm2<T, TH, NT, M2H, BIASC>(acc, acc2, s_b + slab * HC_SLAB * 4, s_w2, r, h, sw, a.s1);
 #ifdef H3D_ABLATE
             t_g2 += __builtin_readcyclecounter() - tg0;
 #endif
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
         const int C_head = a.C[head];
         float *out = a.out[head];
         const size_t cstride = (size_t)a.H * a.W;
+        [[maybe_unused]] const float s2 = a.s2[head];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int oy = oy0 + wv * NT + n, ox = ox0 + r;
@@ -474,7 +480,10 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                         const f32x4 b2v = *reinterpret_cast<const f32x4 *>(s_b + 1024 + c * 4);
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (c + i < C_head) p[i * cstride] = acc2[m2][n][4 * g + i] + b2v[i];
+                            if (c + i < C_head) {
+                                if constexpr (std::is_same_v<T, x3_t>) p[i * cstride] = fmaf(acc2[m2][n][4 * g + i], s2, b2v[i]);
+                                else p[i * cstride] = acc2[m2][n][4 * g + i] + b2v[i];
+                            }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -535,7 +544,12 @@ int h3d_launch_heads(const h3d_op &op, hipStream_t st)
         if (d->head[i].C <= 0 || d->head[i].C > 32 * HC_MT2)
             H3D_FAIL(H3D_ERR_UNSUPPORTED, "heads: head %d has %d channels (max %d)", i, d->head[i].C, 32 * HC_MT2);
         a.w2[i] = (const char *)d->head[i].w2; a.b2[i] = d->head[i].b2; a.out[i] = d->head[i].out; a.C[i] = d->head[i].C;
+        if (d->head[i].wexp2 < -60 || d->head[i].wexp2 > 60 || (d->head[i].wexp2 && op.dtype != H3D_F16X3))
+            H3D_FAIL(H3D_ERR_ARG, "heads: head %d wexp2 %d (an H3D_F16X3 filter exponent)", i, d->head[i].wexp2);
+        a.s2[i] = ldexpf(1.f, -d->head[i].wexp2);
     }
+    if (d->wexp < -60 || d->wexp > 60 || (d->wexp && op.dtype != H3D_F16X3)) H3D_FAIL(H3D_ERR_ARG, "heads: wexp %d (an H3D_F16X3 filter exponent)", d->wexp);
+    a.s1 = ldexpf(1.f, -d->wexp);
     int m2 = 1, m2min = HC_MT2;
     for (int i = 0; i < d->nheads; ++i) {
         m2 = max(m2, (d->head[i].C + 31) / 32);   // row tiles of the widest head

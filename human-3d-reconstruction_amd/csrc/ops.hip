@@ -45,6 +45,17 @@ int h3d_xcd_mode()
 
 extern "C" const char *h3d_last_error(void) { return g_err; }
 extern "C" int h3d_abi_version(void) { return H3D_ABI_VERSION; }
+extern "C" int h3d_build_flags(void)
+{
+    int f = 0;
+#ifdef H3D_EXTRA
+    f |= H3D_BUILD_EXTRA;
+#endif
+#ifdef H3D_ABLATE
+    f |= H3D_BUILD_ABLATE;
+#endif
+    return f;
+}
 
 int h3d_launch_conv(const h3d_op &op, hipStream_t st);
 int h3d_launch_stem(const h3d_op &op, hipStream_t st);
@@ -118,11 +129,19 @@ static int run_one(const h3d_op &op, int i, hipStream_t st)
     case H3D_OP_CONV: rc = h3d_launch_conv(op, st); break;
     case H3D_OP_CONV_STREAM: rc = h3d_launch_conv_stream(op, st); break;
     case H3D_OP_DCN: rc = h3d_launch_dcn2(op, st); break;
+#ifdef H3D_EXTRA
     case H3D_OP_DCN_V1: rc = h3d_launch_dcn(op, st); break;
-    case H3D_OP_DCN_FUSED:
-    case H3D_OP_DCN_FUSED_STREAM: rc = h3d_launch_dcn3(op, st); break;
     case H3D_OP_DCN_FUSED_F16: rc = h3d_launch_dcn4(op, st); break;
     case H3D_OP_UPDCN_F16: rc = h3d_launch_updcn(op, st); break;
+#else
+    case H3D_OP_DCN_V1:
+    case H3D_OP_DCN_FUSED_F16:
+    case H3D_OP_UPDCN_F16:
+        h3d_set_error("op %d (kind %d): a superseded kernel generation, built only by `make EXTRA=1` (csrc/Makefile)", i, op.kind);
+        return H3D_ERR_UNSUPPORTED;
+#endif
+    case H3D_OP_DCN_FUSED:
+    case H3D_OP_DCN_FUSED_STREAM: rc = h3d_launch_dcn3(op, st); break;
     case H3D_OP_HEADS: rc = h3d_launch_heads(op, st); break;
     case H3D_OP_MAXPOOL:
     case H3D_OP_UPADD:

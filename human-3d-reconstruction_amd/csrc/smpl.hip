@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void smpl_verts_kernel(const float *__restrict
     }
 }
 
+#ifdef H3D_EXTRA      // generation 2 (vector FMA, operands streamed through LDS): superseded by generation 3, kept as an A/B reference
 // ------------------------------------------------------------------------------------------------
 // Generation 2 of the vertex kernel (gen 1 above was latency-bound on per-lane L2 loads: 42 TFLOP/s).
 // Workgroup = 64 vertices x 128 persons: lane = vertex, wave w = persons [32w, 32w+32).  The
@@ -439,11 +440,17 @@ __global__ __launch_bounds__(256) void smpl_verts2_kernel(const float *__restric
         }
     }
 }
+#endif
 
 extern "C" int h3d_smpl_verts2(const float *coefT, const float *A, const float *v_template, const float *shapedirsT,
                                const float *posedirsT, const int32_t *lbs_idx, const float *lbs_w, int nnz, int P, int Ppad,
                                int V, int Vpad, float *verts, void *stream)
 {
+#ifndef H3D_EXTRA
+    (void)coefT; (void)A; (void)v_template; (void)shapedirsT; (void)posedirsT; (void)lbs_idx; (void)lbs_w; (void)nnz; (void)P; (void)Ppad; (void)V; (void)Vpad;
+    (void)verts; (void)stream;
+    H3D_FAIL(H3D_ERR_UNSUPPORTED, "smpl_verts2: the generation-2 vertex kernel is built only by `make EXTRA=1` (generation 3, h3d_smpl_verts3, is the product path)");
+#else
     if (!coefT || !A || !v_template || !shapedirsT || !posedirsT || !lbs_idx || !lbs_w || !verts)
         H3D_FAIL(H3D_ERR_ARG, "smpl_verts2: null pointer");
     if (P <= 0 || V <= 0 || nnz <= 0 || nnz > 4 || Ppad % SV_PB || Ppad < P || Vpad % SV_VT || Vpad < V)
@@ -454,6 +461,7 @@ extern "C" int h3d_smpl_verts2(const float *coefT, const float *A, const float *
                        lbs_idx, lbs_w, nnz, P, Ppad, V, Vpad, verts);
     H3D_CHECK_LAUNCH("smpl_verts2_kernel");
     return H3D_OK;
+#endif
 }
 
 extern "C" int h3d_smpl_verts(const float *betas, const float *pose_feat, const float *A, const float *v_template,

@@ -34,6 +34,17 @@ def _t(v):
     return v.detach().float().cpu() if torch.is_tensor(v) else torch.from_numpy(np.asarray(v)).float()
 
 
+def x3_exp(w):
+    """Exponent e of the power-of-two pre-scale of an "f16x3" filter bank: 2^e * max|w| lands in [2^13, 2^14), so the fp16 hi terms stay
+    far below 65504 and the lo terms (~2^-12 of the value) of every filter above 2^-16 of the largest are NORMAL fp16 numbers -- an
+    unscaled 0.05 has a subnormal lo term (3e-8 absolute = 2^-20.7 relative, five times the 2^-23 of the split itself).  The kernels
+    multiply their accumulators by 2^-e, which is exact (h3d_op.wexp)."""
+    m = float(w.abs().max())
+    if not (m > 0.0) or not np.isfinite(m):
+        return 0
+    return int(max(-60, min(60, 13 - int(np.floor(np.log2(m))))))
+
+
 def x3_split(w):
     """fp32 filters [..., K] (K % 8 == 0: the contraction index, 8 consecutive elements = one MFMA fragment of a lane) -> the
     operand format of the "f16x3" plans (csrc/common.h ET<x3_t>): per group of 8 elements the 8 fp16 high terms hi = fp16(x)
@@ -80,6 +91,7 @@ class PackedWeights:
         if missing:
             raise KeyError("state_dict is missing %d keys, e.g. %s" % (len(missing), missing[:3]))
         self.t = {}
+        self.wexp = {}              # f16x3: device pointer of a packed filter bank -> its power-of-two pre-scale exponent (x3_exp; h3d_op.wexp)
         self.dcn_variant = {}       # DeformConv layer (state_dict prefix) -> csrc/dcn3.hip variant bits (DLAEngine.calibrate_dcn_margins)
         if arch_name == "resdcn101":
             # the DCN of up-sampling stage i is `deconv_layers.{6i}` (weight, bias, conv_offset_mask.*) followed by the
@@ -103,6 +115,7 @@ class PackedWeights:
         self.head_conv, self.arch = 0, "bare"
         self.sd = {k: _t(v) for k, v in tensors.items()}
         self.t = {}
+        self.wexp = {}
         self.dcn_variant = {}
         return self
 
@@ -136,9 +149,11 @@ class PackedWeights:
             bp = torch.zeros(rows)
             bp[:co] = b
             td = torch.float16 if (as_half and self.dtype in LOWP) else _TORCH_DT[self.dtype]
-            wp = x3_split(wp) if self.dtype == "f16x3" else wp.to(td)
+            e = x3_exp(wp) if self.dtype == "f16x3" else 0
+            wp = x3_split(wp * 2.0 ** e) if self.dtype == "f16x3" else wp.to(td)
             self.t[key] = (wp.contiguous().to(self.device),
                            bp.contiguous().to(self.device), cout, ci, kh, rows)
+            self.wexp[self.t[key][0].data_ptr()] = e
         return self.t[key]
 
     def conv_stream(self, wkey, bkey=None, bn=None):
@@ -259,7 +274,9 @@ class PackedWeights:
                     wp[row] = w[ch].permute(1, 2, 0).reshape(9, ci)
                     bp[row] = b[ch]
             td = torch.float16 if self.dtype in LOWP else torch.float32
-            self.t[key] = ((x3_split(wp) if self.dtype == "f16x3" else wp.to(td)).contiguous().to(self.device), bp)
+            e = x3_exp(wp) if self.dtype == "f16x3" else 0
+            self.t[key] = ((x3_split(wp * 2.0 ** e) if self.dtype == "f16x3" else wp.to(td)).contiguous().to(self.device), bp)
+            self.wexp[self.t[key][0].data_ptr()] = e
         return self.t[key]
 
     def fused_heads(self, names=None):
@@ -284,10 +301,14 @@ class PackedWeights:
                 w2[:c] = self.sd[head + ".2.weight"].reshape(c, hc)[:, perm]
                 b2 = torch.zeros(96)
                 b2[:c] = self.sd[head + ".2.bias"]
-                per.append((head, c, (x3_split(w2) if self.dtype == "f16x3" else w2.to(td)).contiguous().to(self.device), b2.to(self.device)))
+                e2 = x3_exp(w2) if self.dtype == "f16x3" else 0
+                per.append((head, c, (x3_split(w2 * 2.0 ** e2) if self.dtype == "f16x3" else w2.to(td)).contiguous().to(self.device), b2.to(self.device)))
+                self.wexp[per[-1][2].data_ptr()] = e2
             w1 = torch.cat(w1)
-            self.t[key] = ((x3_split(w1) if self.dtype == "f16x3" else w1.to(td)).contiguous().to(self.device),
-                           torch.cat(b1).float().contiguous().to(self.device), per)
+            e1 = x3_exp(w1) if self.dtype == "f16x3" else 0          # (one exponent for the launch's 3x3 bank; its biases are scaled with it)
+            self.t[key] = ((x3_split(w1 * 2.0 ** e1) if self.dtype == "f16x3" else w1.to(td)).contiguous().to(self.device),
+                           (torch.cat(b1).float() * 2.0 ** e1).contiguous().to(self.device), per)
+            self.wexp[self.t[key][0].data_ptr()] = e1
         return self.t[key]
 
     def nearest_up_key(self, c):
@@ -458,7 +479,7 @@ class Plan:
         self._op(_lib.OP_CONV, in_=x.ptr, in2=res.ptr if res is not None else None, w=wp.data_ptr(),
                  bias=bp.data_ptr(), out=optr, H=x.H, W=x.W, Cin=cin, in_cs=x.cs,
                  in2_cs=res.cs if res is not None else 0, Ho=Ho, Wo=Wo, Cout=cout, out_cs=ocs, ksize=k,
-                 stride=stride, relu=int(relu), out_mode=out_mode, wrows=rows, reserved=tune)
+                 stride=stride, relu=int(relu), out_mode=out_mode, wrows=rows, reserved=tune, wexp=self.pw.wexp.get(wp.data_ptr(), 0))
         return out
 
     def _conv_stream(self, x, wkey, out, bkey, bn, relu, res, stride=1):
@@ -601,7 +622,7 @@ class Plan:
                 out = self._alloc(x.H, x.W, cout)
             self._op(_lib.OP_DCN_FUSED, in_=x.ptr, in2=wo.data_ptr(), w=wp.data_ptr(), bias=bias.data_ptr(), out=out.ptr,
                      H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3, stride=1,
-                     relu=1, out_mode=_lib.OUT_NHWC, wrows=rows)
+                     relu=1, out_mode=_lib.OUT_NHWC, wrows=rows, wexp=self.pw.wexp.get(wp.data_ptr(), 0), wexp2=self.pw.wexp.get(wo.data_ptr(), 0))
             return out
         if self.pw.use_dcn:
             if self.pw.dtype == "f16":
@@ -695,10 +716,12 @@ class Plan:
                 w1, b1, per = self.pw.fused_heads(tuple(groups[m2]))
                 desc = _lib.H3dHeadsDesc()
                 desc.nheads = len(per)
+                desc.wexp = self.pw.wexp.get(w1.data_ptr(), 0)
                 for i, (head, c, w2, b2) in enumerate(per):
                     o = torch.empty(B, c, Ho, Wo, dtype=torch.float32, device=self.pw.device)
                     self.outputs[head] = o
                     desc.head[i].w2, desc.head[i].b2, desc.head[i].out, desc.head[i].C = w2.data_ptr(), b2.data_ptr(), o.data_ptr(), c
+                    desc.head[i].wexp2 = self.pw.wexp.get(w2.data_ptr(), 0)
                 self.keep.append(desc)
                 self._op(_lib.OP_HEADS, in_=feat.ptr, in2=ctypes.addressof(desc), w=w1.data_ptr(), bias=b1.data_ptr(),
                          H=Ho, W=Wo, Cin=feat.C, in_cs=feat.cs, Ho=Ho, Wo=Wo, Cout=self.pw.head_conv, ksize=3, stride=1)

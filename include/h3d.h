@@ -43,7 +43,13 @@ extern "C" {
 const char *h3d_last_error(void);
 /* ABI version of this header; the loader checks it. */
 int h3d_abi_version(void);
-#define H3D_ABI_VERSION 1
+#define H3D_ABI_VERSION 2
+/* How this library was built: H3D_BUILD_EXTRA = `make EXTRA=1` (the superseded kernel generations kept as A/B references are in:
+ * H3D_OP_DCN_V1, H3D_OP_DCN_FUSED_F16, H3D_OP_UPDCN_F16, the 0x4000 DeformConv variant, h3d_smpl_verts2 -- without it they return
+ * H3D_ERR_UNSUPPORTED); H3D_BUILD_ABLATE = `make ABLATE=1` (profiling switches and in-kernel stamps compiled in). */
+#define H3D_BUILD_EXTRA 1
+#define H3D_BUILD_ABLATE 2
+int h3d_build_flags(void);
 
 /* =====================================================================================
  * 1. Operator boundary: replaces pybind module `_ext` (DCNv2/src/vision.cpp:4-9), function
@@ -170,13 +176,13 @@ enum {
 #define H3D_HEADS_MAX 16
 typedef struct h3d_heads_desc {
     int32_t nheads;
-    int32_t reserved;
+    int32_t wexp;       /* H3D_F16X3: op.w holds 2^wexp times the 3x3 filters AND op.bias 2^wexp times their biases (h3d_op.wexp) */
     struct {
         const void *w2;
         const float *b2;
         float *out;
         int32_t C;
-        int32_t pad;
+        int32_t wexp2;  /* H3D_F16X3: w2 holds 2^wexp2 times the 1x1 filters (b2 is unscaled) */
     } head[H3D_HEADS_MAX];
 } h3d_heads_desc;
 /* H3D_OP_UPDCN_F16: the operands that do not fit h3d_op */
@@ -211,6 +217,11 @@ typedef struct h3d_op {
     int32_t reserved;   /* 0 in production.  Profiling only: a per-kind tuning override (CONV_STREAM: MT << 8 | WAVES;
                            UPADD: 1 = tap table from global memory, 2 = from LDS) and, in `make ABLATE=1` builds,
                            ablation switches in the high bits (tools/ab_*.py)                              */
+    int32_t wexp;       /* H3D_F16X3 plans (ABI 2): the packed filters hold 2^wexp times the layer's filters -- chosen by the packer so
+                           that max |w| lands in [2^13, 2^14) and the lo terms of all but vanishing filters are NORMAL fp16 numbers
+                           (an unscaled 0.05 has a subnormal lo term: 3e-8 absolute, 2^-20.7 relative, five times the 2^-23 of the
+                           split itself) -- and the kernel multiplies its accumulators by 2^-wexp (exact) before the bias.  0 elsewhere */
+    int32_t wexp2;      /* ... the same for the offset / mask filters of H3D_OP_DCN_FUSED (in2)                */
 } h3d_op;
 
 /* channels per filter stage H3D_OP_DCN_FUSED_STREAM expects for a layer (16) */

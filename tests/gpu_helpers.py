@@ -12,6 +12,8 @@ TD = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16, "f16x3
 HD = {"f32": _lib.H3D_F32, "bf16": _lib.H3D_BF16, "f16": _lib.H3D_F16, "f16x3": _lib.H3D_F16X3}
 TN = {"f32": "float", "bf16": "unsigned short", "f16": "f16_t", "f16x3": "x3_t"}      # element-type names inside the kernel symbols
 DEV = "cuda:0"
+WEXP = {}     # f16x3: device pointer of a packed filter bank -> its pre-scale exponent (h3d_op.wexp)
+KEEP = []     # ... the banks themselves (a freed bank's address could be handed out again with another exponent)
 
 
 def pack_conv(w, b, dtype, pad_cout_to=None):
@@ -23,9 +25,13 @@ def pack_conv(w, b, dtype, pad_cout_to=None):
     bp = torch.zeros(rows)
     if b is not None:
         bp[:co] = b
-    if dtype == "f16x3":          # fp32 filters as (hi | lo) fp16 terms per 8 input channels (engine.x3_split)
+    if dtype == "f16x3":          # fp32 filters times 2^wexp as (hi | lo) fp16 terms per 8 input channels (engine.x3_split / x3_exp)
         from h3d_amd import engine
-        return engine.x3_split(wp).contiguous().to(DEV), bp.to(DEV), cout, rows
+        e = engine.x3_exp(wp)
+        t = engine.x3_split(wp * 2.0 ** e).contiguous().to(DEV)
+        WEXP[t.data_ptr()] = e
+        KEEP.append(t)
+        return t, bp.to(DEV), cout, rows
     return wp.to(TD[dtype]).contiguous().to(DEV), bp.to(DEV), cout, rows
 
 
@@ -87,7 +93,7 @@ def conv(x, w, b, dtype, stride=1, relu=False, res=None, out_mode=_lib.OUT_NHWC,
         optr = out.data_ptr()
     op = mk(_lib.OP_CONV, dtype, in_=xptr, in2=rptr, w=wp.data_ptr(), bias=bp.data_ptr(), out=optr, B=B, H=H, W=W,
             Cin=Ci, in_cs=Ci + in_pad, in2_cs=rcs, Ho=Ho, Wo=Wo, Cout=cout, out_cs=ocs, ksize=k, stride=stride,
-            relu=int(relu), out_mode=out_mode, wrows=rows, reserved=reserved)
+            relu=int(relu), out_mode=out_mode, wrows=rows, reserved=reserved, wexp=WEXP.get(wp.data_ptr(), 0))
     if name_only:
         return kernel_name(op)
     run(op)
@@ -235,7 +241,7 @@ def dcn_fused_op(kind, x, w, b, wo, bo, dtype="bf16", reserved=0, skip=None, w_u
     out = torch.zeros(B, Ho, Wo, cout, dtype=TD[dtype], device=DEV)
     op = mk(opk, dtype, in_=xptr, in2=in2, w=wptr, bias=bias.data_ptr(), out=out.data_ptr(), B=B, H=H, W=W, Cin=Ci, in_cs=Ci,
             Ho=Ho, Wo=Wo, Cout=cout, out_cs=cout, ksize=3, stride=stride, relu=1, out_mode=_lib.OUT_NHWC, wrows=rows,
-            reserved=reserved)
+            reserved=reserved, wexp=pw.wexp.get(wptr, 0), wexp2=pw.wexp.get(in2, 0) if isinstance(in2, int) else 0)
     return Built(op, keep, lambda: from_nhwc(out, cout))
 
 

@@ -33,8 +33,8 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_op_struct_matches_header_layout():
-    # 2 int32, 5 pointers, 16 int32 -> 8 + 40 + 64 = 112 bytes on LP64
-    assert ctypes.sizeof(_lib.H3dOp) == 112
+    # 2 int32, 5 pointers, 18 int32 (ABI 2: + wexp, wexp2) -> 8 + 40 + 72 = 120 bytes on LP64
+    assert ctypes.sizeof(_lib.H3dOp) == 120 and _lib.H3dOp.wexp.offset == 112
     assert _lib.H3dOp.in_.offset == 8 and _lib.H3dOp.B.offset == 48
 
 

@@ -17,7 +17,7 @@ def model():
     return smpl.SMPLModel.synthetic(seed=0)
 
 
-@pytest.mark.parametrize("kernel,P", [("gen1", 19), ("gen2", 19), ("gen2", 150), ("gen1", 70), ("gen3", 19), ("gen3", 150), ("gen3", 300),
+@pytest.mark.parametrize("kernel,P", [("gen1", 19), pytest.param("gen2", 19, marks=pytest.mark.extra), pytest.param("gen2", 150, marks=pytest.mark.extra), ("gen1", 70), ("gen3", 19), ("gen3", 150), ("gen3", 300),
                                       ("gen3x", 19), ("gen3x", 300)])
 def test_lbs_matches_fp64_oracle(model, kernel, P):
     betas = synth.normalish("betas", (P, 10), 0.0, 1.0, 1)
@@ -61,7 +61,7 @@ def test_matrix_core_kernel_agrees_with_vector_kernel(model):
     betas = torch.from_numpy(synth.normalish("b", (P, 10), 0, 1, 5)).to(DEV)
     thetas = torch.from_numpy(synth.normalish("t", (P, 72), 0, 0.3, 5)).to(DEV)
     v3 = smpl.lbs(model, betas, thetas, kernel="gen3")
-    v2 = smpl.lbs(model, betas, thetas, kernel="gen2")
+    v2 = smpl.lbs(model, betas, thetas, kernel="gen1")          # the fp32 vector kernel (generation 2, the same arithmetic, is an EXTRA=1 build option)
     assert float((v3 - v2).abs().max()) < 1.5e-5
     # gen 3x (h3d_smpl_verts3_exact: all six products, 2^-24 relative -- ADVICE r2: the variant used to exist only behind a
     # compile-time switch no test built; the f32 parity-mode detectors run it) agrees with the fp32 vector kernel to 2e-6,

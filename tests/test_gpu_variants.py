@@ -199,6 +199,16 @@ DCN_CASES = [
 ]
 
 
+def _is_extra(case):
+    """Cases of the superseded generations (csrc/dcn4.hip: kinds f16 / updcn*; csrc/dcn5.hip: fp16 stream cases with 0x4000): `make EXTRA=1`."""
+    return case[0] in ("f16", "updcn2", "updcn4") or (case[0] == "stream" and case[1] == "f16" and bool(case[2] & 0x4000))
+
+
+def _active_dcn_cases():
+    from conftest import has_extra
+    return [c for c in DCN_CASES if has_extra() or not _is_extra(c)]
+
+
 def _dcn_built(case):
     kind, dtype, ov, B, Ci, Co, H, W, oscale = case
     x = rnd("x", (B, Ci, H, W))
@@ -224,7 +234,11 @@ def _dcn_built(case):
     return xin, w, b, wo, bo, built
 
 
-@pytest.mark.parametrize("case", DCN_CASES, ids=lambda c: "%s-%s-%#x-%dx%d-%dx%d-o%g-b%d" % (c[0], c[1], c[2], c[4], c[5], c[6], c[7], c[8], c[3]))
+def _dcn_id(c):
+    return "%s-%s-%#x-%dx%d-%dx%d-o%g-b%d" % (c[0], c[1], c[2], c[4], c[5], c[6], c[7], c[8], c[3])
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, marks=pytest.mark.extra, id=_dcn_id(c)) if _is_extra(c) else pytest.param(c, id=_dcn_id(c)) for c in DCN_CASES])
 def test_dcn_fused_variant_matches_oracle(case):
     kind, dtype = case[0], case[1]
     xin, w, b, wo, bo, built = _dcn_built(case)
@@ -242,7 +256,7 @@ def test_dcn_fused_variant_matches_oracle(case):
     assert torch.equal(got, built.run()), built.name
 
 
-@pytest.mark.parametrize("dtype,ov", [("bf16", 0), ("f16", 0), ("f16", 0x4000), ("bf16", 0x8000), ("bf16", 0x10000)])
+@pytest.mark.parametrize("dtype,ov", [("bf16", 0), ("f16", 0), pytest.param("f16", 0x4000, marks=pytest.mark.extra), ("bf16", 0x8000), ("bf16", 0x10000)])
 def test_dcn_tiles_with_more_far_samples_than_patch_slots_are_deterministic(dtype, ov):
     # A tile with more than NP samples outside its apron sends the surplus through pass 2 (another accumulation order).  Round 2
     # handed out the slots with an LDS atomic per wave, so WHICH samples were the surplus depended on the order the waves arrived
@@ -303,11 +317,17 @@ def test_dcn_wide_margin_variant_is_bit_identical_while_no_tile_overflows():
 
 
 def test_dcn_f16_stream_dispatch():
-    names = {c: _dcn_built(c)[5].name for c in DCN_CASES if c[0] == "stream" and c[1] == "f16"}
+    from conftest import has_extra
+    names = {c: _dcn_built(c)[5].name for c in _active_dcn_cases() if c[0] == "stream" and c[1] == "f16"}
     for c, n in names.items():
         assert n.startswith("dcn5_kernel<" if c[2] & 0x4000 else "dcn3_kernel<f16_t"), (c, n)
         assert n.endswith(", true>") == bool(c[2] & 0x18000 and not c[2] & 0x400), (c, n)
-    assert {"dcn5_kernel<2, 2, 2, 256>", "dcn5_kernel<1, 2, 1, 256>", "dcn5_kernel<4, 4, 2, 256>"} <= set(names.values()), names
+    if has_extra():
+        assert {"dcn5_kernel<2, 2, 2, 256>", "dcn5_kernel<1, 2, 1, 256>", "dcn5_kernel<4, 4, 2, 256>"} <= set(names.values()), names
+    else:       # the default library answers the 0x4000 request with a clear error instead of another kernel
+        c = [c for c in DCN_CASES if c[0] == "stream" and c[1] == "f16" and c[2] & 0x4000][0]
+        with pytest.raises(RuntimeError, match="EXTRA=1"):
+            _dcn_built(c)[5].name
 
 
 def test_dcn_auto_selection_reaches_mt4():
@@ -339,7 +359,7 @@ def test_bench_plan_kernels_are_all_covered():
     compared at full size in test_gpu_fullsize.py."""
     import test_gpu_conv
     from gpu_helpers import conv as _  # noqa: F401
-    tested = {_conv2_built(c)[4].name for c in CONV2_CASES} | {_dcn_built(c)[5].name for c in DCN_CASES}
+    tested = {_conv2_built(c)[4].name for c in CONV2_CASES} | {_dcn_built(c)[5].name for c in _active_dcn_cases()}
     tested |= test_gpu_conv.conv_case_kernel_names("bf16") | test_gpu_conv.gemm1_case_kernel_names()
     single = ("stem3_kernel", "heads_kernel<", "maxpool_kernel<", "upadd_kernel<", "copy_kernel<")
     for batch in (64, 32, 16, 8):   # 16 / 8: the shards one GPU of four / eight gets from the headline batch (bench.py --global-batch 64)
