@@ -679,6 +679,18 @@ def parity_mode(args, size, images, keep, dev, dtype="f32", steps=3, nslot=1):
            "steps_in_flight": nslot, "batch": int(images.shape[0]),
            "step_frac_of_%s_peak" % ("f32_mfma" if dtype == "f32" else "f16x3"): round(gflop * images.shape[0] * steps / dt / 1e3 / PEAK_MFMA_TFLOPS[dtype], 4),
            "index_match": m}
+    # the metric's third clause end to end: meshes against the CPU path's (the fp32 oracle's pose / shape maps read at the GPU's own
+    # centre indices -> oracle/smpl.py in fp64); the north_star's tolerance is 1e-4 abs
+    try:
+        from oracle import smpl as osmpl
+        n = res["verts"].shape[1]
+        inds = res["inds"].cpu().numpy()[:, :n]
+        th = np.concatenate([keep["heads"]["pose"][i].reshape(72, -1)[:, inds[i]].T for i in range(inds.shape[0])])
+        be = np.concatenate([keep["heads"]["shape"][i].reshape(10, -1)[:, inds[i]].T for i in range(inds.shape[0])])
+        v_ref, _ = osmpl.lbs(be, th, det32.smpl_model.numpy_dict())
+        out["verts_max_abs_err_vs_oracle"] = float(np.abs(res["verts"].cpu().numpy().reshape(-1, v_ref.shape[1], 3) - v_ref).max())
+    except Exception as e:
+        out["verts_max_abs_err_vs_oracle"] = "%s: %s" % (type(e).__name__, e)
     if dtype == "f32":
         keep["verts_f32"] = res["verts"].clone()
         keep["inds_f32"] = res["inds"].clone()

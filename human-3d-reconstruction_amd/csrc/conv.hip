@@ -324,6 +324,9 @@ template <> int launch_conv_t<x3_t>(const h3d_op &op, const ConvArgs &a, hipStre
         return launch_conv_cfg<x3_t, 3, 2, 2, 16, 8>(a, st);
     }
     if (op.ksize == 1 && op.stride == 1) {
+        // 64-channel chunks where the layer allows (Root convs over a concat: 128 ... 1280 input channels): a 16-channel chunk of a
+        // 1x1 conv is two barriers and a global round trip for 2 * MT * NT * 3 MFMAs per wave (0x2000: tuning override, 16-channel chunks)
+        if (op.Cin % 64 == 0 && co > 32 && !(op.reserved & 0x2000)) return launch_conv_cfg<x3_t, 1, 1, 2, 64, 8>(a, st);      // (8-row tiles: 52 KB of LDS, three workgroups per CU)
         if (co <= 32) return launch_conv_cfg<x3_t, 1, 1, 1, 16, 16>(a, st);
         return launch_conv_cfg<x3_t, 1, 1, 2, 16, 16>(a, st);
     }

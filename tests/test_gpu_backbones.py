@@ -108,8 +108,9 @@ def _hg(dtype):
     return m.to(DEV).eval(), sd
 
 
-def test_hourglass_f32_matches_oracle():
-    m, sd = _hg("f32")
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])      # f16x3: the fp32 contract on split-operand fp16 MFMAs (every backbone: same kernels)
+def test_hourglass_f32_matches_oracle(dtype):
+    m, sd = _hg(dtype)
     xs = synth.synth_images(1, 128, 256, seed=5)
     outs = m(torch.from_numpy(xs).to(DEV))
     with torch.no_grad():
@@ -156,9 +157,10 @@ def _res(dtype):
     return m.to(DEV).eval(), sd
 
 
-def test_resdcn_f32_matches_oracle():
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_resdcn_f32_matches_oracle(dtype):
     from oracle import resdcn as ores
-    m, sd = _res("f32")
+    m, sd = _res(dtype)
     xs = synth.synth_images(1, 128, 160, seed=5)
     out = m(torch.from_numpy(xs).to(DEV))[0]
     with torch.no_grad():
