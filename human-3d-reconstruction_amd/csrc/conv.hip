@@ -303,7 +303,6 @@ template <> int launch_conv_t<float>(const h3d_op &op, const ConvArgs &a, hipStr
 template <> int launch_conv_t<x3_t>(const h3d_op &op, const ConvArgs &a, hipStream_t st)
 {
     const int co = op.Cout;
-    auto nblk = [&](int th, int bn) { return (long)op.B * cdiv(op.Wo, 16) * cdiv(op.Ho, th) * cdiv(co, bn); };
     if (op.ksize == 3 && op.stride == 1) {
         if (op.reserved & 0x1000) {
             switch (op.reserved & 0xfff) {
@@ -315,8 +314,10 @@ template <> int launch_conv_t<x3_t>(const h3d_op &op, const ConvArgs &a, hipStre
             default: H3D_FAIL(H3D_ERR_ARG, "conv (f16x3): unknown tuning override %#x", op.reserved);
             }
         }
+        // (tools/ab_conv_x3.py, batch 64, same process: 64 -> 64 @128x128 1.170 ms on 4-wave tiles vs 0.985 on 8-wave ones; 512 -> 512
+        //  @16x16 0.639 on 64-channel tiles vs 0.566 on 128-channel ones although that grid is half a round of workgroups)
         if (co <= 32) return launch_conv_cfg<x3_t, 3, 1, 1, 16, 16>(a, st);
-        if (co <= 64 || nblk(16, 128) < 512) return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16>(a, st);
+        if (co <= 64) return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16, 8>(a, st);
         return launch_conv_cfg<x3_t, 3, 1, 4, 16, 16, 8>(a, st);
     }
     if (op.ksize == 3 && op.stride == 2) {
@@ -483,6 +484,66 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float *__restrict_
     }
 }
 
+// f16x3 stem (round 5): the same interleaved-pixel K = 28 (+4) scheme with the fp32 image split into (hi | lo) fp16 terms while it
+// is staged (two LDS tiles) and the filters pre-split by the host ([16][7][4 groups of (8 hi | 8 lo)], times 2^wexp): three
+// v_mfma_f32_16x16x32_f16 per tap row -- lo.hi + hi.lo + hi.hi -- instead of 147 scalar FMAs per output value; fp32 NHWC output.
+__global__ __launch_bounds__(256) void stem_x3_kernel(const float *__restrict__ img, const char *__restrict__ w, const float *__restrict__ bias,
+                                                      float *__restrict__ out, int B, int H, int W, int out_cs, int tiles_x, int tiles_y, float wscale)
+{
+    constexpr int TH = 16, TW = 64, IH = TH + 6, IW = TW + 6 + 2;
+    __shared__ __attribute__((aligned(16))) uint2 s_hi[IH][IW], s_lo[IH][IW];      // 4 fp16 per pixel: (c0, c1, c2, 0)
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, p = l & 15, q = l >> 4;
+    const int tiles = tiles_x * tiles_y;
+    const int b = blockIdx.x / tiles;
+    const int t = blockIdx.x - b * tiles;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    u32x4 fah[7], fal[7];      // A fragments of the 7 tap rows: row = out channel p, K group q -> 8 hi terms, 8 lo terms
+#pragma unroll
+    for (int dy = 0; dy < 7; ++dy) {
+        const char *g = w + ((size_t)(p * 7 + dy) * 32 + 8 * q) * 4;
+        fah[dy] = *reinterpret_cast<const u32x4 *>(g);
+        fal[dy] = *reinterpret_cast<const u32x4 *>(g + 16);
+    }
+    const size_t plane = (size_t)H * W;
+    const float *im = img + (size_t)b * 3 * plane;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int iy = i / IW, ix = i - iy * IW;
+        const int gy = oy0 - 3 + iy, gx = ox0 - 3 + ix;
+        u32x4 raw = {0u, 0u, 0u, 0u};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const size_t o = (size_t)gy * W + gx;
+            raw = u32x4{__float_as_uint(im[o]), __float_as_uint(im[plane + o]), __float_as_uint(im[2 * plane + o]), 0u};
+        }
+        u32x2 hi, lo;
+        x3_split4(raw, hi, lo);
+        s_hi[iy][ix] = uint2{hi[0], hi[1]};
+        s_lo[iy][ix] = uint2{lo[0], lo[1]};
+    }
+    __syncthreads();
+    float bs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bs[i] = bias[4 * q + i];
+#pragma unroll 1
+    for (int g = 0; g < 16; ++g) {
+        const int py = wv * 4 + (g >> 2), px0 = (g & 3) * 16;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 7; ++dy) {
+            const uint2 h0 = s_hi[py + dy][px0 + p + 2 * q], h1 = s_hi[py + dy][px0 + p + 2 * q + 1];
+            const uint2 l0 = s_lo[py + dy][px0 + p + 2 * q], l1 = s_lo[py + dy][px0 + p + 2 * q + 1];
+            const u32x4 fbh = {h0.x, h0.y, h1.x, h1.y}, fbl = {l0.x, l0.y, l1.x, l1.y};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fal[dy]), __builtin_bit_cast(f16x8_t, fbh), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fah[dy]), __builtin_bit_cast(f16x8_t, fbl), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fah[dy]), __builtin_bit_cast(f16x8_t, fbh), acc, 0, 0, 0);
+        }
+        const int oy = oy0 + py, ox = ox0 + px0 + p;
+        if (oy < H && ox < W)
+            store4<float>(out + ((size_t)(b * H + oy) * W + ox) * out_cs + 4 * q, fmaxf(fmaf(acc[0], wscale, bs[0]), 0.f), fmaxf(fmaf(acc[1], wscale, bs[1]), 0.f),
+                          fmaxf(fmaf(acc[2], wscale, bs[2]), 0.f), fmaxf(fmaf(acc[3], wscale, bs[3]), 0.f));
+    }
+}
+
 int h3d_launch_stem_s2(const h3d_op &op, hipStream_t st);      // csrc/extra.hip: the 7x7 stride-2 stems of ResNet / Hourglass
 
 int h3d_launch_stem(const h3d_op &op, hipStream_t st)
@@ -506,11 +567,21 @@ int h3d_launch_stem(const h3d_op &op, hipStream_t st)
         H3D_CHECK_LAUNCH("stem_mfma_kernel");
         return H3D_OK;
     }
+    if (op.dtype == H3D_F16X3) {
+        // op.w: the [16][7][32] (k = dx*4 + c, zero padded) filter bank times 2^wexp as (hi | lo) fp16 terms per 8 k -- engine.PackedWeights.stem
+        if (op.wexp < -60 || op.wexp > 60) H3D_FAIL(H3D_ERR_ARG, "stem: wexp %d", op.wexp);
+        const int mx = cdiv(op.W, 64), my = cdiv(op.H, 16);
+        if (h3d_note_kernel("stem_x3_kernel")) return H3D_OK;
+        hipLaunchKernelGGL(stem_x3_kernel, dim3(op.B * mx * my), dim3(256), 0, st, (const float *)op.in, (const char *)op.w, op.bias, (float *)op.out, op.B,
+                           op.H, op.W, op.out_cs, mx, my, ldexpf(1.f, -op.wexp));
+        H3D_CHECK_LAUNCH("stem_x3_kernel");
+        return H3D_OK;
+    }
     if (h3d_note_kernel("stem_kernel<%s>", op.dtype == H3D_BF16 ? "unsigned short" : "float")) return H3D_OK;
     if (op.dtype == H3D_BF16)
         hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), 0, st, (const float *)op.in, (const float *)op.w,
                            op.bias, (bf16_t *)op.out, op.B, op.H, op.W, op.out_cs, tx, ty);
-    else if (op.dtype == H3D_F32 || op.dtype == H3D_F16X3)      // (3 input channels: nothing for the matrix cores to split)
+    else if (op.dtype == H3D_F32)
         hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), 0, st, (const float *)op.in, (const float *)op.w,
                            op.bias, (float *)op.out, op.B, op.H, op.W, op.out_cs, tx, ty);
     else

@@ -638,86 +638,12 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     H3D_STAMP(blockIdx.x, 3);
     // ================= pass 2 (rare): samples whose corners left the apron ===========================
     bool do_p2 = false;
-    constexpr bool COOP = SS == 4 && NP == 0 && !WDMA;       // fp32-storage plans (f32, f16x3): far samples one at a time, cooperatively
-    if constexpr (decltype(P2)::value && COOP) {
-        // Round 5.  The 4-byte variants have no patch slots, so every sample outside the apron came here, and the pass below re-stages
-        // ALL filter chunks between workgroup barriers for a tile with even one such sample (a third of the f16x3 kernel at the
-        // default offsets, the same in absolute terms for f32).  With the margin-4 apron a tile has a handful of them, so they are
-        // now taken ONE AT A TIME by the wave that owns the pixel, with no barrier and no LDS: the sample's four corners are uniform
-        // addresses (scalar loads), the 64 lanes take one output channel each (lane = filter row; 32-channel tiles compute every
-        // channel twice) and walk Cin as a dot product against their filter row read from global memory, and the 64 results are
-        // dealt to the two lanes that hold the pixel's accumulators (cross-lane reads).  fp32 arithmetic (the f16x3 filters are
-        // rebuilt as hi + lo, in their 2^wexp scale, which the accumulators share); cost ~ number of such samples.
-        if (__any(slow)) {
-            const int co = l & (C::BN - 1);
-            const char *wrow = a.w + (size_t)(cout0 + co) * 9 * a.Cin * SS;
-            const int pxb = a.in_cs * ES, rowb = a.W * pxb;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ti = tap / 3, tj = tap - ti * 3, u = (tap < 5) ? tap : tap - 5, th = (tap < 5) ? 0 : 1;
-                const float h_im = (float)(oy - 1 + ti) + aoffs[3 * u], w_im = (float)(ox - 1 + tj) + aoffs[3 * u + 1];     // (meaningful in half `th`)
-                const float fh = floorf(h_im), fw = floorf(w_im);
-                const int hl = (int)fh, wl = (int)fw;
-                const int ry = hl - hy0, rx = wl - hx0;
-                const bool inside = live && h == th && h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W;
-                const bool pend = inside && !((unsigned)ry < (unsigned)(C::HH - 1) && (unsigned)rx < (unsigned)(C::HH - 1));
-                const float lh = h_im - fh, lw = w_im - fw, hh = 1.f - lh, hw = 1.f - lw, mk = dcn2_sigmoid(aoffs[3 * u + 2]);
-                const float q0 = hh * hw * mk, q1 = hh * lw * mk, q2 = lh * hw * mk, q3 = lh * lw * mk;
-                unsigned long long todo = __ballot(pend);
-                while (todo) {
-                    const int src = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const int shl = __builtin_amdgcn_readlane(hl, src), swl = __builtin_amdgcn_readlane(wl, src);
-                    float sq[4] = {__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q0), src)), __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q1), src)),
-                                   __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q2), src)), __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(q3), src))};
-                    // corners outside the image contribute zero (dcn_v2_im2col_cuda.cu:25-54): zero weight, address of corner (0, 0) of the sample's clamp
-                    const bool ok0 = shl >= 0 && swl >= 0, ok1 = shl >= 0 && swl + 1 <= a.W - 1, ok2 = shl + 1 <= a.H - 1 && swl >= 0, ok3 = shl + 1 <= a.H - 1 && swl + 1 <= a.W - 1;
-                    sq[0] = ok0 ? sq[0] : 0.f; sq[1] = ok1 ? sq[1] : 0.f; sq[2] = ok2 ? sq[2] : 0.f; sq[3] = ok3 ? sq[3] : 0.f;
-                    const char *c00 = img + (size_t)(max(shl, 0) * a.W + max(swl, 0)) * pxb;
-                    const char *cp[4] = {ok0 ? img + (size_t)(shl * a.W + swl) * pxb : c00, ok1 ? img + (size_t)(shl * a.W + swl + 1) * pxb : c00,
-                                         ok2 ? img + (size_t)((shl + 1) * a.W + swl) * pxb : c00, ok3 ? img + (size_t)((shl + 1) * a.W + swl + 1) * pxb : c00};
-                    (void)rowb;
-                    float dot = 0.f;
-                    for (int c0 = 0; c0 < a.Cin; c0 += 8) {
-                        float sv[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) sv[j] = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const f32x4 lo4 = *reinterpret_cast<const f32x4 *>(cp[k] + c0 * 4), hi4 = *reinterpret_cast<const f32x4 *>(cp[k] + c0 * 4 + 16);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { sv[j] = fmaf(sq[k], lo4[j], sv[j]); sv[4 + j] = fmaf(sq[k], hi4[j], sv[4 + j]); }
-                        }
-                        const char *wp = wrow + (size_t)(tap * a.Cin + c0) * SS;
-                        if constexpr (std::is_same_v<T, x3_t>) {
-                            const u32x4 wh = *reinterpret_cast<const u32x4 *>(wp), wl4 = *reinterpret_cast<const u32x4 *>(wp + 16);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const f16x2_t ph = __builtin_bit_cast(f16x2_t, wh[j]), pl = __builtin_bit_cast(f16x2_t, wl4[j]);
-                                dot = fmaf((float)ph[0] + (float)pl[0], sv[2 * j], dot);
-                                dot = fmaf((float)ph[1] + (float)pl[1], sv[2 * j + 1], dot);
-                            }
-                        } else {
-                            const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wp), w1 = *reinterpret_cast<const f32x4 *>(wp + 16);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) { dot = fmaf(w0[j], sv[j], dot); dot = fmaf(w1[j], sv[4 + j], dot); }
-                        }
-                    }
-                    // lane c holds output channel c (mod BN) of the sample; the pixel's accumulators live in lanes (src & 31) and (src & 31) + 32
-                    const bool mine = r == (src & 31);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const float v = __shfl(dot, 32 * m + (i & 3) + 8 * (i >> 2) + 4 * h);
-                            acc[m][0][i] += mine ? v : 0.f;
-                        }
-                }
-            }
-        }
-    } else
+    // (round 5, measured and dropped: the far samples of the fp32-storage variants -- which have no patch slots -- taken one at a time
+    //  by the wave that owns the pixel, 64 lanes = 64 output channels walking Cin as a dot product against filter rows read from global
+    //  memory, no barrier, no LDS: 2.4x SLOWER on the f32 plan's 16 launches (42.1 vs 18.3 ms) and 1.8x on the f16x3 plan's margin-4
+    //  tiles (19.4 vs 10.9): a sample is ~5 us of dependent global round trips, and some layers have hundreds per tile)
     if constexpr (decltype(P2)::value) do_p2 = NP > 0 ? overflow : (bool)__syncthreads_or(slow ? 1 : 0);
-    if constexpr (decltype(P2)::value && !COOP) if (do_p2) {
+    if constexpr (decltype(P2)::value) if (do_p2) {
         if constexpr (D2 && MT < 4) {
             // Under the 128-VGPR cap the phase-A accumulators would be spilled around phase B just for this rare path
             // (13 scratch stores + loads per thread and tile: half of the kernel's HBM write traffic).  Recomputed instead:
@@ -1067,6 +993,10 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
         if (op.reserved & 0x2000) {         // tuning override (tools/ab_flag.py): the f32 plan's margin-2 double-buffered tile
             if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 2>(a, st);
             return launch_dcn3_cfg<x3_t, 2, 16, 2>(a, st);
+        }
+        if (op.reserved & 0x4000) {         // tuning override: margin 6 (30 x 30 apron, 115 KB with its filters)
+            if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 6>(a, st);
+            return launch_dcn3_cfg<x3_t, 2, 16, 6>(a, st);
         }
         if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 4>(a, st);      // margin 4, one stage buffer (Dcn3Cfg::SINGLE)
         return launch_dcn3_cfg<x3_t, 2, 16, 4>(a, st);

@@ -210,12 +210,18 @@ class PackedWeights:
         key = ("stem",)
         if key not in self.t:
             w, b = self._fold(self.sd["base.base_layer.0.weight"], None, "base.base_layer.1")
-            if self.dtype in LOWP:
-                # MFMA stem (csrc/conv.hip stem_mfma_kernel): [16][7 dy][32] bf16 with k = dx*4 + c
+            e = 0
+            if self.dtype in LOWP or self.dtype == "f16x3":
+                # MFMA stem (csrc/conv.hip stem_mfma_kernel / stem_x3_kernel): [16][7 dy][32] with k = dx*4 + c
                 wp = torch.zeros(16, 7, 8, 4)
                 wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)          # [o][dy][dx][c]
-                w = wp.reshape(16, 7, 32).to(_TORCH_DT[self.dtype])
+                if self.dtype == "f16x3":                        # fp32 bank times 2^e as (hi | lo) fp16 terms per 8 k
+                    e = x3_exp(wp)
+                    w = x3_split(wp.reshape(16, 7, 32) * 2.0 ** e)
+                else:
+                    w = wp.reshape(16, 7, 32).to(_TORCH_DT[self.dtype])
             self.t[key] = (w.contiguous().to(self.device), b.contiguous().to(self.device))
+            self.wexp[self.t[key][0].data_ptr()] = e
         return self.t[key]
 
     def stem_s2(self, wkey, bkey, bn):
@@ -678,7 +684,7 @@ class Plan:
             w, b = self.pw.stem()
             x = self._alloc(H, W, C[0])
             self._op(_lib.OP_STEM, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=x.ptr, H=H, W=W,
-                     Cin=3, in_cs=3, Ho=H, Wo=W, Cout=C[0], out_cs=x.cs, ksize=7, stride=1, relu=1)
+                     Cin=3, in_cs=3, Ho=H, Wo=W, Cout=C[0], out_cs=x.cs, ksize=7, stride=1, relu=1, wexp=self.pw.wexp.get(w.data_ptr(), 0))
             y0 = self.conv(x, "base.level0.0.weight", bn="base.level0.1")
             y1 = self.conv(y0, "base.level1.0.weight", bn="base.level1.1", stride=2)
             res2 = None

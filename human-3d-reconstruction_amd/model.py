@@ -134,7 +134,8 @@ class DLASeg(nn.Module):
 
 def dla_net(heads, num_layers=34, head_conv=256, down_ratio=4, not_use_dcn=False, dtype="bf16"):
     """Same signature as the reference factory (model.py:501-516) plus `dtype`
-    ('bf16' throughput mode, 'f32' parity mode)."""
+    ('bf16' throughput mode, 'f16' fp16 activations, 'f32' parity mode, 'f16x3' the parity arithmetic on the fp16 matrix cores:
+    fp32 storage, three fp16 MFMAs on split operands per fp32 product -- h3d_amd.detector.Opt)."""
     if num_layers != 34:
         raise ValueError("only dla34 exists in the reference (model.py:309-315)")
     if down_ratio != 4:

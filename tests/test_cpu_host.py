@@ -147,3 +147,61 @@ def test_flip_helpers_match_the_reference_semantics():
     # overlapping pairs are applied in sequence, as the reference's loop does
     odd = [[0, 1], [1, 2]]
     assert np.array_equal(utils.flip_lr(torch.from_numpy(hm), odd).numpy(), odec.flip_lr(hm, odd))
+
+
+def test_f16x3_filter_split_is_exact_to_23_bits_and_prescaled_into_the_normal_range():
+    """Host half of the f16x3 plans (engine.x3_split / x3_exp; csrc/common.h ET<x3_t>): per 8 consecutive K elements the 8 fp16 high
+    terms then the 8 low terms in the 32 bytes of the fp32 values; hi + lo reproduces x to 2^-23 relative once the bank is pre-scaled
+    so that its low terms are normal fp16 numbers (an unscaled 0.05 is only good to 2^-20.7)."""
+    import numpy as np
+    from h3d_amd import engine
+    rng = np.random.default_rng(0)
+    w = torch.from_numpy((rng.standard_normal((24, 9, 32)) * 0.05).astype(np.float32))
+    e = engine.x3_exp(w)
+    assert 2.0 ** 13 <= float(w.abs().max()) * 2.0 ** e < 2.0 ** 14
+    s = engine.x3_split(w * 2.0 ** e)
+    assert s.shape == w.shape and s.dtype == torch.float32
+    h = s.contiguous().view(torch.float16).reshape(-1, 4, 2, 8)          # [rows, K/8, (hi | lo), 8]
+    hi, lo = h[:, :, 0].float().reshape(w.shape), h[:, :, 1].float().reshape(w.shape)
+    assert torch.equal(hi, (w * 2.0 ** e).half().float())
+    back = (hi.double() + lo.double()) * 2.0 ** -e
+    rel = ((back - w.double()).abs() / w.double().abs().clamp_min(1e-30))
+    big = w.abs() > float(w.abs().max()) * 2.0 ** -15                    # filters whose low term is a normal fp16 number
+    assert float(rel[big].max()) <= 2.0 ** -23 * 1.01
+    # without the pre-scale the same bank is an order of magnitude coarser: the reason h3d_op.wexp exists
+    s0 = engine.x3_split(w).contiguous().view(torch.float16).reshape(-1, 4, 2, 8)
+    back0 = s0[:, :, 0].double().reshape(w.shape) + s0[:, :, 1].double().reshape(w.shape)
+    assert float(((back0 - w.double()).abs() / w.double().abs().clamp_min(1e-30))[big].max()) > 2.0 ** -21
+    assert engine.x3_exp(torch.zeros(4, 8)) == 0
+
+
+def test_build_flags_and_default_library_has_no_superseded_generations():
+    L = _lib.lib()
+    flags = L.h3d_build_flags()
+    assert flags & ~3 == 0
+    assert _lib.has_extra() == bool(flags & 1)
+
+
+def test_plan_faithful_emulation_rounds_where_the_plans_round():
+    """oracle/dla.py emulate='bf16_plan' (round 5): small input, CPU only -- it is a bf16-level evaluation of the graph
+    (close to the fp32 oracle, not equal), differs from the older conv-input emulation, and with no rounding point selected
+    (plan_parts=[]) it is that older emulation's treatment up to the up-sampling tap weights, which the plans keep in fp32."""
+    import numpy as np
+    from h3d_amd import synth
+    from oracle import dla as odla
+    heads = {"hm": 1, "wh": 2}
+    sd = synth.synth_state_dict(arch.state_dict_shapes(heads, True), seed=0, gain=1.25)
+    x = torch.from_numpy(synth.synth_images(1, 64, 64, seed=3))
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, heads, use_dcn=True)(x)[0]["hm"]
+        old = odla.DLAOracle(sd, heads, use_dcn=True, emulate="bf16")(x)[0]["hm"]
+        plan = odla.DLAOracle(sd, heads, use_dcn=True, emulate="bf16_plan")(x)[0]["hm"]
+        none = odla.DLAOracle(sd, heads, use_dcn=True, emulate="bf16_plan", plan_parts=[])(x)[0]["hm"]
+    scale = float(ref.abs().max())
+    for t in (old, plan, none):
+        e = float((t - ref).abs().max())
+        assert 1e-4 * scale < e < 0.2 * scale, (e, scale)
+    assert float((plan - old).abs().max()) > 0
+    # plan_parts=[]: conv inputs and raw filters rounded, BatchNorm in fp32 -- the 'bf16' mode's arithmetic except for the depthwise
+    # up-sampling weights (fp32 in every plan, rounded by emulate='bf16'): closer to it than either is to fp32
+    assert float((none - old).abs().max()) < 0.5 * float((old - ref).abs().max())

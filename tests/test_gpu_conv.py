@@ -194,14 +194,20 @@ def test_stem(dtype):
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 3)).float()
     xi = x.contiguous().to(DEV)
     wd, bd = w.contiguous().to(DEV), b.to(DEV)
-    if dtype not in ("f32", "f16x3"):                     # MFMA stem: bf16 / fp16 image and weights, [16][7][32] k = dx*4+c
+    wexp = 0
+    if dtype != "f32":                                    # MFMA stems: [16][7][32] k = dx*4+c; bf16 / fp16 image and weights, or (f16x3) split fp32
         ref = F.relu(F.conv2d(lowp_round(x, dtype).double(), lowp_round(w, dtype).double(), b.double(), 1, 3)).float()
         wp = torch.zeros(16, 7, 8, 4)
         wp[:, :, :7, :3] = w.permute(0, 2, 3, 1)
-        wd = wp.reshape(16, 7, 32).to(TD[dtype]).contiguous().to(DEV)
+        if dtype == "f16x3":
+            from h3d_amd import engine
+            wexp = engine.x3_exp(wp)
+            wd = engine.x3_split(wp.reshape(16, 7, 32) * 2.0 ** wexp).contiguous().to(DEV)
+        else:
+            wd = wp.reshape(16, 7, 32).to(TD[dtype]).contiguous().to(DEV)
     out = torch.zeros(2, 40, 56, 16, dtype=TD[dtype], device=DEV)
     run(mk(_lib.OP_STEM, dtype, in_=xi.data_ptr(), w=wd.data_ptr(), bias=bd.data_ptr(), out=out.data_ptr(), B=2, H=40,
-           W=56, Cin=3, in_cs=3, Ho=40, Wo=56, Cout=16, out_cs=16, ksize=7, stride=1, relu=1))
+           W=56, Cin=3, in_cs=3, Ho=40, Wo=56, Cout=16, out_cs=16, ksize=7, stride=1, relu=1, wexp=wexp))
     _check(from_nhwc(out, 16), ref, dtype)
 
 
