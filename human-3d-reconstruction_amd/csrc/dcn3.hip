@@ -994,7 +994,10 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
             if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 2>(a, st);
             return launch_dcn3_cfg<x3_t, 2, 16, 2>(a, st);
         }
-        if (op.reserved & 0x4000) {         // tuning override: margin 6 (30 x 30 apron, 115 KB with its filters)
+        // margin 6 (30 x 30 apron, 115 KB with its filters) on the large maps with <= 64 output channels (tools/ab_op_reserved.py, batch
+        // 64, same process, margin 4 / 2 / 6: 64 -> 64 @128x128 4.79 / 4.60 / 4.32 ms for the five launches, 128 -> 64 @64x64 1.58 / 1.76 /
+        // 1.49; the 128- and 256-channel layers 3.73 / 3.88 / 3.79: they stay on margin 4); 0x4000 / 0x8000: force margin 6 / margin 4
+        if (((op.Cout <= 64 && op.H >= 64) || (op.reserved & 0x4000)) && !(op.reserved & 0x8000)) {
             if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 6>(a, st);
             return launch_dcn3_cfg<x3_t, 2, 16, 6>(a, st);
         }

@@ -692,7 +692,7 @@ def test_flip_test_on_a_mirror_symmetric_input_keeps_symmetry_and_runs_both_pass
     assert torch.equal(res["heads"]["reg"], a["reg"]) and res["dets"].shape == (2, 30, 40)
 
 
-@pytest.mark.parametrize("arch_args", [[], ["--arch", "resdcn_101"], ["--arch", "hourglass"]])
+@pytest.mark.parametrize("arch_args", [[], ["--arch", "resdcn_101"], ["--arch", "hourglass"], ["--dtype", "f16x3"]])
 def test_bench_cli_prints_one_contract_line(arch_args):
     """bench.py end to end as the driver starts it (a child process; small batch and image): ONE JSON line with the contract's
     keys, `roofline` with a live per-launch figure, and a value that is a rate of the K timed steps."""
@@ -709,10 +709,13 @@ def test_bench_cli_prints_one_contract_line(arch_args):
               "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "images/s" and d["higher_is_better"] is True
-    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and d["vs_baseline"] is None
+    assert d["dtype"] == ("f16x3" if "f16x3" in arch_args else "bf16") and d["data"] == "synthetic" and "workload" in d["config"] and d["vs_baseline"] is None
+    for k in ("shader_clock_mhz", "value_long"):          # (round 5; value_long is null for the other backbones, the clock where sysfs hides it)
+        assert k in d, k
     assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) <= 0.01 * d["value"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "frac_rocprof", "mfma_util", "shader_clock_mhz_timed_region",
+              "peak_assumes_mhz"):
         assert k in rf, k
     assert rf["avg_launch_ms"] > 0 and 0 < rf["frac"] < 1
 
