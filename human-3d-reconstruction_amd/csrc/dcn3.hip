@@ -88,10 +88,11 @@ struct Dcn3Cfg {
     // offsets, tools/ab_lib.py --offset-scale 0.01 vs 0.5); the wider apron keeps 8 of 10 of them inside for a second barrier per stage.
     static constexpr bool SINGLE = !WDMA && SS == 4 && MARGIN > 2;
     static constexpr int LDS_MAIN = WDMA ? PB + LDS_H + 2 * WSLOT : SINGLE ? STAGE : 2 * STAGE;
-    static constexpr int LDS_DESC = NP ? NP * 16 + 32 : 0;             // sample list (16 B each) + the eight per-wave sample counts
+    static constexpr int DESC_B = SS == 4 ? 32 : 16;                   // a list entry: (hl | wl), fp16 weight pairs -- or four fp32 weights (f16x3)
+    static constexpr int LDS_DESC = NP ? NP * DESC_B + 32 : 0;         // sample list + the eight per-wave sample counts
     static constexpr int LDS_EPI = 8 * ((32 * (64 * MT + 16) + 1023) / 1024 * 1024);   // epilogue.h tile_epilogue_lds regions
     static constexpr int LDS = LDS_MAIN + LDS_DESC > LDS_EPI ? LDS_MAIN + LDS_DESC : LDS_EPI;
-    static_assert(NP == 0 || (WDMA && sizeof(T) == 2), "patches: bf16 plans with DMA'd filters");
+    static_assert(NP == 0 || (WDMA && (sizeof(T) == 2 || std::is_same_v<T, x3_t>)), "patches: plans with DMA'd filters (bf16 / fp16 / f16x3)");
     static_assert(NP * (CK * SS / 16) <= 1024, "at most two 16-byte patch units per thread (the second one in a second fill round)");
 };
 
@@ -125,7 +126,7 @@ __device__ __forceinline__ u32x4 dcn3_patch_corner(const char *img, int bytes, i
 // STATS: the statistics launch of h3d_dcn_far_samples -- its own instantiation (phase A + geometry only; everything behind the
 // slot count is compiled out), so that a profiler lists it under its own name and the production kernel carries no switch for it.
 template <typename T, int MT, int CK, int MARGIN, int EPI = 0, bool WDMA = false, int NP = 0, bool PK = false, bool F16IN = false, bool STATS = false>   // EPI: 0 general, 1 lean NHWC, 2 LDS-transposed (bf16)
-__global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dcn3Args a)
+__global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) void dcn3_kernel(Dcn3Args a)
 {
     using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP, PK>;
     using X = SE<std::conditional_t<F16IN, f16_t, T>>;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     //      stage s in set s & 1 (the loops are unrolled by two, so Cin % 32 == 0); loads are range-checked buffer loads
     //      (outside the image: zeros, no branch), so every wave issues exactly NV of them per stage and the wait for the
     //      filter DMA of stage s can be counted: only the NV loads of stage s+1 were issued after it.
-    constexpr bool D2 = WDMA && NP > 0 && sizeof(T) == 2;
+    constexpr bool D2 = WDMA && NP > 0;
 #ifndef DCN3_TAPAHEAD
 #define DCN3_TAPAHEAD 1
 #endif
@@ -254,12 +255,17 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             for (int j = 0; j < NV; ++j) stg2[q][j] = dcn3_patch_corner(img, img_bytes, avoff[j], c0 * ES);
         }
     };
-    auto store2 = [&](auto P) {
+    auto store2 = [&](auto P, auto PHASE_A) {
         if constexpr (D2) {
             constexpr int q = decltype(P)::value;
 #pragma unroll
-            for (int j = 0; j < NV; ++j)
-                if (adst[j] >= 0) *reinterpret_cast<u32x4 *>(smem + C::PB + adst[j]) = X::convert16(stg2[q][j]);      // (converting in front of the barrier instead, in place: +0.5 %, tools/ab_lib.py)
+            for (int j = 0; j < NV; ++j) {
+                if constexpr (X::SPLIT_A && decltype(PHASE_A)::value) {      // f16x3, phase A: finished operand fragments (x3_store4; the vector's
+                    if (adst[j] >= 0) x3_store4(smem + C::PB + adst[j] - (tid & 1) * 16, tid & 1, stg2[q][j]);   // half of its 8-channel group = tid & 1: VPP = 4)
+                } else {
+                    if (adst[j] >= 0) *reinterpret_cast<u32x4 *>(smem + C::PB + adst[j]) = X::convert16(stg2[q][j]);      // (converting in front of the barrier instead, in place: +0.5 %, tools/ab_lib.py)
+                }
+            }
         }
     };
     [[maybe_unused]] constexpr std::integral_constant<int, 0> I0{};
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         load2(1, I1);                            // (nchunks is even: stage 1 exists)
         auto stepA = [&](int s, auto P) {
             if (s) __syncthreads();              // (single apron buffer)
-            store2(P);
+            store2(P, std::true_type{});
             __builtin_amdgcn_s_waitcnt(WAIT_NV); // the filters of stage s have landed; the apron of stage s+1 may still fly
             __syncthreads();
             issue_w(s + 1);
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             int cnt = 0;
 #pragma unroll
             for (int u = 0; u < 5; ++u) { m[u] = __ballot(my_want[u]); cnt += __popcll(m[u]); }
-            int *s_cnt = reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * 16);
+            int *s_cnt = reinterpret_cast<int *>(smem + C::LDS_MAIN + NP * C::DESC_B);
             if (l == 0) s_cnt[wv] = cnt;
             __syncthreads();
             int base = 0;
@@ -397,6 +403,10 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                             *reinterpret_cast<u32x4 *>(smem + C::LDS_MAIN + slot * 16) = u32x4{my_hw[u], my_geo[u].w01, my_geo[u].w23, 0u};
                             my_geo[u].w01 = 0x00003c00u;             // (1, 0 | 0, 0): the blend is done when the patch is filled
                             my_geo[u].w23 = 0u;
+                        } else {                                     // f16x3: (hl | wl) and the four fp32 weights (mask folded in)
+                            *reinterpret_cast<uint32_t *>(smem + C::LDS_MAIN + slot * C::DESC_B) = my_hw[u];
+                            *reinterpret_cast<f32x4 *>(smem + C::LDS_MAIN + slot * C::DESC_B + 16) = f32x4{my_geo[u].w[0], my_geo[u].w[1], my_geo[u].w[2], my_geo[u].w[3]};
+                            my_geo[u].w[0] = 1.f; my_geo[u].w[1] = 0.f; my_geo[u].w[2] = 0.f; my_geo[u].w[3] = 0.f;
                         }
                         my_off[u] = slot * C::PSLOT - C::PB;         // the patch pixel, relative to the apron base
                         my_pm |= 1 << u;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         __syncthreads();                                                 // the list is complete
         int nwant = 0;
         {
-            const int *s_cnt = reinterpret_cast<const int *>(smem + C::LDS_MAIN + NP * 16);
+            const int *s_cnt = reinterpret_cast<const int *>(smem + C::LDS_MAIN + NP * C::DESC_B);
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) nwant += s_cnt[w8];
         }
@@ -457,9 +467,13 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
         //  batch-64 plan 3.5 % SLOWER (2.205 vs 2.129 ms, tools/ab_lib.py): the scalar branch splits the block the four loads are
         //  scheduled in, and the loads of an idle thread cost nothing but their issue slot)
         if (phas) {
-            const u32x4 d = *reinterpret_cast<const u32x4 *>(smem + C::LDS_MAIN + ps * 16);
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(smem + C::LDS_MAIN + ps * C::DESC_B);
             const int hl = (int)d[0] >> 16, wl = (int)(short)(d[0] & 0xffffu);
             if constexpr (sizeof(T) == 2) { pgeo.w01 = d[1]; pgeo.w23 = d[2]; }
+            else {
+                const f32x4 w4 = *reinterpret_cast<const f32x4 *>(smem + C::LDS_MAIN + ps * C::DESC_B + 16);
+                pgeo.w[0] = w4[0]; pgeo.w[1] = w4[1]; pgeo.w[2] = w4[2]; pgeo.w[3] = w4[3];
+            }
             pbase = ((hl * a.W + wl) * a.in_cs) * ES + pv * 16;          // (may be negative: only used for corners inside the image)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     // apron buffer (they touch no LDS), so their latency overlaps the barrier wait and the apron stores; blend + store after
     [[maybe_unused]] u32x4 pst[4];
     auto patch_issue = [&](int s) {
-        if constexpr (NP > 0 && sizeof(T) == 2) {
+        if constexpr (NP > 0) {
             if (H3D_DBG(a) & 16) return;
             const int c0 = (s - nchunks) * CK;
 #pragma unroll
@@ -482,7 +496,21 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             }
         }
     };
+    // f16x3: a patch unit is 4 fp32 channels of the sample, blended in fp32 with the entry's four weights
+    auto blend4 = [&](const u32x4 (&c)[4], const typename X::geo &g) -> u32x4 {
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if constexpr (SS == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = __float_as_uint(fmaf(g.w[3], __uint_as_float(c[3][e]), fmaf(g.w[2], __uint_as_float(c[2][e]), fmaf(g.w[1], __uint_as_float(c[1][e]), g.w[0] * __uint_as_float(c[0][e])))));
+        }
+        return o;
+    };
     auto patch_commit = [&](char *s_h) {
+        if constexpr (NP > 0 && SS == 4) {
+            if (!phas || (H3D_DBG(a) & 16)) return;
+            *reinterpret_cast<u32x4 *>(s_h - C::PB + tid * 16) = blend4(pst, pgeo);      // entry tid / VPP, unit tid % VPP: PSLOT = VPP * 16
+        }
         if constexpr (NP > 0 && sizeof(T) == 2) {
             if (!phas || (H3D_DBG(a) & 16)) return;
             typename X::frag v[4];
@@ -498,6 +526,28 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
     // it), its four corner loads exposed (they are issued behind the barrier, ~2k cycles per stage) -- instead of sending
     // those samples through pass 2, which costs the tile 3x its time
     auto patch_round2 = [&](int s, char *s_h) {
+        if constexpr (NP * C::VPP > 512 && SS == 4) {            // f16x3: 4 units per entry, so entries 128 ... NP - 1 are the second round
+            constexpr int R = 512 / C::VPP;
+            if (nsl2 <= R) return;                                       // workgroup-uniform
+            const int ps = R + tid / C::VPP, pv = tid % C::VPP;
+            if (ps >= nsl2) return;
+            const uint32_t hw = *reinterpret_cast<const uint32_t *>(smem + C::LDS_MAIN + ps * C::DESC_B);
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(smem + C::LDS_MAIN + ps * C::DESC_B + 16);
+            const int hl = (int)hw >> 16, wl = (int)(short)(hw & 0xffffu);
+            typename X::geo g2;
+            g2.w[0] = w4[0]; g2.w[1] = w4[1]; g2.w[2] = w4[2]; g2.w[3] = w4[3];
+            const int base2 = ((hl * a.W + wl) * a.in_cs) * ES + pv * 16;
+            const int c0 = (s - nchunks) * CK;
+            u32x4 c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = hl + (k >> 1), xx = wl + (k & 1);
+                const bool ok = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                const int voff = base2 + ((k & 1) + (k >> 1) * a.W) * a.in_cs * ES;
+                c[k] = dcn3_patch_corner(img, img_bytes, ok ? voff : 0x7ffffff0, c0 * ES);
+            }
+            *reinterpret_cast<u32x4 *>(s_h - C::PB + (R * C::VPP + tid) * 16) = blend4(c, g2);
+        }
         if constexpr (NP * C::VPP > 512 && sizeof(T) == 2) {
             constexpr int R = 512 / C::VPP;
             if (nsl2 <= R) return;                                       // workgroup-uniform
@@ -606,7 +656,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             patch_issue(s);
             __syncthreads();
             H3D_STAMP_B(s, 1);
-            store2(P);
+            store2(P, std::false_type{});
             patch_commit(smem + C::PB);
             patch_round2(s, smem + C::PB);
             __builtin_amdgcn_s_waitcnt(0x0f70);  // (the patch loads were the youngest: nothing older is pending either)
@@ -654,14 +704,19 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                 __syncthreads();
                 issue_w(s);
                 load2(s, I0);
-                store2(I0);
+                store2(I0, std::true_type{});
                 __builtin_amdgcn_s_waitcnt(0x0f70);
                 __syncthreads();
                 computeA(s);
             }
             const float *bo = a.bias + a.wrows;
+            if constexpr (std::is_same_v<T, x3_t>) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
+                for (int i = 0; i < 16; ++i) aoffs[i] = fmaf(aoffs[i], a.oscale, bo[(i & 3) + 8 * (i >> 2) + 4 * h]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
+            }
         }
         if constexpr (D2) {
             // The tile ran out of patch slots.  Pass 2 as round 1 wrote it takes one global round trip per tap and chunk
@@ -669,7 +724,8 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
             // is computed once, and per chunk the corner loads of TB taps are in flight together (range-checked buffer
             // loads: lanes without a pending sample read zeros, no branch); a wave skips the taps none of its lanes needs.
             // Registers spill in this branch under the 128-VGPR cap -- it is the rare path.
-            constexpr int TB = 3;
+            constexpr int TB = SS == 4 ? 1 : 3;          // (an fp32 corner fragment is 32 bytes per lane: two loads, twice the registers)
+            constexpr int CV = SS == 4 ? 2 : 1;          // 16-byte loads per corner fragment
             int qb[9], qok[9], wmask = 0;
             typename X::geo qg[9];
 #pragma unroll
@@ -697,7 +753,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                 if (__any(pend)) wmask |= 1 << tap;
             }
             const int pxb = a.in_cs * ES, rowb = a.W * pxb;
-            u32x4 pv[TB][4];
+            u32x4 pv[TB][4][CV];
             for (int c0 = 0; c0 < a.Cin; c0 += CK) {
                 auto fetch = [&](int t0) {
 #pragma unroll
@@ -705,7 +761,9 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                         if (!((wmask >> (t0 + j)) & 1)) continue;                // wave-uniform
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            pv[j][k] = dcn3_patch_corner(img, img_bytes, ((qok[t0 + j] >> k) & 1) ? qb[t0 + j] + (k & 1) * pxb + (k >> 1) * rowb : 0x7ffffff0, c0 * ES);
+#pragma unroll
+                            for (int cv = 0; cv < CV; ++cv)
+                                pv[j][k][cv] = dcn3_patch_corner(img, img_bytes, ((qok[t0 + j] >> k) & 1) ? qb[t0 + j] + (k & 1) * pxb + (k >> 1) * rowb + cv * 16 : 0x7ffffff0, c0 * ES);
                     }
                 };
                 __syncthreads();
@@ -715,14 +773,19 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2) ? 4 : 2) void dcn3_kernel(Dc
                 __syncthreads();
 #pragma unroll
                 for (int t0 = 0; t0 < 9; t0 += TB) {
-                    typename X::frag fbs[TB];
+                    typename X::bfrag fbs[TB];
 #pragma unroll
                     for (int j = 0; j < TB; ++j) {
                         if (!((wmask >> (t0 + j)) & 1)) continue;
                         typename X::frag v[4];
+                        if constexpr (SS == 4) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k].v = __builtin_bit_cast(half8_t, X::convert16(pv[j][k]));
-                        fbs[j] = X::blend(v, qg[t0 + j]);
+                            for (int k = 0; k < 4; ++k) { v[k].lo = __builtin_bit_cast(f32x4, pv[j][k][0]); v[k].hi = __builtin_bit_cast(f32x4, pv[j][k][CV - 1]); }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k].v = __builtin_bit_cast(half8_t, X::convert16(pv[j][k][0]));
+                        }
+                        fbs[j] = X::prep(X::blend(v, qg[t0 + j]));
                     }
                     if (t0 + TB < 9) fetch(t0 + TB);                               // the next taps fly while these are multiplied
 #pragma unroll
@@ -833,7 +896,7 @@ template <typename T, int MT, int CK, int MARGIN, bool WDMA = false, int NP = 0,
 static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
 {
     using C = Dcn3Cfg<T, MT, CK, MARGIN, WDMA, NP, PK>;
-    static_assert(!(WDMA && MT <= 2) || C::LDS * 2 <= 160 * 1024, "two workgroups per CU");
+    static_assert(!(WDMA && MT <= 2 && sizeof(T) == 2) || C::LDS * 2 <= 160 * 1024, "two workgroups per CU");
     static_assert(C::LDS <= 160 * 1024, "LDS budget");
     Dcn3Args a = a0;
     a.tiles_x = cdiv(a.W, 16);
@@ -851,7 +914,7 @@ static int launch_dcn3_cfg(const Dcn3Args &a0, hipStream_t st)
                               : PK ? "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d, true>" : "dcn3_kernel<%s, %d, %d, %d, %d, %s, %d>", h3d_tname<T>(), MT, CK, MARGIN, epi,
                         WDMA ? "true" : "false", NP))
         return H3D_OK;
-    if constexpr (NP > 0) {
+    if constexpr (NP > 0 && sizeof(T) == 2) {
         if (a.dbg & 0x20000) {                  // h3d_dcn_far_samples
             hipLaunchKernelGGL((dcn3_kernel<T, MT, CK, MARGIN, 1, WDMA, NP, PK, F16IN, true>), dim3(grid.x), dim3(C::THREADS), 0, st, a);
             H3D_CHECK_LAUNCH("dcn3_kernel<stats>");
@@ -946,7 +1009,7 @@ int h3d_launch_dcn5(const h3d_op &op, hipStream_t st);      // csrc/dcn5.hip: fp
 int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
 {
     const bool wdma = op.kind == H3D_OP_DCN_FUSED_STREAM;
-    if (wdma && op.dtype != H3D_BF16 && op.dtype != H3D_F16) H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused_stream: bf16 / fp16 plans only");
+    if (wdma && op.dtype != H3D_BF16 && op.dtype != H3D_F16 && op.dtype != H3D_F16X3) H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused_stream: bf16 / fp16 / f16x3 plans only");
     if (!op.in || !op.w || !op.bias || !op.out || !op.in2) H3D_FAIL(H3D_ERR_ARG, "dcn_fused: null pointer");
     const int es = h3d_dtype_bytes(op.dtype);
     if (!es) H3D_FAIL(H3D_ERR_DTYPE, "dcn_fused: dtype %d", op.dtype);
@@ -988,6 +1051,15 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
     if (op.dtype == H3D_F32) {
         if (op.Cout <= 32) return launch_dcn3_cfg<float, 1, 16, 2>(a, st);
         return launch_dcn3_cfg<float, 2, 16, 2>(a, st);
+    }
+    if (op.dtype == H3D_F16X3 && wdma) {
+        // f16x3 with PATCH SLOTS (round 5): the 2-byte plans' pipeline -- filters as stage-major images by LDS-DMA (pre-split (hi | lo)
+        // terms: 592-byte rows), the apron two stages ahead through registers, 256 patch slots per tile (32-byte list entries: four
+        // fp32 weights; a patch unit is four fp32 channels; entries 128 ... 255 in a second fill round) -- on the fp32 apron of margin 2:
+        // 141 KB of LDS, one workgroup per CU.  A far sample costs its four corner loads instead of a share of pass 2's re-walk.
+        if (op.Cin % 32) H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused_stream (f16x3): Cin %d must be a multiple of 32 (two stages per pipeline turn); use H3D_OP_DCN_FUSED", op.Cin);
+        if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 2, true, 256>(a, st);
+        return launch_dcn3_cfg<x3_t, 2, 16, 2, true, 256>(a, st);
     }
     if (op.dtype == H3D_F16X3) {            // the f32 plan's tiles (fp32 apron, register-staged pre-split filters) on 3 fp16 MFMAs per step
         if (op.reserved & 0x2000) {         // tuning override (tools/ab_flag.py): the f32 plan's margin-2 double-buffered tile

@@ -187,6 +187,47 @@ class PackedWeights:
         img[:, :, :, :9 * spt] = v.reshape(ci // ck, G, 32, 9 * spt, 8)
         return img
 
+    @staticmethod
+    def _stage_image_x3(ws):
+        """float32-TYPED split filters [rows (multiple of 32)][9][Cin] (x3_split: per 8 channels 8 hi | 8 lo fp16 terms) -> the stage-major
+        LDS image of the f16x3 patch-slot DeformConv (csrc/dcn3.hip WDMA, 16 channels per stage): [Cin/16][rows/32][32][37 slots of 16 B]:
+        slot 4 * tap + j = bytes 16 j .. 16 j + 15 of the tap's 64 bytes (channels 16 * stage ... + 15), slot 36 zero -- rows of 592 B."""
+        rows, _, ci = ws.shape
+        G = rows // 32
+        img = torch.zeros(ci // 16, G, 32, 37, 4)
+        v = ws.reshape(G, 32, 9, ci // 16, 4, 4).permute(3, 0, 1, 2, 4, 5)
+        img[:, :, :, :36] = v.reshape(ci // 16, G, 32, 36, 4)
+        return img
+
+    def dcn_stream_x3(self, p):
+        """Fused DeformConv `p` for the f16x3 patch-slot variant: (main image, offset image, bias [rows | 32], Cout, Cin, rows); the
+        power-of-two pre-scale exponents of the two banks land in `self.wexp` under the images' device pointers."""
+        key = ("dcn_stream_x3", p)
+        if key not in self.t:
+            w, b = self._fold(self.sd[p + ".conv.weight"], self.sd[p + ".conv.bias"], p + ".actf.0")
+            co, ci = w.shape[:2]
+            rows = ((co + 127) // 128) * 128
+            wp = torch.zeros(rows, 9, ci)
+            wp[:co] = w.permute(0, 2, 3, 1).reshape(co, 9, ci)
+            bp = torch.zeros(rows)
+            bp[:co] = b
+            wo = torch.zeros(32, 9, ci)
+            bo = torch.zeros(32)
+            ow, ob = self.sd[p + ".conv.conv_offset_mask.weight"], self.sd[p + ".conv.conv_offset_mask.bias"]
+            for tap in range(9):                         # rows permuted as offset_conv() does
+                hh, u = (0, tap) if tap < 5 else (1, tap - 5)
+                for c, ch in enumerate((2 * tap, 2 * tap + 1, 18 + tap)):
+                    i = 3 * u + c
+                    row = (i & 3) + 8 * (i >> 2) + 4 * hh
+                    wo[row] = ow[ch].permute(1, 2, 0).reshape(9, ci)
+                    bo[row] = ob[ch]
+            e, eo = x3_exp(wp), x3_exp(wo)
+            wimg = self._stage_image_x3(x3_split(wp * 2.0 ** e)).contiguous().to(self.device)
+            woimg = self._stage_image_x3(x3_split(wo * 2.0 ** eo)).contiguous().to(self.device)
+            self.t[key] = (wimg, woimg, torch.cat([bp, bo]).contiguous().to(self.device), co, ci, rows)
+            self.wexp[wimg.data_ptr()], self.wexp[woimg.data_ptr()] = e, eo
+        return self.t[key]
+
     def dcn_stream(self, p, ck=16):
         """Fused DeformConv `p` packed as fp16 stage-major images of the main and the offset/mask filters, `ck`
         channels per stage (csrc/dcn4.hip: 16; csrc/dcn3.hip WDMA: h3d_dcn_fused_ck)
@@ -409,6 +450,8 @@ class Plan:
                                # (up-sample + add, max-pool, gathers), which the 198-register narrow-heads launch lets onto its
                                # CUs, have to wait
         wide_heads_m2=0,       # 3: heads wider than 32 channels share one launch (measured: no gain)
+        x3_dcn_patches=True,      # f16x3 plans: the patch-slot DeformConv variant (filters by LDS-DMA, far samples as patch pixels) for layers with
+                                  # Cin % 32 == 0; False: the f32 plan's register-staged tiles, every far sample through pass 2
         stem_s2_direct=True,      # bf16 plans of the other backbones: the 7x7 stride-2 stem conv itself instead of im2col + 1x1 conv
         conv1x1_th16_min_cin=0,   # > 0: 1x1 convs with at least this many input channels (and > 32 outputs) use 16-row tiles
     )
@@ -617,6 +660,14 @@ class Plan:
             self.dcn_layers.append((p, len(self.ops) - 1))
             return out
         assert not in_f16, p
+        if self.pw.use_dcn and self.fuse_offsets and self.pw.dtype == "f16x3" and self.x3_dcn_patches and w.shape[1] % 32 == 0:
+            wimg, woimg, bias, cout, cin, rows = self.pw.dcn_stream_x3(p)
+            if out is None:
+                out = self._alloc(x.H, x.W, cout)
+            self._op(_lib.OP_DCN_FUSED_STREAM, in_=x.ptr, in2=woimg.data_ptr(), w=wimg.data_ptr(), bias=bias.data_ptr(), out=out.ptr,
+                     H=x.H, W=x.W, Cin=cin, in_cs=x.cs, Ho=x.H, Wo=x.W, Cout=cout, out_cs=out.cs, ksize=3, stride=1, relu=1,
+                     out_mode=_lib.OUT_NHWC, wrows=rows, wexp=self.pw.wexp[wimg.data_ptr()], wexp2=self.pw.wexp[woimg.data_ptr()])
+            return out
         if self.pw.use_dcn and self.fuse_offsets:
             wp, bp, cout, cin, k, rows = self.pw.conv(p + ".conv.weight", p + ".conv.bias", p + ".actf.0", as_half=True)
             wo, bo = self.pw.offset_conv(p + ".conv.conv_offset_mask.weight", p + ".conv.conv_offset_mask.bias", rows)

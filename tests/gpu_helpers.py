@@ -209,9 +209,9 @@ def dcn_fused_op(kind, x, w, b, wo, bo, dtype="bf16", reserved=0, skip=None, w_u
         opk, wptr, in2 = _lib.OP_DCN_FUSED, wp.data_ptr(), wop.data_ptr()
         keep += [wp, wop, bias, xin]
     else:
-        assert dtype in ("bf16", "f16") and (dtype == "bf16" or kind == "stream")
+        assert dtype in ("bf16", "f16", "f16x3") and (dtype == "bf16" or kind == "stream")
         ck = int(_lib.lib().h3d_dcn_fused_ck(Ci, w.shape[0])) if kind in ("stream", "stream16") else 16
-        wimg, woimg, bias, cout, cin, rows = pw.dcn_stream("p", ck)
+        wimg, woimg, bias, cout, cin, rows = pw.dcn_stream_x3("p") if dtype == "f16x3" else pw.dcn_stream("p", ck)
         wptr = wimg.data_ptr()
         keep += [wimg, woimg, bias]
         if kind == "stream":

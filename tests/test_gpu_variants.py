@@ -124,6 +124,12 @@ DCN_CASES = [
     ("fused", "f16x3", 0, 1, 64, 64, 64, 80, 3.0),         # dcn3<x3_t,2,16,6>: margin-6 apron on maps of >= 64 rows
     ("fused", "f16x3", 0x4000, 1, 32, 32, 16, 16, 12.0),   # dcn3<x3_t,1,16,6>
     ("fused", "f16x3", 0x2000, 1, 64, 64, 20, 24, 3.0),    # dcn3<x3_t,2,16,2>: the f32 plan's margin-2 double-buffered tile
+    ("stream", "f16x3", 0, 2, 128, 64, 24, 40, 0.5),       # dcn3<x3_t,2,16,2,WDMA,256>: f16x3 with patch slots (fp32 list entries and patch units)
+    ("stream", "f16x3", 0, 1, 256, 64, 16, 32, 3.0),       #   ... 4-13 % of the samples in patches, second fill round (entries >= 128)
+    ("stream", "f16x3", 0, 2, 64, 64, 40, 24, 6.0),        #   ... more far samples than slots: patches AND pass 2
+    ("stream", "f16x3", 0, 1, 64, 64, 16, 16, 40.0),       #   ... nearly every sample outside the apron or the image
+    ("stream", "f16x3", 0, 1, 64, 32, 20, 20, 12.0),       # dcn3<x3_t,1,16,2,WDMA,256>
+    ("stream", "f16x3", 0, 1, 256, 256, 16, 16, 3.0),      #   four channel groups per tile (grid.y = 4)
     ("stream", "bf16", 0, 2, 128, 64, 24, 40, 0.5),        # dcn3<bf16,2,16,2,WDMA,256>: two workgroups per CU, patch slots
     ("stream", "bf16", 0, 1, 256, 64, 16, 32, 3.0),        #   ... 4-13 % of the samples in patches
     ("stream", "bf16", 0, 2, 64, 64, 40, 24, 6.0),         #   ... more samples leave the apron than a tile has slots: patches AND pass 2
