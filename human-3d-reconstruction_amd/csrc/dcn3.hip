@@ -1058,6 +1058,13 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
         // fp32 weights; a patch unit is four fp32 channels; entries 128 ... 255 in a second fill round) -- on the fp32 apron of margin 2:
         // 141 KB of LDS, one workgroup per CU.  A far sample costs its four corner loads instead of a share of pass 2's re-walk.
         if (op.Cin % 32) H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused_stream (f16x3): Cin %d must be a multiple of 32 (two stages per pipeline turn); use H3D_OP_DCN_FUSED", op.Cin);
+        // margin 3 (24 x 24 apron, 150 KB) on the 128 x 128 maps and the layers with more than 64 output channels (tools/ab_op_reserved.py
+        // --kind 12 --codes 0 0x8000, batch 64, same process, margin 2 / 3: 64 -> 64 @128x128 3.31 / 3.05 ms for the five launches,
+        // 128 -> 128 @64x64 1.45 / 1.25, 256 -> 256 @32x32 0.83 / 0.77; 128 -> 64 @64x64 1.00 / 1.04: margin 2); 0x8000 / 0x4000 force 3 / 2
+        if (((op.H >= 128 || op.Cout > 64) || (op.reserved & 0x8000)) && !(op.reserved & 0x4000)) {
+            if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 3, true, 256>(a, st);
+            return launch_dcn3_cfg<x3_t, 2, 16, 3, true, 256>(a, st);
+        }
         if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 2, true, 256>(a, st);
         return launch_dcn3_cfg<x3_t, 2, 16, 2, true, 256>(a, st);
     }

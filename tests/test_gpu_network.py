@@ -73,6 +73,17 @@ def test_bf16_mode_within_stated_tolerance(use_dcn):
 F16_TOL = 0.012    # abs: 1/8 of bf16's step (3 more mantissa bits per stored activation), same 2x margin (measured worst below)
 
 
+def test_f16x3_plan_saturates_beyond_its_contract_instead_of_producing_nan():
+    """CONTRACT of the f16x3 plans: |activation| <= 65504 (the split's hi term is an fp16).  Beyond it every split clamps (x3_split4:
+    the staging of conv / heads / DeformConv tiles, the blended DeformConv sample, the heads' slab), so a wildly scaled input gives
+    finite, saturated heads -- never inf * 0 = NaN."""
+    m, sd = _net(True, "f16x3")
+    xs = synth.synth_images(1, 64, 96, seed=5) * 3e4
+    out = m(torch.from_numpy(xs).to(DEV))[0]
+    for k in HEADS:
+        assert bool(torch.isfinite(out[k]).all()), k
+
+
 @pytest.mark.parametrize("use_dcn", [False, True])
 def test_f16_mode_within_stated_tolerance(use_dcn):
     """fp16 plans (H3D_F16: the arithmetic BASELINE configs[4] names; also `dla_net(..., dtype="f16")`): same kernels with

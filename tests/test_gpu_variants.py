@@ -129,7 +129,9 @@ DCN_CASES = [
     ("stream", "f16x3", 0, 2, 64, 64, 40, 24, 6.0),        #   ... more far samples than slots: patches AND pass 2
     ("stream", "f16x3", 0, 1, 64, 64, 16, 16, 40.0),       #   ... nearly every sample outside the apron or the image
     ("stream", "f16x3", 0, 1, 64, 32, 20, 20, 12.0),       # dcn3<x3_t,1,16,2,WDMA,256>
-    ("stream", "f16x3", 0, 1, 256, 256, 16, 16, 3.0),      #   four channel groups per tile (grid.y = 4)
+    ("stream", "f16x3", 0, 1, 256, 256, 16, 16, 3.0),      # dcn3<x3_t,2,16,3,WDMA,256>: margin 3 (more than 64 output channels), grid.y = 4
+    ("stream", "f16x3", 0x8000, 1, 64, 32, 20, 20, 12.0),  # dcn3<x3_t,1,16,3,WDMA,256>
+    ("stream", "f16x3", 0x4000, 1, 256, 128, 16, 16, 6.0), # dcn3<x3_t,2,16,2,WDMA,256> forced on a wide layer
     ("stream", "bf16", 0, 2, 128, 64, 24, 40, 0.5),        # dcn3<bf16,2,16,2,WDMA,256>: two workgroups per CU, patch slots
     ("stream", "bf16", 0, 1, 256, 64, 16, 32, 3.0),        #   ... 4-13 % of the samples in patches
     ("stream", "bf16", 0, 2, 64, 64, 40, 24, 6.0),         #   ... more samples leave the apron than a tile has slots: patches AND pass 2
@@ -340,11 +342,11 @@ def test_dcn_f16_stream_dispatch():
 
 
 def test_dcn_auto_selection_reaches_mt4():
-    c = [c for c in DCN_CASES if c[3] == 12 and c[0] == "fused"][0]
+    c = [c for c in DCN_CASES if c[3] == 12 and c[0] == "fused" and c[1] == "bf16"][0]
     assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 4, 16, 2, 2, false, 0>"
-    c = [c for c in DCN_CASES if c[3] == 12 and c[0] == "stream"][0]
+    c = [c for c in DCN_CASES if c[3] == 12 and c[0] == "stream" and c[1] == "bf16"][0]
     assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 4, 16, 4, 2, true, 256>"
-    c = [c for c in DCN_CASES if c[0] == "stream" and c[2] == 0 and c[4:8] == (256, 256, 16, 16)][0]      # 1 tile x 2 groups: small grid
+    c = [c for c in DCN_CASES if c[0] == "stream" and c[1] == "bf16" and c[2] == 0 and c[4:8] == (256, 256, 16, 16)][0]      # 1 tile x 2 groups: small grid
     assert _dcn_built(c)[5].name == "dcn3_kernel<unsigned short, 2, 16, 2, 2, true, 256>"
 
 
