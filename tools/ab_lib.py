@@ -35,6 +35,9 @@ names = [kernel_name(op) for op in plan.ops]
 builds = {"in-tree": _lib.lib()}
 for p in args.libs:
     L = ctypes.CDLL(p)
+    L.h3d_abi_version.restype = ctypes.c_int
+    if L.h3d_abi_version() != _lib.ABI_VERSION:      # (ABI 2 appended two fields to h3d_op: an older build would walk the op array with the wrong stride)
+        raise SystemExit("%s: ABI %d, this tree binds ABI %d -- rebuild the baseline from the same include/h3d.h" % (p, L.h3d_abi_version(), _lib.ABI_VERSION))
     L.h3d_run_ops_timed.argtypes = _lib.lib().h3d_run_ops_timed.argtypes
     L.h3d_run_ops_timed.restype = ctypes.c_int
     builds[p] = L
