@@ -154,3 +154,30 @@ def test_sampling_rule_agrees_with_scipy_map_coordinates():
                 want[bi] += w[:, c, i, j][:, None, None] * (s * m[bi, t])[None]
         want[bi] += b[:, None, None]
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_f16_blend_mode_models_four_fp16_roundings():
+    """oracle/dcn.py blend='f16' (round 5: the 2-byte GPU plans' blend, csrc/dcn_traits.h SE<bf16_t>::blend): with weights and samples
+    that are exactly representable and whose products need no rounding it equals the fp32 blend bit for bit; in general it differs
+    from it by at most four fp16 roundings of the running sum (2^-11 relative each)."""
+    torch.manual_seed(0)
+    B, C, H, W, Co = 1, 4, 7, 9, 3
+    x = torch.randint(-8, 9, (B, C, H, W)).float()                      # small integers: exact in fp16, products exact
+    w = torch.randint(-2, 3, (Co, C, 3, 3)).float()
+    b = torch.zeros(Co)
+    off = torch.zeros(B, 18, H, W)
+    off[:, 0::2] = 0.5                                                  # half-pixel shifts: bilinear weights 0.25 / 0.5, exact
+    off[:, 1::2] = -0.5
+    m = torch.full((B, 9, H, W), 0.5)
+    a = odcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
+    f = odcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64, blend="f16")
+    assert torch.equal(a, f)
+    x = torch.randn(B, C, H, W).half().float()
+    off = torch.randn(B, 18, H, W) * 1.5
+    m = torch.rand(B, 9, H, W)
+    w = torch.randn(Co, C, 3, 3).half().float() * 0.2
+    a = odcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
+    f = odcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64, blend="f16")
+    scale = float(a.abs().max())
+    err = float((a - f).abs().max())
+    assert 0 < err < 6 * 2.0 ** -11 * scale, (err, scale)
