@@ -1058,6 +1058,16 @@ def main():
                     line["parity_mode"]["f16x3"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 keep.pop("verts_f32", None)
                 print("[bench] parity_mode f16x3 %s" % json.dumps(line["parity_mode"]["f16x3"]), file=sys.stderr, flush=True)
+                px = line["parity_mode"]["f16x3"]
+                if "images_per_s" in px:
+                    line["metric_note"] += (
+                        "  PARITY PLAN f16x3 (Opt(dtype='f16x3'): fp32 storage, three fp16 MFMAs on split operands per fp32 product), same 64 images: "
+                        "%.1f images/s (%.2fx the f32 plan's %.1f), max head error vs the fp32 oracle %.2g (f32 plan: %.2g), top-k agreement %.3f, "
+                        "robust prefix %d bit-identical, meshes within %s of the CPU path's (tolerance 1e-4)."
+                        % (px["images_per_s"], px["images_per_s"] / line["parity_mode"]["images_per_s"], line["parity_mode"]["images_per_s"],
+                           px["index_match"]["max_abs_head_err"], line["parity_mode"]["index_match"]["max_abs_head_err"], px["index_match"]["agreement"],
+                           px["index_match"]["robust_prefix"],
+                           ("%.2g" % px["verts_max_abs_err_vs_oracle"]) if isinstance(px.get("verts_max_abs_err_vs_oracle"), float) else "n/a"))
                 if args.dtype == "bf16":
                     try:
                         line["fp16_plan"] = fp16_plan(args, size, images, keep, dev, nslot)

@@ -306,6 +306,8 @@ template <> int launch_conv_t<x3_t>(const h3d_op &op, const ConvArgs &a, hipStre
     if (op.ksize == 3 && op.stride == 1) {
         if (op.reserved & 0x1000) {
             switch (op.reserved & 0xfff) {
+            case 0x142: return launch_conv_cfg<x3_t, 3, 1, 1, 16, 16>(a, st);
+            case 0x182: return launch_conv_cfg<x3_t, 3, 1, 1, 16, 16, 8>(a, st);
             case 0x242: return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16>(a, st);
             case 0x282: return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16, 8>(a, st);
             case 0x482: return launch_conv_cfg<x3_t, 3, 1, 4, 16, 16, 8>(a, st);
@@ -316,18 +318,32 @@ template <> int launch_conv_t<x3_t>(const h3d_op &op, const ConvArgs &a, hipStre
         }
         // (tools/ab_conv_x3.py, batch 64, same process: 64 -> 64 @128x128 1.170 ms on 4-wave tiles vs 0.985 on 8-wave ones; 512 -> 512
         //  @16x16 0.639 on 64-channel tiles vs 0.566 on 128-channel ones although that grid is half a round of workgroups)
-        if (co <= 32) return launch_conv_cfg<x3_t, 3, 1, 1, 16, 16>(a, st);
+        if (co <= 32) return launch_conv_cfg<x3_t, 3, 1, 1, 16, 16, 8>(a, st);      // (16 -> 16 @512x512: 0.912 ms on 4-wave tiles, 0.773 on 8-wave ones)
         if (co <= 64) return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16, 8>(a, st);
         return launch_conv_cfg<x3_t, 3, 1, 4, 16, 16, 8>(a, st);
     }
     if (op.ksize == 3 && op.stride == 2) {
+        if (op.reserved & 0x1000) {         // tuning override (tools/ab_conv_x3.py --stride 2)
+            switch (op.reserved & 0xfff) {
+            case 0x282: return launch_conv_cfg<x3_t, 3, 2, 2, 16, 16, 8>(a, st);
+            case 0x182: return launch_conv_cfg<x3_t, 3, 2, 1, 16, 16, 8>(a, st);
+            case 0x141: return launch_conv_cfg<x3_t, 3, 2, 1, 16, 8>(a, st);
+            case 0x241: return launch_conv_cfg<x3_t, 3, 2, 2, 16, 8>(a, st);
+            default: H3D_FAIL(H3D_ERR_ARG, "conv (f16x3, stride 2): unknown tuning override %#x", op.reserved);
+            }
+        }
+        // (tools/ab_conv_x3.py --stride 2, batch 64, same process: 8-wave 16-row tiles against the f32 plan's 4-wave 8-row ones, which
+        //  leave ONE 4-wave workgroup on a CU: 32 -> 64 @256 0.357 -> 0.285 ms, 64 -> 128 0.303 -> 0.228, 128 -> 256 0.251 -> 0.191, 256 -> 512 0.219 -> 0.145)
         if (co <= 32) return launch_conv_cfg<x3_t, 3, 2, 1, 16, 8>(a, st);
-        return launch_conv_cfg<x3_t, 3, 2, 2, 16, 8>(a, st);
+        return launch_conv_cfg<x3_t, 3, 2, 2, 16, 16, 8>(a, st);
     }
     if (op.ksize == 1 && op.stride == 1) {
         // 64-channel chunks where the layer allows (Root convs over a concat: 128 ... 1280 input channels): a 16-channel chunk of a
         // 1x1 conv is two barriers and a global round trip for 2 * MT * NT * 3 MFMAs per wave (0x2000: tuning override, 16-channel chunks)
-        if (op.Cin % 64 == 0 && co > 32 && !(op.reserved & 0x2000)) return launch_conv_cfg<x3_t, 1, 1, 2, 64, 8>(a, st);      // (8-row tiles: 52 KB of LDS, three workgroups per CU)
+        // ... and 128-channel tiles above 64 output channels: a 64-channel tile walks the whole input once per channel block (tools/ab_conv_x3.py
+        // --ksize 1, batch 64: 448 -> 128 @64x64 0.218 -> 0.156 ms, 256 -> 128 0.144 -> 0.108, 896 -> 256 0.149 -> 0.126, 1280 -> 512 0.102 -> 0.080)
+        if (op.Cin % 64 == 0 && co > 64 && !(op.reserved & 0x6000)) return launch_conv_cfg<x3_t, 1, 1, 4, 64, 8>(a, st);
+        if (op.Cin % 64 == 0 && co > 32 && !(op.reserved & 0x2000)) return launch_conv_cfg<x3_t, 1, 1, 2, 64, 8>(a, st);      // (0x4000: force these for > 64 channels)      // (8-row tiles: 52 KB of LDS, three workgroups per CU)
         if (co <= 32) return launch_conv_cfg<x3_t, 1, 1, 1, 16, 16>(a, st);
         return launch_conv_cfg<x3_t, 1, 1, 2, 16, 16>(a, st);
     }

@@ -13,6 +13,10 @@ from bench import kernel_name
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--stride", type=int, default=1)
+ap.add_argument("--ksize", type=int, default=3)
+ap.add_argument("--min-cout", type=int, default=64)
+ap.add_argument("--codes", nargs="*", default=None)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 opt = Opt(input_h=512, input_w=512, smpl=True, dtype="f16x3")
@@ -21,9 +25,9 @@ det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.
 x = torch.from_numpy(synth.synth_image_batch(args.batch, 512, 512)).to(dev)
 det.run(x); torch.cuda.synchronize()
 plan = det.model.engine(dev).plan(args.batch, 512, 512)
-ops = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_CONV and op.ksize == 3 and op.stride == 1 and op.Cout >= 64]
+ops = [i for i, op in enumerate(plan.ops) if op.kind == _lib.OP_CONV and op.ksize == args.ksize and op.stride == args.stride and op.Cout >= args.min_cout]
 shapes = sorted({(plan.ops[i].Cin, plan.ops[i].Cout, plan.ops[i].H) for i in ops})
-codes = [0, 0x1242, 0x1282, 0x1482, 0x1441, 0x1241]
+codes = [int(c, 0) for c in args.codes] if args.codes else [0, 0x1242, 0x1282, 0x1482, 0x1441, 0x1241]
 ms = (ctypes.c_float * 1)()
 print("%-22s" % "Cin->Cout @H (n)" + "".join("%10s" % ("auto" if c == 0 else hex(c)) for c in codes))
 for sh in shapes:
