@@ -1083,7 +1083,7 @@ def main():
                             "%.3g (bf16: %.3g), top-k set overlap %.3f (bf16: %.3f), positional agreement %.3f (bf16: %.3f).  Which to run: "
                             "bf16 is the arithmetic north_star prices the roofline in and stays `value`; run fp16 when the ranking of the "
                             "peaks matters more than ~2 %% of throughput (the stored activations of DLA-34 stay far inside +-65504 and the fp16 "
-                            "epilogues saturate), and f32 (parity_mode) when indices must match the reference bit for bit."
+                            "epilogues saturate), and f16x3 (or f32: parity_mode) when indices must match the reference bit for bit."
                             % (f16["images_per_s"], f16["images_per_s"] / line["value"], im16["max_abs_head_err"], im["max_abs_head_err"],
                                im16["set_overlap"], im["set_overlap"], im16["agreement"], im["agreement"]))
         if extras:
