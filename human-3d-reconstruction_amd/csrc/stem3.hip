@@ -352,14 +352,17 @@ __global__ __launch_bounds__(512, 4) void stem3_kernel(Stem3Args a)   // 4 waves
     }
 }
 
+int h3d_launch_stem3x(const h3d_op &op, hipStream_t st);      // csrc/stem3x.hip: the f16x3 twin (fp32 storage, split-operand fp16 MFMAs)
+
 int h3d_launch_stem3(const h3d_op &op, hipStream_t st)
 {
     if (!op.in || !op.w || !op.bias || !op.out) H3D_FAIL(H3D_ERR_ARG, "stem3: null pointer");
-    if (op.dtype != H3D_BF16 && op.dtype != H3D_F16) H3D_FAIL(H3D_ERR_DTYPE, "stem3: bf16 / fp16 plans only (dtype %d)", op.dtype);
+    if (op.dtype != H3D_BF16 && op.dtype != H3D_F16 && op.dtype != H3D_F16X3) H3D_FAIL(H3D_ERR_DTYPE, "stem3: bf16 / fp16 / f16x3 plans only (dtype %d)", op.dtype);
     if (op.Cin != 3 || op.Cout != 32 || op.Ho != (op.H - 1) / 2 + 1 || op.Wo != (op.W - 1) / 2 + 1 || op.out_cs % 4 || op.out_cs < 32)
         H3D_FAIL(H3D_ERR_SHAPE, "stem3: expects 3 -> 16 -> 16 -> 32 channels, output %dx%d (got %d -> %d, %dx%d)", (op.H - 1) / 2 + 1,
                  (op.W - 1) / 2 + 1, op.Cin, op.Cout, op.Ho, op.Wo);
     if (((uintptr_t)op.bias & 15) || ((uintptr_t)op.w & 15)) H3D_FAIL(H3D_ERR_ARG, "stem3: weights / bias must be 16-byte aligned");
+    if (op.dtype == H3D_F16X3) return h3d_launch_stem3x(op, st);
     Stem3Args a;
     a.wproj = nullptr; a.bproj = nullptr; a.res_out = nullptr; a.res_cs = 0;
     const bool proj = op.in2 != nullptr;       // in2 = level2's residual map [B,Ho/2,Wo/2,in2_cs] (output); its filters follow level1's in w / bias

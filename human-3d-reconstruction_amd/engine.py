@@ -302,6 +302,29 @@ class PackedWeights:
             self.t[key] = (flat.contiguous().to(self.device), bias.contiguous().to(self.device))
         return self.t[key]
 
+    def stem3_x3(self):
+        """base_layer + level0 + level1 for csrc/stem3x.hip (f16x3 plans): the three banks of `stem3()` as float32-typed (hi | lo) fp16
+        terms per 8 k, each times its own power of two, and fp32 biases [16 | 16 | 32 | 2^-e0, 2^-e1, 2^-e2, 0]."""
+        key = ("stem3_x3",)
+        if key not in self.t:
+            w0, b0 = self._fold(self.sd["base.base_layer.0.weight"], None, "base.base_layer.1")
+            w1, b1 = self._fold(self.sd["base.level0.0.weight"], None, "base.level0.1")       # [16,16,3,3]
+            w2, b2 = self._fold(self.sd["base.level1.0.weight"], None, "base.level1.1")       # [32,16,3,3]
+            wp = torch.zeros(16, 7, 8, 4)
+            wp[:, :, :7, :3] = w0.permute(0, 2, 3, 1)                                           # [o][dy][dx][c], k = dx*4 + c
+            t0 = wp.reshape(16, 7, 32)
+            t1 = torch.zeros(5, 16, 2, 16)
+            w1t = w1.permute(0, 2, 3, 1).reshape(16, 9, 16)                                    # [o][tap][c]
+            for tap in range(9):
+                t1[tap // 2, :, tap % 2, :] = w1t[:, tap, :]
+            t1 = t1.reshape(5, 16, 32)
+            t2 = w2.permute(0, 2, 3, 1).reshape(32, 9, 16)
+            es = [x3_exp(t) for t in (t0, t1, t2)]
+            flat = torch.cat([x3_split(t * 2.0 ** e).reshape(-1) for t, e in zip((t0, t1, t2), es)])
+            bias = torch.cat([b0.float(), b1.float(), b2.float(), torch.tensor([2.0 ** -es[0], 2.0 ** -es[1], 2.0 ** -es[2], 0.0])])
+            self.t[key] = (flat.contiguous().to(self.device), bias.contiguous().to(self.device))
+        return self.t[key]
+
     def offset_conv(self, wkey, bkey, main_rows):
         """conv_offset_mask packed for the fused DeformConv kernel (csrc/dcn3.hip): the 27 filters are
         spread over 32 MFMA rows so that accumulator half h of a pixel owns whole (dh, dw, mask)
@@ -720,7 +743,15 @@ class Plan:
     def _lower(self):
         B, H, W = self.B, self.H, self.W
         C = arch.CHANNELS
-        if self.fuse_stem and self.pw.dtype in LOWP and C[0] == 16 and C[1] == 32:
+        if self.fuse_stem and self.pw.dtype == "f16x3" and C[0] == 16 and C[1] == 32:
+            # the f16x3 twin of the fused stem (csrc/stem3x.hip): the two full-resolution maps stay in LDS as split operand fragments
+            y0 = None
+            y1 = self._alloc((H - 1) // 2 + 1, (W - 1) // 2 + 1, C[1])
+            w, b = self.pw.stem3_x3()
+            self._op(_lib.OP_STEM3, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=y1.ptr, H=H, W=W,
+                     Cin=3, in_cs=3, Ho=y1.H, Wo=y1.W, Cout=C[1], out_cs=y1.cs, ksize=7, stride=2, relu=1)
+            res2 = None
+        elif self.fuse_stem and self.pw.dtype in LOWP and C[0] == 16 and C[1] == 32:
             # base_layer + level0 + level1 in one launch: the two full-resolution maps never reach HBM (nothing else
             # reads them: DLAUp starts at level 2)
             y0 = None

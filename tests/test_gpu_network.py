@@ -573,23 +573,26 @@ def test_dense_dcn3_matches_register_staged(offset_scale, tol):
         assert e_ref <= max(BF16_TOL, 1.5 * e_off), (k, e_ref, e_off)
 
 
-def test_fused_stem_levels_match_three_launches():
+@pytest.mark.parametrize("dtype,tol", [("bf16", 3e-2), ("f16x3", 2e-4)])
+def test_fused_stem_levels_match_three_launches(dtype, tol):
     # csrc/stem3.hip (base_layer + level0 + level1 in one kernel, intermediates in LDS) vs the three separate
-    # launches: the same bf16 rounding points, only the fp32 summation order inside the MFMA chains differs
-    m, _ = _net(False, "bf16")
+    # launches: the same bf16 rounding points, only the fp32 summation order inside the MFMA chains differs.
+    # f16x3 (csrc/stem3x.hip): the intermediates are split by the lane that produced them exactly as the consumer's staging would split
+    # the stored fp32 value -- the same numbers, another accumulation order: fp32-level agreement
+    m, _ = _net(False, dtype)
     xs = torch.from_numpy(synth.synth_images(3, 96, 160, seed=37)).to(DEV)      # ragged 8x16 tiles on both axes
     on, off = _ab(m, xs, "fuse_stem")
     from h3d_amd import _lib
     assert _lib.OP_STEM3 in [op.kind for op in m.engine(xs.device).plan(3, 96, 160).ops]
     for k in HEADS:
         e = float((on[k] - off[k]).abs().max())
-        assert e <= 3e-2, (k, e)
+        assert e <= tol, (k, e)
     # a single tile row / narrow image
     xs = torch.from_numpy(synth.synth_images(1, 32, 224, seed=41)).to(DEV)
     on, off = _ab(m, xs, "fuse_stem")
     for k in HEADS:
         e = float((on[k] - off[k]).abs().max())
-        assert e <= 3e-2, (k, e)
+        assert e <= tol, (k, e)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
