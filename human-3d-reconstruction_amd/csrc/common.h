@@ -176,12 +176,14 @@ template <> struct ET<f16_t> {
 // DLA-34 / Hourglass / ResNet feature map holds.
 struct x3_t { float v; };          // element type tag: 4 bytes of fp32 in memory
 // 4 fp32 (16 raw bytes) -> their 4 hi and 4 lo fp16 terms
+// (CLAMP = false: the caller knows |x| <= 65504 already -- a DeformConv sample blended from clamped apron values)
+template <bool CLAMP = true>
 __device__ __forceinline__ void x3_split4(const u32x4 raw, u32x2 &hi, u32x2 &lo)
 {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const float a = __builtin_amdgcn_fmed3f(__uint_as_float(raw[2 * p]), -65504.f, 65504.f);
-        const float b = __builtin_amdgcn_fmed3f(__uint_as_float(raw[2 * p + 1]), -65504.f, 65504.f);
+        const float a = CLAMP ? __builtin_amdgcn_fmed3f(__uint_as_float(raw[2 * p]), -65504.f, 65504.f) : __uint_as_float(raw[2 * p]);
+        const float b = CLAMP ? __builtin_amdgcn_fmed3f(__uint_as_float(raw[2 * p + 1]), -65504.f, 65504.f) : __uint_as_float(raw[2 * p + 1]);
         const _Float16 ha = (_Float16)a, hb = (_Float16)b;
         const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
         hi[p] = __builtin_bit_cast(uint32_t, f16x2_t{ha, hb});
@@ -215,12 +217,13 @@ template <> struct ET<x3_t> {
         return f;
     }
     // 8 fp32 values held in registers (a blended DeformConv sample, a ReLU-ed accumulator slab) -> operand fragment
+    template <bool CLAMP = true>
     static __device__ __forceinline__ frag split8(const float (&x)[8])
     {
         frag f;
         u32x2 h0, l0, h1, l1;
-        x3_split4(u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])}, h0, l0);
-        x3_split4(u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])}, h1, l1);
+        x3_split4<CLAMP>(u32x4{__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3])}, h0, l0);
+        x3_split4<CLAMP>(u32x4{__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7])}, h1, l1);
         f.hi = u32x4{h0[0], h0[1], h1[0], h1[1]};
         f.lo = u32x4{l0[0], l0[1], l1[0], l1[1]};
         return f;

@@ -147,6 +147,40 @@ __global__ __launch_bounds__(64 * WAVES) void conv_kernel(ConvArgs a)
         __syncthreads();
         if (c0 + CK < a.Cin) load_stage(c0 + CK);
         // ---- contraction over this chunk: taps x CK/16 k-steps -------------------------------------
+        if constexpr (std::is_same_v<T, x3_t> && KS == 3 && CK == 16 && (MT + C::NT) * 16 + MT * C::NT * 16 <= 176) {
+            // f16x3: left to itself hipcc reads ONE 16-byte fragment half, waits for it (lgkmcnt(0)) and issues one or two MFMAs -- an LDS
+            // round trip exposed per 48-96 matrix cycles, 2 waves a SIMD to cover it (SQ counters: pipe 0.43 busy, waves parked 0.53 of
+            // the time).  Two fragment sets: tap t+1 is read while tap t multiplies, the order pinned by sched_group_barrier.
+            typename E::frag fa[2][MT], fb[2][C::NT];
+            auto rd = [&](int tap, int q) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n) fb[q][n] = E::lds_frag(s_in + boff[n] + dy * C::RB + dx * C::SB);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[q][m] = E::lds_frag(s_w + aoff + m * 32 * C::WB + tap * CK * ES);
+            };
+            constexpr int NRD = 2 * (MT + C::NT), NMM = 3 * MT * C::NT;
+            rd(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) rd(tap + 1, (tap + 1) & 1);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < C::NT; ++n) E::mma(acc[m][n], fa[tap & 1][m], fb[tap & 1][n]);
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int i = 0; i < NRD; ++i) {      // one fragment read behind each of the first MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int tap = 0; tap < KS * KS; ++tap) {
             const int dy = tap / KS, dx = tap - dy * KS;
@@ -313,6 +347,8 @@ template <> int launch_conv_t<x3_t>(const h3d_op &op, const ConvArgs &a, hipStre
             case 0x482: return launch_conv_cfg<x3_t, 3, 1, 4, 16, 16, 8>(a, st);
             case 0x441: return launch_conv_cfg<x3_t, 3, 1, 4, 16, 8>(a, st);
             case 0x241: return launch_conv_cfg<x3_t, 3, 1, 2, 16, 8>(a, st);
+            case 0x484: return launch_conv_cfg<x3_t, 3, 1, 4, 16, 32, 8>(a, st);      // two N-tiles per wave: a filter fragment feeds 6 MFMAs
+            case 0x284: return launch_conv_cfg<x3_t, 3, 1, 2, 16, 32, 8>(a, st);
             default: H3D_FAIL(H3D_ERR_ARG, "conv (f16x3): unknown tuning override %#x", op.reserved);
             }
         }
@@ -320,6 +356,9 @@ template <> int launch_conv_t<x3_t>(const h3d_op &op, const ConvArgs &a, hipStre
         //  @16x16 0.639 on 64-channel tiles vs 0.566 on 128-channel ones although that grid is half a round of workgroups)
         if (co <= 32) return launch_conv_cfg<x3_t, 3, 1, 1, 16, 16, 8>(a, st);      // (16 -> 16 @512x512: 0.912 ms on 4-wave tiles, 0.773 on 8-wave ones)
         if (co <= 64) return launch_conv_cfg<x3_t, 3, 1, 2, 16, 16, 8>(a, st);
+        // (two N-tiles per wave on 64-channel tiles against one on 128-channel tiles, both with the pipelined fragment reads: 128 -> 128
+        //  @64x64 1.656 -> 1.609 ms for the seven launches, 256 -> 256 @32x32 1.383 -> 1.331; 32-row tiles on a 16-row map: 0.54 -> 0.87)
+        if (a.Ho % 32 == 0) return launch_conv_cfg<x3_t, 3, 1, 2, 16, 32, 8>(a, st);
         return launch_conv_cfg<x3_t, 3, 1, 4, 16, 16, 8>(a, st);
     }
     if (op.ksize == 3 && op.stride == 2) {

@@ -502,7 +502,8 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
         if constexpr (SS == 4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                o[e] = __float_as_uint(fmaf(g.w[3], __uint_as_float(c[3][e]), fmaf(g.w[2], __uint_as_float(c[2][e]), fmaf(g.w[1], __uint_as_float(c[1][e]), g.w[0] * __uint_as_float(c[0][e])))));
+                o[e] = __float_as_uint(__builtin_amdgcn_fmed3f(fmaf(g.w[3], __uint_as_float(c[3][e]), fmaf(g.w[2], __uint_as_float(c[2][e]), fmaf(g.w[1], __uint_as_float(c[1][e]), g.w[0] * __uint_as_float(c[0][e])))),
+                                                               -65504.f, 65504.f));      // (the slot is read by X::prep, which does not clamp)
         }
         return o;
     };
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[k].v = __builtin_bit_cast(half8_t, X::convert16(pv[j][k][0]));
                         }
-                        fbs[j] = X::prep(X::blend(v, qg[t0 + j]));
+                        fbs[j] = X::prep_raw(X::blend(v, qg[t0 + j]));
                     }
                     if (t0 + TB < 9) fetch(t0 + TB);                               // the next taps fly while these are multiplied
 #pragma unroll
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
                     typename X::wfrag fa[MT];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
-                    const typename X::bfrag pb = X::prep(fb[kk]);
+                    const typename X::bfrag pb = X::prep_raw(fb[kk]);
 #pragma unroll
                     for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], pb);
                 }

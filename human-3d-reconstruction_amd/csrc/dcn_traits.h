@@ -28,6 +28,7 @@ template <> struct SE<float> {
     using bfrag = frag;
     static __device__ __forceinline__ wfrag lds_w(const char *p) { return lds(p); }
     static __device__ __forceinline__ bfrag prep(const frag &f) { return f; }
+    static __device__ __forceinline__ bfrag prep_raw(const frag &f) { return f; }
     // apron fragment of the OFFSET convolution (phase A of csrc/dcn3.hip), ready for the MFMA
     static __device__ __forceinline__ bfrag lds_a(const char *p) { return lds(p); }
     static constexpr bool SPLIT_A = false;
@@ -99,6 +100,7 @@ template <> struct SE<bf16_t> {
     using bfrag = frag;
     static __device__ __forceinline__ wfrag lds_w(const char *p) { return lds(p); }
     static __device__ __forceinline__ bfrag prep(const frag &f) { return f; }
+    static __device__ __forceinline__ bfrag prep_raw(const frag &f) { return f; }
     // apron fragment of the OFFSET convolution (phase A of csrc/dcn3.hip), ready for the MFMA
     static __device__ __forceinline__ bfrag lds_a(const char *p) { return lds(p); }
     static constexpr bool SPLIT_A = false;
@@ -191,10 +193,25 @@ template <> struct SE<x3_t> : SE<float> {
     using wfrag = ET<x3_t>::frag;
     using bfrag = ET<x3_t>::frag;
     static __device__ __forceinline__ wfrag lds_w(const char *p) { return ET<x3_t>::lds_frag(p); }
+    // prep: a sample blended from values that went through convert16 (clamped to the fp16 range while staging: a convex combination
+    // times a mask in (0, 1) stays inside it), so the split needs no clamp of its own -- 8 of its 28 vector instructions, nine times per
+    // staged element.  prep_raw: a sample blended from values read straight from memory (pass 2).
     static __device__ __forceinline__ bfrag prep(const frag &f)
     {
         const float x[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
-        return ET<x3_t>::split8(x);
+        return ET<x3_t>::split8<false>(x);
+    }
+    static __device__ __forceinline__ bfrag prep_raw(const frag &f)
+    {
+        const float x[8] = {f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
+        return ET<x3_t>::split8<true>(x);
+    }
+    static __device__ __forceinline__ u32x4 convert16(u32x4 raw)
+    {
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __float_as_uint(__builtin_amdgcn_fmed3f(__uint_as_float(raw[i]), -65504.f, 65504.f));
+        return o;
     }
     // phase A only multiplies the apron (no blend), so the thread that stages a phase-A chunk stores it already split (x3_store4:
     // once per element) and the nine taps read finished operand fragments; phase B stages the same chunk again as plain fp32

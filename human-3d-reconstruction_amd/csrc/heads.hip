@@ -417,6 +417,47 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                 } else {
                     plain();
                 }
+                } else if constexpr (std::is_same_v<T, x3_t>) {
+                    // f16x3: one tap x 64 channels per stage = 4 steps of (2 filter + NT pixel fragments, 32 bytes each) feeding 6 NT
+                    // MFMAs.  Two fragment sets, step k+1 read while step k multiplies (the compiler's own schedule: two 16-byte reads,
+                    // lgkmcnt(0), three MFMAs); the fragments are plain loads here, the order is pinned by sched_group_barrier
+                    const int dy = tr / 3, dx = tr - dy * 3;
+                    const char *br = s_in + dy * C::RB + dx * C::SB;
+                    typename E::frag fa[2][2], fb[2][NT];
+                    auto rd = [&](int kk, int q) {
+                        const int c = (kk * 16 + 8 * h) * ES / 16;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const char *row = slot + (m * 32 + r) * C::RBW;
+                            fa[q][m] = E::lds_frag2(row + ((c ^ sw) << 4), row + (((c + 1) ^ sw) << 4));
+                        }
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) fb[q][n] = E::lds_frag(br + boff[n] + kk * 16 * ES);
+                    };
+                    constexpr int NRD = 2 * (2 + NT), NMM = 6 * NT;
+                    rd(0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll
+                    for (int kk = 0; kk < HC_IN / 16; ++kk) {
+                        if (kk + 1 < HC_IN / 16) rd(kk + 1, (kk + 1) & 1);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n) {
+                                if (FIRST && kk == 0) { load_bias(acc[m][n], m); }
+                                E::mma(acc[m][n], fa[kk & 1][m], fb[kk & 1][n]);
+                            }
+                        if (kk + 1 < HC_IN / 16) {
+#pragma unroll
+                            for (int i = 0; i < (NRD < NMM ? NRD : NMM); ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            }
+                            if (NMM > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMM - NRD, 0);
+                        } else {
+                            __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
+                        }
+                    }
                 } else {
                     plain();
                 }

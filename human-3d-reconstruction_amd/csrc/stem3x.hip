@@ -30,7 +30,8 @@ constexpr int S3X_SH = 19, S3X_SW = 35, S3X_LH = 17, S3X_LW = 33;
 constexpr int S3X_PX = 80;                               // bytes per pixel of S and L0
 constexpr int S3X_LDS_I = S3X_IH * S3X_IW * 8;           // one of the two image tiles
 constexpr int S3X_LDS_S = (S3X_SH * S3X_SW + 1) * S3X_PX, S3X_LDS_L = (S3X_LH * S3X_LW + 1) * S3X_PX;
-constexpr int S3X_LDS = 2 * S3X_LDS_I + S3X_LDS_S + S3X_LDS_L;
+constexpr int S3X_LDS = 2 * S3X_LDS_I + S3X_LDS_S + S3X_LDS_L + 128;      // + level1's 32 biases (read in P3 only: 16 registers less to hold)
+constexpr int S3X_NPF = (S3X_IH * S3X_IW + 511) / 512;                   // image-patch items per thread (3)
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_s3x;
 
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(512, 2) void stem3x_kernel(Stem3xArgs a)
     __shared__ __attribute__((aligned(16))) char smem[S3X_LDS];
     uint2 *s_ih = reinterpret_cast<uint2 *>(smem), *s_il = reinterpret_cast<uint2 *>(smem + S3X_LDS_I);
     char *s_s = smem + 2 * S3X_LDS_I, *s_l = s_s + S3X_LDS_S;
+    float *s_b2 = reinterpret_cast<float *>(s_l + S3X_LDS_L);
 
     const int tid = threadIdx.x, l = tid & 63, p = l & 15, q = l >> 4, r = l & 31, h = l >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,36 +76,53 @@ __global__ __launch_bounds__(512, 2) void stem3x_kernel(Stem3xArgs a)
         f2h[tap] = *reinterpret_cast<const u32x4 *>(g);
         f2l[tap] = *reinterpret_cast<const u32x4 *>(g + 16);
     }
-    float b0[4], b1[4], b2[16];
+    float b0[4], b1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { b0[i] = a.bias[4 * q + i]; b1[i] = a.bias[16 + 4 * q + i]; }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) b2[i] = a.bias[32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+    if (tid < 32) s_b2[tid] = a.bias[32 + tid];
     const float s0 = a.bias[64], s1 = a.bias[65], s2 = a.bias[66];
 
-    for (int ti = blockIdx.x * a.tpb; ti < min((int)(blockIdx.x + 1) * a.tpb, ntile); ++ti) {
+    // image patch of tile `ti` -> registers (three fp32 planes of up to S3X_NPF pixels per thread): issued while the previous tile
+    // computes, so that a tile does not start with an exposed global round trip (the first version did: 1.15 ms for the launch)
+    float pf[S3X_NPF][3];
+    auto load_patch = [&](int ti) {
+        const int pb = ti / tiles, pt = ti - pb * tiles;
+        const int pty = pt / a.tiles_x, ptx = pt - pty * a.tiles_x;
+        const int piy0 = 2 * (pty * 8) - 5, pix0 = 2 * (ptx * 16) - 5;
+        const float *im = a.img + (size_t)pb * 3 * plane;
+#pragma unroll
+        for (int j = 0; j < S3X_NPF; ++j) {
+            const int i = tid + j * 512;
+            const int iy = i / S3X_IW, ix = i - iy * S3X_IW;
+            const int gy = piy0 + iy, gx = pix0 + ix;
+            pf[j][0] = pf[j][1] = pf[j][2] = 0.f;
+            if (ti < ntile && i < S3X_IH * S3X_IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < 41) {
+                const size_t o = (size_t)gy * a.W + gx;
+                pf[j][0] = im[o]; pf[j][1] = im[plane + o]; pf[j][2] = im[2 * plane + o];
+            }
+        }
+    };
+    const int t_first = blockIdx.x * a.tpb, t_end = min((int)(blockIdx.x + 1) * a.tpb, ntile);
+    load_patch(t_first);
+    for (int ti = t_first; ti < t_end; ++ti) {
         const int b = ti / tiles, t = ti - b * tiles;
         const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
         const int oy0 = ty * 8, ox0 = tx * 16;                    // level1 tile origin
         const int ly0 = 2 * oy0 - 1, lx0 = 2 * ox0 - 1;           // level0 region origin (full resolution)
-        const int sy0 = ly0 - 1, sx0 = lx0 - 1;                   // stem region origin
-        const int iy0 = sy0 - 3, ix0 = sx0 - 3;                   // image patch origin
-        // ---- P0: image patch, split ----------------------------------------------------------------------------------------
-        const float *im = a.img + (size_t)b * 3 * plane;
-        for (int i = tid; i < S3X_IH * S3X_IW; i += 512) {
-            const int iy = i / S3X_IW, ix = i - iy * S3X_IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            u32x4 raw = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ix < 41) {
-                const size_t o = (size_t)gy * a.W + gx;
-                raw = u32x4{__float_as_uint(im[o]), __float_as_uint(im[plane + o]), __float_as_uint(im[2 * plane + o]), 0u};
+        const int sy0 = ly0 - 1, sx0 = lx0 - 1;                   // stem region origin (the image patch starts 3 pixels further out)
+        // ---- P0: image patch (prefetched), split -> LDS -------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < S3X_NPF; ++j) {
+            const int i = tid + j * 512;
+            if (i < S3X_IH * S3X_IW) {
+                u32x2 hi, lo;
+                x3_split4(u32x4{__float_as_uint(pf[j][0]), __float_as_uint(pf[j][1]), __float_as_uint(pf[j][2]), 0u}, hi, lo);
+                s_ih[i] = uint2{hi[0], hi[1]};
+                s_il[i] = uint2{lo[0], lo[1]};
             }
-            u32x2 hi, lo;
-            x3_split4(raw, hi, lo);
-            s_ih[i] = uint2{hi[0], hi[1]};
-            s_il[i] = uint2{lo[0], lo[1]};
         }
         __syncthreads();
+        load_patch(ti + 1);                                       // (ti + 1 == ntile or the next workgroup's tile: loads nothing / is not used)
         // ---- P1: stem -> S ---------------------------------------------------------------------------------------------------
         for (int g = wv; g < (S3X_SH * S3X_SW + 15) / 16; g += 8) {
             const int f = min(16 * g + p, S3X_SH * S3X_SW - 1);
@@ -162,9 +181,11 @@ __global__ __launch_bounds__(512, 2) void stem3x_kernel(Stem3xArgs a)
             if (oy < a.Ho && ox < a.Wo) {
                 float *op = a.out + ((size_t)(b * a.Ho + oy) * a.Wo + ox) * a.out_cs + 4 * h;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)        // accumulator registers 4g .. 4g+3 = channels 8g + 4h .. + 3
-                    store4<float>(op + 8 * g4, fmaxf(fmaf(acc[4 * g4 + 0], s2, b2[4 * g4 + 0]), 0.f), fmaxf(fmaf(acc[4 * g4 + 1], s2, b2[4 * g4 + 1]), 0.f),
-                                  fmaxf(fmaf(acc[4 * g4 + 2], s2, b2[4 * g4 + 2]), 0.f), fmaxf(fmaf(acc[4 * g4 + 3], s2, b2[4 * g4 + 3]), 0.f));
+                for (int g4 = 0; g4 < 4; ++g4) {      // accumulator registers 4g .. 4g+3 = channels 8g + 4h .. + 3
+                    const f32x4 bb = *reinterpret_cast<const f32x4 *>(s_b2 + 8 * g4 + 4 * h);
+                    store4<float>(op + 8 * g4, fmaxf(fmaf(acc[4 * g4 + 0], s2, bb[0]), 0.f), fmaxf(fmaf(acc[4 * g4 + 1], s2, bb[1]), 0.f),
+                                  fmaxf(fmaf(acc[4 * g4 + 2], s2, bb[2]), 0.f), fmaxf(fmaf(acc[4 * g4 + 3], s2, bb[3]), 0.f));
+                }
             }
         }
         // (no barrier here: the next tile's P0 writes the image tiles, last read in P1; its P1 writes S, last read in P2 -- both behind
