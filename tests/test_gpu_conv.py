@@ -38,6 +38,7 @@ CONV_CASES = [
     (2, 128, 64, 24, 24, 1, 1, True, False),    # level2 root (Cin % 64 == 0, <= 64 channels: 8-row tiles)
     (1, 32, 64, 40, 24, 3, 2, True, False),     # level2 tree1.conv1 (stride 2 below 64 input channels stays on conv.hip)
     (1, 128, 256, 24, 24, 3, 2, True, False),   # stride 2, 128-channel workgroups
+    (1, 128, 192, 32, 40, 3, 1, True, True),    # f16x3: 32-row tiles (two N-tiles per wave, 64-channel blocks), partial tile in x
 ]
 
 

@@ -548,6 +548,28 @@ def test_dma_filter_dcn3_matches_register_staged(offset_scale, tol):
         assert e <= tol, (k, e)
 
 
+def test_node_f16_plan_error_is_not_above_the_bf16_node_plan():
+    # engine.node_f16 (default on, bf16 plans): the up-sample + add launches write the `node` DeformConvs' inputs as fp16 instead of
+    # bf16 (three more mantissa bits on the tensors whose rounding the heads see most directly).  Whole network, both settings against
+    # the fp32 oracle: the flag must not cost precision on any head (it had a kernel-level case only)
+    from h3d_amd import _lib
+    sd = synth.synth_state_dict(arch.state_dict_shapes(HEADS, True), seed=0)
+    m = model.dla_net(HEADS, not_use_dcn=False, dtype="bf16")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(DEV).eval()
+    x = synth.synth_images(2, 96, 160, seed=37)
+    xs = torch.from_numpy(x).to(DEV)
+    eng = m.engine(xs.device)
+    on, off = _ab(m, xs, "node_f16")
+    assert _lib.OUT_NHWC_F16 in [op.out_mode for op in eng.plan(2, 96, 160).ops]      # the flag is live in this plan
+    with torch.no_grad():
+        ref = odla.DLAOracle(sd, HEADS, use_dcn=True)(torch.from_numpy(x))[0]
+    for k in HEADS:
+        e_on = float(((on[k].cpu() - ref[k]) ** 2).mean().sqrt())
+        e_off = float(((off[k].cpu() - ref[k]) ** 2).mean().sqrt())
+        assert e_on <= 1.1 * e_off + 1e-4, (k, e_on, e_off)
+
+
 @pytest.mark.parametrize("offset_scale,tol", [(0.5, 6e-2), (3.0, 0.1), (12.0, 0.25)])
 def test_dense_dcn3_matches_register_staged(offset_scale, tol):
     # the default for DeformConvs with <= 64 output channels: csrc/dcn3.hip with DMA'd filters, a margin-1 apron and
