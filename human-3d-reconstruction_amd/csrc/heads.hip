@@ -418,6 +418,8 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadsArgs a)
                     plain();
                 }
                 } else if constexpr (std::is_same_v<T, x3_t>) {
+                    // (a third ring slot for the one-tile heads -- the 64 rows of the 1x1 slice they never read pay for it --, filters two
+                    //  stages ahead behind counted vmcnt waits: 4.364 -> 4.381 ms, tools/ab_lib.py; the one-tap stages do not wait for their DMA)
                     // f16x3: one tap x 64 channels per stage = 4 steps of (2 filter + NT pixel fragments, 32 bytes each) feeding 6 NT
                     // MFMAs.  Two fragment sets, step k+1 read while step k multiplies (the compiler's own schedule: two 16-byte reads,
                     // lgkmcnt(0), three MFMAs); the fragments are plain loads here, the order is pinned by sched_group_barrier
