@@ -349,6 +349,16 @@ int h3d_launch_conv_stream(const h3d_op &op, hipStream_t st)
     if (gq >= 4) {
         if (op.Ho % 32 == 0 && nblk(32, 4) >= 256) return launch_conv2_cfg<4, 16, 1, 2, 1, true>(a, st);   // 16 waves: 32 x 16 px share one weight stream
         if (nblk(16, 4) >= 256) return launch_conv2_cfg<4, 8, 1, 2, 1, true>(a, st);
+        // grids that leave CUs idle at 128 channels per workgroup (the deep levels of Hourglass-104 at 16 images per GPU, DLA's level 5
+        // in an 8-image shard): narrower channel blocks.  Such a launch is a chain of Cin / 16 DMA round trips per workgroup whatever its
+        // width, so more, smaller workgroups per CU is what hides them (tools/arch_kernels.py hourglass --codes ..., batch 16, same process:
+        // 384 -> 384 @32x32 1.166 -> 0.846 ms for the 18 launches on <2,8>; @16x16 0.708 -> 0.421, @8x8 0.685 -> 0.337 on <1,4>;
+        // 512 -> 512 @4x4 1.041 -> 0.559 for the 26 launches)
+        if (!(op.reserved & 0x10000000)) {          // (0x10000000: round 4's rule, 128-channel 8-row tiles, for A/B runs)
+            if (nblk(16, 2) >= 256) return launch_conv2_cfg<2, 8, 1, 2, 1, true>(a, st);
+            if (nblk(16, 1) >= 256) return launch_conv2_cfg<1, 8>(a, st);
+            return launch_conv2_cfg<1, 4>(a, st);
+        }
         return launch_conv2_cfg<4, 4>(a, st);
     }
     if (gq >= 2) {
