@@ -363,6 +363,10 @@ int h3d_launch_stem3(const h3d_op &op, hipStream_t st)
                  (op.W - 1) / 2 + 1, op.Cin, op.Cout, op.Ho, op.Wo);
     if (((uintptr_t)op.bias & 15) || ((uintptr_t)op.w & 15)) H3D_FAIL(H3D_ERR_ARG, "stem3: weights / bias must be 16-byte aligned");
     if (op.dtype == H3D_F16X3) return h3d_launch_stem3x(op, st);
+    // the image patch is fetched as aligned float4 (load_patch): a row must be whole vectors, or a vector straddles the right edge (and
+    // the last one of the batch the end of the buffer).  csrc/stem3x.hip loads single pixels and takes any width.
+    if (op.W % 4 || ((uintptr_t)op.in & 15))
+        H3D_FAIL(H3D_ERR_SHAPE, "stem3: the 2-byte kernel needs an image width that is a multiple of 4 and a 16-byte aligned image (W = %d)", op.W);
     Stem3Args a;
     a.wproj = nullptr; a.bproj = nullptr; a.res_out = nullptr; a.res_cs = 0;
     const bool proj = op.in2 != nullptr;       // in2 = level2's residual map [B,Ho/2,Wo/2,in2_cs] (output); its filters follow level1's in w / bias

@@ -751,7 +751,8 @@ class Plan:
             self._op(_lib.OP_STEM3, in_=self.images.data_ptr(), w=w.data_ptr(), bias=b.data_ptr(), out=y1.ptr, H=H, W=W,
                      Cin=3, in_cs=3, Ho=y1.H, Wo=y1.W, Cout=C[1], out_cs=y1.cs, ksize=7, stride=2, relu=1)
             res2 = None
-        elif self.fuse_stem and self.pw.dtype in LOWP and C[0] == 16 and C[1] == 32:
+        elif self.fuse_stem and self.pw.dtype in LOWP and C[0] == 16 and C[1] == 32 and W % 4 == 0:
+            # (W % 4: csrc/stem3.hip reads the image as aligned float4; any other width takes the three launches)
             # base_layer + level0 + level1 in one launch: the two full-resolution maps never reach HBM (nothing else
             # reads them: DLAUp starts at level 2)
             y0 = None

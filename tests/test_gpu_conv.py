@@ -294,3 +294,45 @@ def test_error_codes_raise():
     w = rnd("w", (16, 16, 5, 5))
     with pytest.raises(RuntimeError, match="not covered"):
         conv(x, w, None, "bf16")
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 64), (1, 45, 72), (1, 45, 70), (3, 16, 32), (1, 130, 34), (1, 131, 36)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x3"])
+def test_fused_stem_op_matches_torch(dtype, shape):
+    """H3D_OP_STEM3 on its own (csrc/stem3.hip; f16x3: csrc/stem3x.hip): base_layer 7x7 3->16 + BN + ReLU -> level0 3x3 16->16 + BN + ReLU ->
+    level1 3x3 stride 2 16->32 + BN + ReLU (model.py:231-249) against the same chain in fp64 on the CPU, on shapes the network never
+    hands it: odd heights / widths, ragged 8 x 16 tiles, a single tile, a narrow tall image.  The 2-byte kernel reads the image as aligned
+    float4 and must REFUSE a width that is not a multiple of 4 (this test found it computing the right edge from the next row's pixels
+    instead: the launcher had no such check); the f16x3 kernel takes any width."""
+    from gpu_helpers import fake_pw, mk, run
+    B, H, W = shape
+    sd = {}
+    for name, (co, ci, k) in (("base.base_layer", (16, 3, 7)), ("base.level0", (16, 16, 3)), ("base.level1", (32, 16, 3))):
+        sd[name + ".0.weight"] = rnd(name + "w", (co, ci, k, k)) * (1.8 / np.sqrt(ci * k * k))
+        sd[name + ".1.weight"] = rnd(name + "g", (co,), 0.6, 1.4)
+        sd[name + ".1.bias"] = rnd(name + "b", (co,), -0.3, 0.3)
+        sd[name + ".1.running_mean"] = rnd(name + "m", (co,), -0.2, 0.2)
+        sd[name + ".1.running_var"] = rnd(name + "v", (co,), 0.5, 1.5)
+    pw = fake_pw(sd, dtype)
+    x = rnd("img", (B, 3, H, W), -2.0, 2.0)
+    wdev, bdev = pw.stem3_x3() if dtype == "f16x3" else pw.stem3()
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    img = x.to(DEV).contiguous()
+    out = torch.full((B, Ho, Wo, 32), float("nan"), dtype=TD[dtype], device=DEV)
+    op = mk(_lib.OP_STEM3, dtype, in_=img.data_ptr(), w=wdev.data_ptr(), bias=bdev.data_ptr(), out=out.data_ptr(), B=B, H=H, W=W, Cin=3,
+            in_cs=3, Ho=Ho, Wo=Wo, Cout=32, out_cs=32, ksize=7, stride=1, relu=1)
+    if dtype != "f16x3" and W % 4:
+        with pytest.raises(RuntimeError, match="multiple of 4"):
+            run(op)
+        return
+    run(op)
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    assert bool(torch.isfinite(got).all())
+    t = x.double()
+    for name, (k, s) in (("base.base_layer", (7, 1)), ("base.level0", (3, 1)), ("base.level1", (3, 2))):
+        w, b = pw._fold(sd[name + ".0.weight"], None, name + ".1")
+        if dtype != "f16x3":                    # the 2-byte plans round the image, the folded filters and both intermediates
+            w, t = lowp_round(w, dtype), lowp_round(t.float(), dtype).double()
+        t = F.relu(F.conv2d(t, w.double(), b.double(), s, k // 2))
+    tol = {"bf16": 2e-2, "f16": 3e-3, "f16x3": 2e-5}[dtype] * max(1.0, float(t.abs().max()))
+    assert float((got.double() - t).abs().max()) <= tol, (dtype, shape, float((got.double() - t).abs().max()), tol)
