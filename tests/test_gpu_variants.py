@@ -55,6 +55,16 @@ CONV2_CASES = [
     (0, 32, 32, 128, 64, 64, 1, True, True, 0, 0),         # level3/4 class: 256 tiles of 32 x 16 px -> <4,16>
     (0, 24, 32, 128, 48, 64, 1, True, True, 0, 0),         # level5 class: H not a multiple of 32 -> <4,8>
     (0, 4, 64, 64, 128, 128, 1, True, True, 0, 0),         # level2 class -> <2,8>
+    # round 5: grids too small for 128-channel tiles (deep Hourglass levels, small DLA shards) take narrower channel blocks
+    (0, 16, 128, 256, 4, 4, 1, True, False, 0, 0),         # 4 x 4 maps: <1,4>, 8 channel blocks per image
+    (0, 16, 256, 256, 8, 8, 1, True, True, 0, 0),          # 8 x 8 maps: <1,8> (256 workgroups of 32 channels on 16-row tiles)
+    (0, 16, 128, 384, 32, 32, 1, True, True, 0, 0),        # 32 x 32 maps, 16 images: <2,8,PIPE>
+    (0x10000000, 16, 128, 256, 4, 4, 1, True, False, 0, 0),  # ... round 4's rule on the same tensor: <4,4>
+    # odd sizes (the C ABI takes any H, W)
+    (0, 2, 128, 128, 13, 21, 1, True, True, 0, 0),
+    (0, 1, 64, 64, 7, 5, 1, False, False, 0, 0),           # smaller than one tile both ways
+    (0, 1, 64, 128, 11, 19, 2, True, False, 0, 0),         # stride 2, odd input: 6 x 10 outputs
+    (0, 3, 128, 256, 5, 7, 2, True, True, 0, 0),           # stride 2, 3 x 4 outputs
 ]
 
 
@@ -66,6 +76,21 @@ def _conv2_built(case, dtype="bf16"):
     Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
     res = lowp_round(rnd("r", (B, Co, Ho, Wo)), dtype) if use_res else None
     return x, w, b, res, conv_stream_op(x, w, b, s, relu, res, ov, ipad, opad, dtype=dtype)
+
+
+def test_conv2_small_grid_rule_selects_narrower_channel_blocks():
+    # csrc/conv2.hip, round 5: below 256 workgroups at 128 channels per workgroup the launcher takes 64-channel 16-row tiles
+    # if THEY reach 256, else 32-channel ones; 0x10000000 keeps round 4's 128-channel 8-row tile
+    want = {(16, 128, 256, 4, 0): "conv2_kernel<unsigned short, 1, 4, ", (16, 256, 256, 8, 0): "conv2_kernel<unsigned short, 1, 8, ",
+            (16, 128, 384, 32, 0): "conv2_kernel<unsigned short, 2, 8, ", (16, 128, 256, 4, 0x10000000): "conv2_kernel<unsigned short, 4, 4, "}
+    seen = 0
+    for c in CONV2_CASES:
+        key = (c[1], c[2], c[3], c[4], c[0])
+        if key in want and c[6] == 1:
+            n = _conv2_built(c)[4].name
+            assert n.startswith(want[key]), (c, n)
+            seen += 1
+    assert seen == len(want)
 
 
 # fp16 plans (H3D_F16, BASELINE configs[4]) run the same templates with v_mfma_f32_32x32x16_f16 and an fp16 epilogue: the
