@@ -249,21 +249,26 @@ def test_maxpool_and_upadd_and_copy(dtype):
     run(mk(_lib.OP_MAXPOOL, dtype, in_=xp, out=out.data_ptr(), B=2, H=18, W=22, Cin=32, in_cs=48, Ho=9, Wo=11, Cout=32,
            out_cs=32, ksize=2, stride=2))
     assert torch.equal(from_nhwc(out, 32), F.max_pool2d(x, 2, 2))
-    for f in (2, 4):
+    x = lowp_round(rnd("xo", (1, 16, 19, 23)), dtype)                   # odd map: the last row / column is dropped (nn.MaxPool2d(2) floors)
+    xb, xp = nhwc(x, dtype)
+    out = torch.zeros(1, 9, 11, 16, dtype=TD[dtype], device=DEV)
+    run(mk(_lib.OP_MAXPOOL, dtype, in_=xp, out=out.data_ptr(), B=1, H=19, W=23, Cin=16, in_cs=16, Ho=9, Wo=11, Cout=16, out_cs=16, ksize=2, stride=2))
+    assert torch.equal(from_nhwc(out, 16), F.max_pool2d(x, 2, 2))
+    for f, (uh, uw) in ((2, (6, 10)), (4, (6, 10)), (2, (5, 7)), (4, (3, 1)), (8, (2, 3))):
         k = 2 * f
         C = 64
-        x = rnd("u", (2, C, 6, 10))
-        skip = rnd("s", (2, C, 6 * f, 10 * f))
+        x = rnd("u", (2, C, uh, uw))
+        skip = rnd("s", (2, C, uh * f, uw * f))
         w = rnd("w", (C, 1, k, k), 0.0, 1.0)
         x, skip = lowp_round(x, dtype), lowp_round(skip, dtype)
         ref = (F.conv_transpose2d(x.double(), w.double(), None, stride=f, padding=f // 2, groups=C) + skip.double()).float()
         xb, xp = nhwc(x, dtype)
         sb, sp = nhwc(skip, dtype)
         wd = w.reshape(C, k * k).t().contiguous().to(DEV)
-        out = torch.zeros(2, 6 * f, 10 * f, C, dtype=TD[dtype], device=DEV)
-        run(mk(_lib.OP_UPADD, dtype, in_=xp, in2=sp, w=wd.data_ptr(), out=out.data_ptr(), B=2, H=6, W=10, Cin=C, in_cs=C,
-               in2_cs=C, Ho=6 * f, Wo=10 * f, Cout=C, out_cs=C, ksize=k, stride=f))
-        _check(from_nhwc(out, C), ref, dtype, "upadd f=%d" % f)
+        out = torch.zeros(2, uh * f, uw * f, C, dtype=TD[dtype], device=DEV)
+        run(mk(_lib.OP_UPADD, dtype, in_=xp, in2=sp, w=wd.data_ptr(), out=out.data_ptr(), B=2, H=uh, W=uw, Cin=C, in_cs=C,
+               in2_cs=C, Ho=uh * f, Wo=uw * f, Cout=C, out_cs=C, ksize=k, stride=f))
+        _check(from_nhwc(out, C), ref, dtype, "upadd f=%d %dx%d" % (f, uh, uw))
     x = lowp_round(rnd("c", (1, 16, 5, 7)), dtype)
     xb, xp = nhwc(x, dtype)
     out = torch.zeros(1, 5, 7, 32, dtype=TD[dtype], device=DEV)

@@ -157,6 +157,10 @@ DCN_CASES = [
     ("stream", "f16x3", 0, 1, 256, 256, 16, 16, 3.0),      # dcn3<x3_t,2,16,3,WDMA,256>: margin 3 (more than 64 output channels), grid.y = 4
     ("stream", "f16x3", 0x8000, 1, 64, 32, 20, 20, 12.0),  # dcn3<x3_t,1,16,3,WDMA,256>
     ("stream", "f16x3", 0x4000, 1, 256, 128, 16, 16, 6.0), # dcn3<x3_t,2,16,2,WDMA,256> forced on a wide layer
+    ("stream", "f16x3", 0, 1, 64, 64, 13, 21, 3.0),        # odd map sizes (the C ABI takes any H, W)
+    ("stream", "bf16", 0, 2, 64, 64, 13, 21, 3.0),
+    ("stream", "bf16", 0, 1, 128, 128, 7, 5, 2.0),         # a map smaller than one tile both ways
+    ("fused", "f32", 0, 1, 64, 64, 13, 21, 3.0),
     ("stream", "bf16", 0, 2, 128, 64, 24, 40, 0.5),        # dcn3<bf16,2,16,2,WDMA,256>: two workgroups per CU, patch slots
     ("stream", "bf16", 0, 1, 256, 64, 16, 32, 3.0),        #   ... 4-13 % of the samples in patches
     ("stream", "bf16", 0, 2, 64, 64, 40, 24, 6.0),         #   ... more samples leave the apron than a tile has slots: patches AND pass 2
