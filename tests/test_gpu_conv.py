@@ -341,3 +341,48 @@ def test_fused_stem_op_matches_torch(dtype, shape):
         t = F.relu(F.conv2d(t, w.double(), b.double(), s, k // 2))
     tol = {"bf16": 2e-2, "f16": 3e-3, "f16x3": 2e-5}[dtype] * max(1.0, float(t.abs().max()))
     assert float((got.double() - t).abs().max()) <= tol, (dtype, shape, float((got.double() - t).abs().max()), tol)
+
+
+@pytest.mark.parametrize("shape", [(2, 13, 21), (1, 7, 5), (1, 33, 65), (3, 16, 32)])
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f16x3", "f32"])
+def test_fused_heads_op_matches_torch(dtype, shape):
+    """H3D_OP_HEADS on its own (csrc/heads.hip): per head Conv3x3(64 -> 256) + bias + ReLU -> Conv1x1(256 -> C) + bias (model.py:451-460) in
+    one launch per width class, on map sizes no network produces (odd, smaller than a tile, one pixel past a tile) against fp64 on the CPU.
+    The 256-channel intermediate is rounded to the plan's storage type on its way back into the matrix core."""
+    import ctypes
+    from gpu_helpers import fake_pw
+    B, H, W = shape
+    heads = {"hm": 1, "hps": 34, "pose": 72, "wh": 2}
+    sd = {}
+    for h, c in heads.items():
+        sd[h + ".0.weight"] = rnd(h + "w1", (256, 64, 3, 3)) * (1.6 / np.sqrt(64 * 9))
+        sd[h + ".0.bias"] = rnd(h + "b1", (256,), -0.2, 0.2)
+        sd[h + ".2.weight"] = rnd(h + "w2", (c, 256, 1, 1)) * (1.6 / np.sqrt(256))
+        sd[h + ".2.bias"] = rnd(h + "b2", (c,), -0.5, 0.5)
+    pw = fake_pw(sd, dtype)
+    pw.heads, pw.head_conv = dict(heads), 256
+    x = lowp_round(rnd("feat", (B, 64, H, W), -1.5, 1.5), dtype)
+    xb, xp = nhwc(x, dtype)
+    outs, keep = {}, []
+    for names in (("hm", "wh"), ("hps",), ("pose",)):                      # one launch per number of 32-row output tiles, as engine.Plan._lower_heads
+        w1, b1, per = pw.fused_heads(names)
+        desc = _lib.H3dHeadsDesc()
+        desc.nheads = len(per)
+        desc.wexp = pw.wexp.get(w1.data_ptr(), 0)
+        for i, (hname, c, w2, b2) in enumerate(per):
+            outs[hname] = torch.full((B, c, H, W), float("nan"), dtype=torch.float32, device=DEV)
+            desc.head[i].w2, desc.head[i].b2, desc.head[i].out, desc.head[i].C = w2.data_ptr(), b2.data_ptr(), outs[hname].data_ptr(), c
+            desc.head[i].wexp2 = pw.wexp.get(w2.data_ptr(), 0)
+        keep.append(desc)
+        run(mk(_lib.OP_HEADS, dtype, in_=xp, in2=ctypes.addressof(desc), w=w1.data_ptr(), bias=b1.data_ptr(), B=B, H=H, W=W, Cin=64, in_cs=64,
+               Ho=H, Wo=W, Cout=256, ksize=3, stride=1))
+    for h, c in heads.items():
+        w1, w2 = lowp_round(sd[h + ".0.weight"], dtype), lowp_round(sd[h + ".2.weight"], dtype)
+        t = F.relu(F.conv2d(x.double(), w1.double(), sd[h + ".0.bias"].double(), 1, 1))
+        if dtype in ("bf16", "f16"):
+            t = lowp_round(t.float(), dtype).double()
+        ref = F.conv2d(t, w2.double(), sd[h + ".2.bias"].double())
+        got = outs[h].cpu().double()
+        assert bool(torch.isfinite(got).all()), h
+        tol = {"bf16": 3e-2, "f16": 4e-3, "f16x3": 3e-5, "f32": 3e-5}[dtype] * max(1.0, float(ref.abs().max()))
+        assert float((got - ref).abs().max()) <= tol, (dtype, shape, h, float((got - ref).abs().max()), tol)
