@@ -603,6 +603,61 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
     auto computeB = [&](int s) {
         const char *s_h = smem + C::PB + (ONEBUF ? 0 : (s & 1) * C::STAGE);
         const char *s_w = s_h + C::LDS_H + (WDMA ? (s & 1) * C::WSLOT : 0);
+#ifndef DCN3_X3_PIPE
+#define DCN3_X3_PIPE 1
+#endif
+        if constexpr (DCN3_X3_PIPE && std::is_same_v<T, x3_t> && CK == 16 && WDMA) {
+            // f16x3, one workgroup per CU (two waves a SIMD): per launch the vector work (blend + split: ~55 instructions per tap), the six
+            // MFMAs of a tap and its twelve LDS reads each cost about the same -- and hipcc's order runs them one after the other in every
+            // wave (gather -> wait -> blend -> split -> filter reads -> wait -> MFMAs): the kernel took the SUM of the three.  A wave issues in
+            // order, so vector work only overlaps matrix work when it sits BETWEEN the MFMAs: tap t+1 is blended and split while tap t is
+            // multiplied (second operand register set), one MFMA per ~6 vector instructions, the order pinned by sched_group_barrier; tap
+            // t+2's corners are requested as soon as tap t+1 is blended.
+            typename X::frag v[4];
+            typename X::bfrag pb[2];
+            auto gather = [&](int tap) {
+                const char *p00 = s_h + boff[tap], *p10 = p00 + C::RBH;
+                v[0] = X::lds(p00);
+                v[1] = X::lds(p00 + C::SBH);
+                v[2] = X::lds(p10);
+                v[3] = X::lds(p10 + C::SBH);
+            };
+            gather(0);
+            {
+                const typename X::frag fb = X::blend(v, geo[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                gather(1);
+                pb[0] = X::prep(fb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                typename X::wfrag fa[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + tap * CK * SS);
+                if (tap + 1 < 9) {
+                    const typename X::frag fb = X::blend(v, geo[tap + 1]);
+                    if (tap + 2 < 9) gather(tap + 2);
+                    pb[(tap + 1) & 1] = X::prep(fb);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], pb[tap & 1]);
+                // pinned order: filter reads, then MFMA / vector / MFMA / vector ...; the corner reads of tap t+2 behind the blend
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int i = 0; i < 3 * MT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i == 3 * MT - 1) __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x002, 36 / (3 * MT - 1) + 1, 0);
+                        if (i == (MT > 1 ? 2 : 1) && tap + 2 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
+                }
+            }
+            return;
+        }
         if constexpr (std::is_same_v<T, x3_t> && CK == 16 && MARGIN == 2 && WDMA) {
             // f16x3 (one workgroup per CU): hipcc's own order per tap is gather (8 reads) -> wait -> blend -> split -> filter reads ->
             // lgkmcnt(0) -> 6 MFMAs, the next gather behind the last MFMA: two LDS round trips exposed per tap.  Here the filter fragments
@@ -1106,10 +1161,18 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
         // fp32 weights; a patch unit is four fp32 channels; entries 128 ... 255 in a second fill round) -- on the fp32 apron of margin 2:
         // 141 KB of LDS, one workgroup per CU.  A far sample costs its four corner loads instead of a share of pass 2's re-walk.
         if (op.Cin % 32) H3D_FAIL(H3D_ERR_UNSUPPORTED, "dcn_fused_stream (f16x3): Cin %d must be a multiple of 32 (two stages per pipeline turn); use H3D_OP_DCN_FUSED", op.Cin);
-        // margin 3 (24 x 24 apron, 150 KB) on the 128 x 128 maps and the layers with more than 64 output channels (tools/ab_op_reserved.py
-        // --kind 12 --codes 0 0x8000, batch 64, same process, margin 2 / 3: 64 -> 64 @128x128 3.31 / 3.05 ms for the five launches,
-        // 128 -> 128 @64x64 1.45 / 1.25, 256 -> 256 @32x32 0.83 / 0.77; 128 -> 64 @64x64 1.00 / 1.04: margin 2); 0x8000 / 0x4000 force 3 / 2
-        if (((op.H >= 128 || op.Cout > 64) || (op.reserved & 0x8000)) && !(op.reserved & 0x4000)) {
+        // The in-kernel stamps of the margin-3 tiles (make ABLATE=1, tools/stamp_dcn.py --f16x3) showed pass 2 -- the tiles with more far
+        // samples than patch slots -- at 21 % of the 256 -> 256 layer and 12 % of a 128 -> 128 one: the `node` DeformConvs (Cin == Cout: their
+        // input is the up-sampled sum) have the largest offsets.  Margin 4 (26 x 26 apron, 160 KB) for them, margin 2 for the rest
+        // (tools/ab_op_reserved.py --kind 12 --codes 0x4000 0x8000 0x10000, batch 64, same process, margin 2 / 3 / 4: 256 -> 256 @32x32
+        // 0.791 / 0.757 / 0.541 ms, 128 -> 128 @64x64 1.343 / 1.222 / 1.112 for the two launches, 64 -> 64 @128x128 2.849 / 3.001 / 3.178 for
+        // the five (margin 3 was ahead there before phase B interleaved its vector work with the MFMAs), 256 -> 128 0.446 / 0.451 / 0.472,
+        // 512 -> 256 @16x16 0.186 / 0.199 / 0.215).  0x4000 / 0x8000 / 0x10000 force margin 2 / 3 / 4.
+        if (((op.Cin == op.Cout && op.Cout > 64) || (op.reserved & 0x10000)) && !(op.reserved & 0xc000)) {
+            if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 4, true, 256>(a, st);
+            return launch_dcn3_cfg<x3_t, 2, 16, 4, true, 256>(a, st);
+        }
+        if ((op.reserved & 0x8000) && !(op.reserved & 0x4000)) {
             if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 3, true, 256>(a, st);
             return launch_dcn3_cfg<x3_t, 2, 16, 3, true, 256>(a, st);
         }

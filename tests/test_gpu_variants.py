@@ -154,7 +154,10 @@ DCN_CASES = [
     ("stream", "f16x3", 0, 2, 64, 64, 40, 24, 6.0),        #   ... more far samples than slots: patches AND pass 2
     ("stream", "f16x3", 0, 1, 64, 64, 16, 16, 40.0),       #   ... nearly every sample outside the apron or the image
     ("stream", "f16x3", 0, 1, 64, 32, 20, 20, 12.0),       # dcn3<x3_t,1,16,2,WDMA,256>
-    ("stream", "f16x3", 0, 1, 256, 256, 16, 16, 3.0),      # dcn3<x3_t,2,16,3,WDMA,256>: margin 3 (more than 64 output channels), grid.y = 4
+    ("stream", "f16x3", 0, 1, 256, 256, 16, 16, 3.0),      # dcn3<x3_t,2,16,4,WDMA,256>: margin 4 (a `node` layer above 64 channels), grid.y = 4
+    ("stream", "f16x3", 0x8000, 1, 256, 256, 16, 16, 3.0), # dcn3<x3_t,2,16,3,WDMA,256>: margin 3
+    ("stream", "f16x3", 0x10000, 1, 64, 32, 20, 20, 12.0), # dcn3<x3_t,1,16,4,WDMA,256>
+    ("stream", "f16x3", 0x10000, 2, 64, 64, 40, 24, 6.0),  #   margin 4 with more far samples than slots: patches AND pass 2
     ("stream", "f16x3", 0x8000, 1, 64, 32, 20, 20, 12.0),  # dcn3<x3_t,1,16,3,WDMA,256>
     ("stream", "f16x3", 0x4000, 1, 256, 128, 16, 16, 6.0), # dcn3<x3_t,2,16,2,WDMA,256> forced on a wide layer
     ("stream", "f16x3", 0, 1, 64, 64, 13, 21, 3.0),        # odd map sizes (the C ABI takes any H, W)

@@ -7,9 +7,10 @@ from h3d_amd import _lib, arch, synth
 from h3d_amd.detector import MultiPoseDetector, Opt
 from bench import kernel_name
 STAGE_B = "--stage-b" in sys.argv      # library built with ABLATE=1 and -DDCN3_STAMP_B: sub-steps of phase B's second stage
-sys.argv = [a for a in sys.argv if a != "--stage-b"]
+DTYPE = "f16x3" if "--f16x3" in sys.argv else "bf16"
+sys.argv = [a for a in sys.argv if a not in ("--stage-b", "--f16x3")]
 dev = torch.device("cuda:0")
-opt = Opt(input_h=512, input_w=512, smpl=True, dtype="bf16")
+opt = Opt(input_h=512, input_w=512, smpl=True, dtype=DTYPE)
 sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, True), seed=0, gain=float(sys.argv[2]) if len(sys.argv) > 2 else 1.25)
 det = MultiPoseDetector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=dev)
 B = 64
