@@ -57,7 +57,8 @@ CONV2_CASES = [
     (0, 4, 64, 64, 128, 128, 1, True, True, 0, 0),         # level2 class -> <2,8>
     # round 5: grids too small for 128-channel tiles (deep Hourglass levels, small DLA shards) take narrower channel blocks
     (0, 16, 128, 256, 4, 4, 1, True, False, 0, 0),         # 4 x 4 maps: <1,4>, 8 channel blocks per image
-    (0, 16, 256, 256, 8, 8, 1, True, True, 0, 0),          # 8 x 8 maps: <1,8> (256 workgroups of 32 channels on 16-row tiles)
+    (0, 16, 256, 256, 8, 8, 1, True, True, 0, 0),          # 8 x 8 maps: <1,4> (128 workgroups even at 32 channels)
+    (0, 16, 64, 512, 4, 4, 1, True, False, 0, 0),          # 512 output channels: 32-channel blocks make 256 workgroups on 16-row tiles: <1,8>
     (0, 16, 128, 384, 32, 32, 1, True, True, 0, 0),        # 32 x 32 maps, 16 images: <2,8,PIPE>
     (0x10000000, 16, 128, 256, 4, 4, 1, True, False, 0, 0),  # ... round 4's rule on the same tensor: <4,4>
     # odd sizes (the C ABI takes any H, W)
@@ -81,7 +82,7 @@ def _conv2_built(case, dtype="bf16"):
 def test_conv2_small_grid_rule_selects_narrower_channel_blocks():
     # csrc/conv2.hip, round 5: below 256 workgroups at 128 channels per workgroup the launcher takes 64-channel 16-row tiles
     # if THEY reach 256, else 32-channel ones; 0x10000000 keeps round 4's 128-channel 8-row tile
-    want = {(16, 128, 256, 4, 0): "conv2_kernel<unsigned short, 1, 4, ", (16, 256, 256, 8, 0): "conv2_kernel<unsigned short, 1, 8, ",
+    want = {(16, 128, 256, 4, 0): "conv2_kernel<unsigned short, 1, 4, ", (16, 256, 256, 8, 0): "conv2_kernel<unsigned short, 1, 4, ", (16, 64, 512, 4, 0): "conv2_kernel<unsigned short, 1, 8, ",
             (16, 128, 384, 32, 0): "conv2_kernel<unsigned short, 2, 8, ", (16, 128, 256, 4, 0x10000000): "conv2_kernel<unsigned short, 4, 4, "}
     seen = 0
     for c in CONV2_CASES:
