@@ -269,8 +269,10 @@ def test_single_class_topk_shortcut_equals_the_merge_kernel(golden_dir):
             assert a.dtype == b.dtype and torch.equal(a, b), name
 
 
-def test_ctdet_end_to_end_f32_vs_reference_output(golden_dir):
-    """The `ctdet` task entry against reference OUTPUT (tests/golden/e2e_ctdet_256.npz: the imported reference's plain-conv
+@pytest.mark.parametrize("dtype", ["f32", "f16x3"])
+def test_ctdet_end_to_end_f32_vs_reference_output(golden_dir, dtype):
+    """(f16x3, round 5: the same contract on the fp16 matrix cores -- fp32 storage, three fp16 MFMAs on split operands per fp32 product.)
+    The `ctdet` task entry against reference OUTPUT (tests/golden/e2e_ctdet_256.npz: the imported reference's plain-conv
     `dla_net` with the ctdet heads -> `_sigmoid` -> `ctdet_decode(K=100)`, trainer.py:444-455): the product's `CtdetDetector`
     (f32 plan, `not_use_dcn=True`) returns the reference's top-100 indices and classes on both images and its `dets` within
     2e-3 px / 2e-6 of score."""
@@ -278,7 +280,7 @@ def test_ctdet_end_to_end_f32_vs_reference_output(golden_dir):
     from h3d_amd import arch
     from h3d_amd.detector import Opt, make_detector
     g = np.load(os.path.join(golden_dir, "e2e_ctdet_256.npz"))
-    opt = Opt(task="ctdet", input_h=256, input_w=256, dtype="f32", K=100, num_classes=80, not_use_dcn=True)
+    opt = Opt(task="ctdet", input_h=256, input_w=256, dtype=dtype, K=100, num_classes=80, not_use_dcn=True)
     sd = synth.synth_state_dict(arch.state_dict_shapes(opt.heads, False), seed=0, gain=1.1)
     det = make_detector(opt, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, device=DEV)
     res = det.run(torch.from_numpy(synth.synth_images(2, 256, 256, seed=317)).to(DEV))
