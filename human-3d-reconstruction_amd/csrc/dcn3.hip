@@ -305,11 +305,11 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
 #ifndef DCN3_ADEPTH
 #define DCN3_ADEPTH 4
 #endif
-        if constexpr (DCN3_ADEPTH > 0 && CK == 16 && SS != 4 + 0 * DCN3_ADEPTH) {
+        if constexpr (DCN3_ADEPTH > 0 && CK == 16 && sizeof(T) == 2) {
             // the nine MFMAs of a stage form one dependent chain, and hipcc feeds it one tap at a time: two fragment reads, lgkmcnt(1), MFMA
             // -- a read issued two instructions earlier is waited for in front of every MFMA.  Pinned order: the fragments of DCN3_ADEPTH
             // taps requested up front, then one tap's reads behind each MFMA, so a read has DCN3_ADEPTH MFMAs of time to land.
-            constexpr int RPT = 2 * (int)(sizeof(typename X::wfrag) / 16), MPT = std::is_same_v<T, x3_t> ? 3 : 1;
+            constexpr int RPT = 2, MPT = 1;        // two 16-byte fragments, one MFMA per tap
             __builtin_amdgcn_sched_group_barrier(0x100, RPT * DCN3_ADEPTH, 0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -612,7 +612,9 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
             // wave (gather -> wait -> blend -> split -> filter reads -> wait -> MFMAs): the kernel took the SUM of the three.  A wave issues in
             // order, so vector work only overlaps matrix work when it sits BETWEEN the MFMAs: tap t+1 is blended and split while tap t is
             // multiplied (second operand register set), one MFMA per ~6 vector instructions, the order pinned by sched_group_barrier; tap
-            // t+2's corners are requested as soon as tap t+1 is blended.
+            // t+2's corners are requested as soon as tap t+1 is blended.  (tools/ab_lib.py, batch 64, same process: the margin-2 launches
+            // 1.048 -> 0.986 ms for four of them, the margin-3 ones +0.7 % at 144 instead of 112 bytes of scratch; a first version that only
+            // moved the corner request of tap t+1 behind the blend of tap t, one register set: -4 % / +2 %)
             typename X::frag v[4];
             typename X::bfrag pb[2];
             auto gather = [&](int tap) {
@@ -655,38 +657,6 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
                 }
-            }
-            return;
-        }
-        if constexpr (std::is_same_v<T, x3_t> && CK == 16 && MARGIN == 2 && WDMA) {
-            // f16x3 (one workgroup per CU): hipcc's own order per tap is gather (8 reads) -> wait -> blend -> split -> filter reads ->
-            // lgkmcnt(0) -> 6 MFMAs, the next gather behind the last MFMA: two LDS round trips exposed per tap.  Here the filter fragments
-            // are requested before the blend (behind the corners: the blend waits for the corners only) and tap t+1's corners as soon
-            // as tap t is blended -- into the SAME registers: they fly during the split and the MFMAs of tap t.
-            // (tools/ab_lib.py, batch 64: the five margin-2 launches 1.129 -> 1.086 ms; the margin-3 variant goes from 112 to 144 bytes
-            //  of scratch with it and its eleven launches from 5.61 to 5.74 ms: it keeps the compiler's order)
-            typename X::frag v[4];
-            auto gather = [&](int tap) {
-                const char *p00 = s_h + boff[tap], *p10 = p00 + C::RBH;
-                v[0] = X::lds(p00);
-                v[1] = X::lds(p00 + C::SBH);
-                v[2] = X::lds(p10);
-                v[3] = X::lds(p10 + C::SBH);
-            };
-            gather(0);
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                typename X::wfrag fa[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + tap * CK * SS);
-                __builtin_amdgcn_sched_barrier(0);
-                const typename X::frag fb = X::blend(v, geo[tap]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (tap + 1 < 9) gather(tap + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                const typename X::bfrag pb = X::prep(fb);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], pb);
             }
             return;
         }
