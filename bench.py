@@ -416,7 +416,16 @@ def boundary_op_times(batch, dev):
     from h3d_amd import dcn_v2
     res = {}
     g = torch.Generator(device="cpu").manual_seed(0)
-    tot = {"reference": 0.0, "nhwc": 0.0, "bf16": 0.0}
+    tot = {"reference": 0.0, "nhwc": 0.0, "bf16": 0.0, "reference_f32_mfma": 0.0}
+
+    def f32_mfma(fn):                    # the fp32 tensors' arithmetic of rounds 1-4 (exact fmaf chains on the fp32 matrix instruction)
+        def run():
+            dcn_v2.OP_F32_MFMA = True
+            try:
+                return fn()
+            finally:
+                dcn_v2.OP_F32_MFMA = False
+        return run
 
     def timed(fn):
         for _ in range(2):
@@ -450,17 +459,22 @@ def boundary_op_times(batch, dev):
                 flop = 2.0 * batch * hw * hw * o * cin * 9
                 ms = {"reference": timed(lambda: dcn_v2.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)),
                       "nhwc": timed(lambda: dcn_v2.dcn_v2_forward(xcl, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)),
-                      "bf16": timed(lambda: dcn_v2.dcn_v2_forward(xbf, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1))}
-                res[key] = {"n": 1, "ms": round(ms["reference"], 3), "tflops": round(flop / ms["reference"] / 1e9, 1),
+                      "bf16": timed(lambda: dcn_v2.dcn_v2_forward(xbf, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)),
+                      "reference_f32_mfma": timed(f32_mfma(lambda: dcn_v2.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)))}
+                res[key] = {"n": 1, "ms": round(ms["reference"], 3), "tflops": round(flop / ms["reference"] / 1e9, 1), "ms_f32_mfma": round(ms["reference_f32_mfma"], 3),
                             "ms_nhwc": round(ms["nhwc"], 3), "ms_bf16": round(ms["bf16"], 3), "tflops_bf16": round(flop / ms["bf16"] / 1e9, 1)}
                 del x, w, off, m, xcl, xbf
     for v in res.values():
         tot["reference"] += v["ms"] * v["n"]
         tot["nhwc"] += v["ms_nhwc"] * v["n"]
         tot["bf16"] += v["ms_bf16"] * v["n"]
-    return {"dtype": "reference / nhwc: f32 (v_mfma_f32_32x32x2_f32, peak 157 TFLOP/s); bf16: fp16 blend + v_mfma_f32_32x32x16_f16",
+        tot["reference_f32_mfma"] += v["ms_f32_mfma"] * v["n"]
+    return {"dtype": "reference / nhwc: fp32 tensors, every product as three fp16 MFMAs on split operands (f16x3, round 5; fp64-oracle error 4e-7 "
+                     "relative, tests/test_gpu_dcn.py); ms_f32_mfma: the same call on v_mfma_f32_32x32x2_f32 (H3D_DCN_F32_MFMA, the rounds 1-4 "
+                     "arithmetic, 7e-7); bf16: fp16 blend + v_mfma_f32_32x32x16_f16",
             "batch": batch, "layers": sum(v["n"] for v in res.values()),
             "total_ms": round(tot["reference"], 3), "total_ms_nhwc": round(tot["nhwc"], 3), "total_ms_bf16": round(tot["bf16"], 3),
+            "total_ms_f32_mfma": round(tot["reference_f32_mfma"], 3),
             "shapes": res}
 
 

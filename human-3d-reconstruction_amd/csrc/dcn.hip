@@ -189,18 +189,34 @@ __global__ void dcn_om_pack_kernel(const float *__restrict__ off, const float *_
     for (int q = 0; q < 8; ++q) reinterpret_cast<f32x4 *>(om + i * 32)[q] = row[q];
 }
 
+// max |filter| of an fp32 pack, as the bit pattern of the float (monotonic for non-negative values; a NaN sorts above everything and
+// is recognised by the consumer): one atomicMax per wave into `wmax`, which the caller zeroed in front of the pack kernel.  The f16x3
+// operator kernel (csrc/dcn2.hip, H3D_F16X3) derives its power-of-two filter scale from it -- on the device, no host round trip.
+#define H3D_DCN_AUX_BYTES 256      // behind the bias of an fp32 pack: [0] = max |filter| bits
+__device__ __forceinline__ void dcn_wmax_accumulate(unsigned *wmax, float v)
+{
+    unsigned m = __float_as_uint(fabsf(v));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, d));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(wmax, m);
+}
+
 __global__ void dcn_w_pack_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ wp, float *__restrict__ bp,
-                                  int Cout, int C, int rows)
+                                  int Cout, int C, int rows, unsigned *__restrict__ wmax)
 {
     // wp [rows][9][C] <- w [Cout][C][3][3]; rows beyond Cout are zero
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)rows * 9 * C;
     if (i < (size_t)rows) bp[i] = i < (size_t)Cout ? bias[i] : 0.f;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const int tap = (int)((i / C) % 9);
-    const int o = (int)(i / ((size_t)9 * C));
-    wp[i] = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+    float v = 0.f;
+    if (i < total) {
+        const int c = (int)(i % C);
+        const int tap = (int)((i / C) % 9);
+        const int o = (int)(i / ((size_t)9 * C));
+        v = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+        wp[i] = v;
+    }
+    dcn_wmax_accumulate(wmax, v);          // (every lane of the wave takes part in the shuffles)
 }
 
 static size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -223,7 +239,16 @@ extern "C" size_t h3d_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cou
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
     const size_t rows = ((size_t)Cout + 127) / 128 * 128, px = (size_t)B * H * W;
-    return ws_align(px * C * 4) + ws_align(px * 32 * 4) + ws_align(rows * 9 * C * 4) + ws_align(rows * 4);
+    return ws_align(px * C * 4) + ws_align(px * 32 * 4) + ws_align(rows * 9 * C * 4) + ws_align(rows * 4) + H3D_DCN_AUX_BYTES;
+}
+
+// The arithmetic of the operator's fp32 fast path: three fp16 MFMAs on split operands per fp32 product (H3D_F16X3: 2^-22 relative per
+// product, fp32 accumulation; ~2x the rate of the fp32 matrix instruction on these shapes) unless H3D_DCN_OP_F32=1 is in the environment
+// (exact fmaf chains on v_mfma_f32_32x32x2_f32, the round 1-4 behaviour) or the caller passes H3D_DCN_F32_MFMA.
+static bool dcn_op_f32_mfma()
+{
+    static const bool v = [] { const char *e = getenv("H3D_DCN_OP_F32"); return e && e[0] && e[0] != '0'; }();
+    return v;
 }
 
 extern "C" int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *bias, const float *offset,
@@ -245,20 +270,22 @@ extern "C" int h3d_dcn_v2_forward_ws(const float *input, const float *weight, co
     float *x_nhwc = (float *)ws;                ws += ws_align(px * C * 4);
     float *om = (float *)ws;                    ws += ws_align(px * 32 * 4);
     float *wp = (float *)ws;                    ws += ws_align((size_t)rows * 9 * C * 4);
-    float *bp = (float *)ws;
+    float *bp = (float *)ws;                    // [rows] + H3D_DCN_AUX_BYTES (rows is a multiple of 128: no padding in between)
+    unsigned *wmax = (unsigned *)(bp + rows);
+    if (hipMemsetAsync(wmax, 0, H3D_DCN_AUX_BYTES, st) != hipSuccess) H3D_FAIL(H3D_ERR_LAUNCH, "dcn_v2_forward: memset");
     int rc = h3d_nchw_f32_to_nhwc(input, x_nhwc, H3D_F32, B, C, H, W, C, stream);
     if (rc != H3D_OK) return rc;
     hipLaunchKernelGGL(dcn_om_pack_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, offset, mask, om, H * W, px);
     H3D_CHECK_LAUNCH("dcn_om_pack_kernel");
     const size_t wtotal = (size_t)rows * 9 * C;
-    hipLaunchKernelGGL(dcn_w_pack_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, st, weight, bias, wp, bp, Cout, C, rows);
+    hipLaunchKernelGGL(dcn_w_pack_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, st, weight, bias, wp, bp, Cout, C, rows, wmax);
     H3D_CHECK_LAUNCH("dcn_w_pack_kernel");
     h3d_op op = {};
-    op.kind = H3D_OP_DCN; op.dtype = H3D_F32;
+    op.kind = H3D_OP_DCN; op.dtype = dcn_op_f32_mfma() ? H3D_F32 : H3D_F16X3;
     op.in = x_nhwc; op.in2 = om; op.w = wp; op.bias = bp; op.out = output;
     op.B = B; op.H = H; op.W = W; op.Cin = C; op.in_cs = C; op.in2_cs = 32; op.Ho = H; op.Wo = W; op.Cout = Cout; op.out_cs = Cout;
     op.ksize = 3; op.stride = 1; op.relu = 0; op.out_mode = H3D_OUT_NCHW_F32; op.wrows = rows;
-    op.reserved = 0x800;                        // the mask operand is final (the reference applies the sigmoid in DCN.forward, dcn_v2.py:124)
+    op.reserved = 0x800 | (op.dtype == H3D_F16X3 ? 0x100000 : 0);      // the mask operand is final (the reference applies the sigmoid in DCN.forward, dcn_v2.py:124); fp32 pack + max |w|
     return h3d_launch_dcn2(op, st);
 }
 
@@ -273,7 +300,7 @@ extern "C" size_t h3d_dcn_v2_packed_weight_bytes(int Cout, int C, int dtype)
 {
     if (Cout <= 0 || C <= 0 || (dtype != H3D_F32 && dtype != H3D_BF16)) return 0;
     const size_t rows = ((size_t)Cout + 127) / 128 * 128;
-    return ws_align(rows * 9 * C * (dtype == H3D_F32 ? 4 : 2)) + ws_align(rows * 4);
+    return ws_align(rows * 9 * C * (dtype == H3D_F32 ? 4 : 2)) + ws_align(rows * 4) + (dtype == H3D_F32 ? H3D_DCN_AUX_BYTES : 0);
 }
 
 extern "C" int h3d_dcn_v2_pack_weights(const float *weight, const float *bias, int Cout, int C, int dtype, void *packed, void *stream)
@@ -284,9 +311,11 @@ extern "C" int h3d_dcn_v2_pack_weights(const float *weight, const float *bias, i
     const int rows = (Cout + 127) / 128 * 128;
     const size_t wtotal = (size_t)rows * 9 * C;
     float *bp = (float *)((char *)packed + ws_align(wtotal * (dtype == H3D_F32 ? 4 : 2)));
-    if (dtype == H3D_F32)
-        hipLaunchKernelGGL(dcn_w_pack_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, bias, (float *)packed, bp, Cout, C, rows);
-    else
+    if (dtype == H3D_F32) {
+        if (hipMemsetAsync(bp + rows, 0, H3D_DCN_AUX_BYTES, (hipStream_t)stream) != hipSuccess) H3D_FAIL(H3D_ERR_LAUNCH, "dcn_v2_pack_weights: memset");
+        hipLaunchKernelGGL(dcn_w_pack_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, bias, (float *)packed, bp, Cout, C, rows,
+                           (unsigned *)(bp + rows));
+    } else
         hipLaunchKernelGGL(dcn_w_pack_f16_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, bias, (_Float16 *)packed, bp, Cout, C, rows);
     H3D_CHECK_LAUNCH("dcn_w_pack_kernel");
     return H3D_OK;
@@ -346,20 +375,28 @@ static int sig_begin(unsigned long long *state, const void *const *bufs, const s
     return H3D_OK;
 }
 
+__global__ void dcn_wmax_reset_if_kernel(const unsigned long long *__restrict__ state, unsigned *__restrict__ wmax)
+{
+    if (state[0] != state[1]) *wmax = 0u;                  // the pack kernel behind this one rebuilds the image and its maximum
+}
+
 __global__ void dcn_w_pack_if_kernel(const float *__restrict__ w, const float *__restrict__ bias, void *__restrict__ wp_, float *__restrict__ bp,
-                                     int Cout, int C, int rows, int f16, const unsigned long long *__restrict__ state)
+                                     int Cout, int C, int rows, int f16, const unsigned long long *__restrict__ state, unsigned *__restrict__ wmax)
 {
     if (state[0] == state[1]) return;                      // the packed image was built from exactly these bytes
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)rows * 9 * C;
     if (i < (size_t)rows) bp[i] = i < (size_t)Cout ? bias[i] : 0.f;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const int tap = (int)((i / C) % 9);
-    const int o = (int)(i / ((size_t)9 * C));
-    const float v = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
-    if (f16) ((_Float16 *)wp_)[i] = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-    else ((float *)wp_)[i] = v;
+    float v = 0.f;
+    if (i < total) {
+        const int c = (int)(i % C);
+        const int tap = (int)((i / C) % 9);
+        const int o = (int)(i / ((size_t)9 * C));
+        v = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+        if (f16) ((_Float16 *)wp_)[i] = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+        else ((float *)wp_)[i] = v;
+    }
+    if (!f16) dcn_wmax_accumulate(wmax, v);
 }
 
 extern "C" int h3d_dcn_v2_pack_weights_cached(const float *weight, const float *bias, int Cout, int C, int dtype, void *packed, void *state_,
@@ -377,8 +414,13 @@ extern "C" int h3d_dcn_v2_pack_weights_cached(const float *weight, const float *
     const int rows = (Cout + 127) / 128 * 128;
     const size_t wtotal = (size_t)rows * 9 * C;
     float *bp = (float *)((char *)packed + ws_align(wtotal * (dtype == H3D_F32 ? 4 : 2)));
+    unsigned *wmax = dtype == H3D_F32 ? (unsigned *)(bp + rows) : nullptr;
+    if (wmax) {
+        hipLaunchKernelGGL(dcn_wmax_reset_if_kernel, dim3(1), dim3(1), 0, st, state, wmax);
+        H3D_CHECK_LAUNCH("dcn_wmax_reset_if_kernel");
+    }
     hipLaunchKernelGGL(dcn_w_pack_if_kernel, dim3((unsigned)((wtotal + 255) / 256)), dim3(256), 0, st, weight, bias, packed, bp, Cout, C, rows,
-                       dtype == H3D_F32 ? 0 : 1, state);
+                       dtype == H3D_F32 ? 0 : 1, state, wmax);
     H3D_CHECK_LAUNCH("dcn_w_pack_if_kernel");
     hipLaunchKernelGGL(sig_commit_kernel, dim3(1), dim3(1), 0, st, state);
     H3D_CHECK_LAUNCH("sig_commit_kernel");
@@ -471,12 +513,13 @@ extern "C" int h3d_dcn_v2_forward_packed(const void *input, const void *packed, 
     hipLaunchKernelGGL(dcn_om_pack_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, offset, mask, om, H * W, px);
     H3D_CHECK_LAUNCH("dcn_om_pack_kernel");
     h3d_op op = {};
-    op.kind = H3D_OP_DCN; op.dtype = dtype;
+    op.kind = H3D_OP_DCN;
+    op.dtype = dtype == H3D_F32 && !(flags & H3D_DCN_F32_MFMA) && !dcn_op_f32_mfma() ? H3D_F16X3 : dtype;
     op.in = x; op.in2 = om; op.w = packed;
     op.bias = (const float *)((const char *)packed + ws_align((size_t)rows * 9 * C * (dtype == H3D_F32 ? 4 : 2)));
     op.out = output;
     op.B = B; op.H = H; op.W = W; op.Cin = C; op.in_cs = C; op.in2_cs = 32; op.Ho = H; op.Wo = W; op.Cout = Cout; op.out_cs = Cout;
     op.ksize = 3; op.stride = 1; op.relu = 0; op.out_mode = (flags & H3D_DCN_OUTPUT_NHWC) ? H3D_OUT_NHWC : H3D_OUT_NCHW_F32; op.wrows = rows;
-    op.reserved = 0x800;                        // the mask operand is final
+    op.reserved = 0x800 | (op.dtype == H3D_F16X3 ? 0x100000 : 0);      // the mask operand is final; fp32 pack + max |w| behind the bias
     return h3d_launch_dcn2(op, st);
 }

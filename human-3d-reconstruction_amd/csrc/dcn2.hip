@@ -31,6 +31,7 @@ struct Dcn2Args {
     int tiles_x, tiles_y;
     int dbg;   // ablation switches for profiling (h3d_op.reserved): 1 = stage only chunk 0, 2 = no gather/blend, 4 = no MFMA
     int mask_final;   // om[18..26] is the mask itself, not its logit (operator boundary h3d_dcn_v2_forward_ws; op.reserved & 0x800)
+    const unsigned *wmax;   // H3D_F16X3 (the operator's fp32 fast path): bit pattern of max |filter|, written by the pack kernels (csrc/dcn.hip)
 };
 
 template <typename T, int MT, int CK, int MARGIN, int NT_>
@@ -82,6 +83,28 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
 
     const char *img = a.in + (size_t)b * a.H * a.W * a.in_cs * ES;
     const int aoff = r * C::WB + 8 * h * SS;
+    // f16x3 (round 5): `w` is the operator's plain fp32 pack; the filters are scaled by a power of two and split into (hi | lo) fp16 terms by
+    // the thread that stages them (as the activations of every f16x3 kernel are).  The scale puts max |w| into [2^13, 2^14) -- the rule of
+    // engine.x3_exp, evaluated here from the maximum the pack kernel left behind the bias -- so that lo terms are normal fp16 numbers
+    // whatever the magnitude of the caller's filters; the accumulators are multiplied by its inverse (exact).
+    [[maybe_unused]] float wsc = 1.f, wun = 1.f;
+    if constexpr (std::is_same_v<T, x3_t>) {
+        const float m = __uint_as_float(*a.wmax);
+        int k = 14;
+        if (m > 0.f && m < __builtin_inff()) (void)frexpf(m, &k);
+        const int e = min(60, max(-60, 14 - k));
+        wsc = ldexpf(1.f, e);
+        wun = ldexpf(1.f, -e);
+    }
+    [[maybe_unused]] auto store_w = [&](char *dst_row_tap, int v, u32x4 raw) {      // one 16-byte vector of a staged filter row -> LDS
+        if constexpr (std::is_same_v<T, x3_t>) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) raw[i] = __float_as_uint(__uint_as_float(raw[i]) * wsc);
+            x3_store4(dst_row_tap + (v >> 1) * 32, v & 1, raw);
+        } else {
+            *reinterpret_cast<u32x4 *>(dst_row_tap + v * 16) = raw;
+        }
+    };
 
     // ---- sampling geometry of every (pixel, tap) of this lane, ONCE per workgroup: the reference's
     //      float arithmetic (im2col.cu:163-185).  Kept in registers: boff = LDS byte offset of corner
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
                 const int q0 = i - NH;
                 const int row = q0 / WV, q = q0 - row * WV;
                 const int tap = q / C::VPP, v = q - tap * C::VPP;
-                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = stg[j];
+                store_w(s_w + row * C::WB + tap * CK * SS, v, stg[j]);
             }
         }
     };
@@ -199,20 +222,24 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
             }
 #pragma unroll
             for (int kk = 0; kk < CK / 16; ++kk) {
-                typename X::frag fa[MT];
+                typename X::wfrag fa[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
-                if (H3D_DBG(a) & 4) {
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+                if constexpr (!std::is_same_v<T, x3_t>) {
+                    if (H3D_DBG(a) & 4) {
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                        for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) { X::keep(fa[m]); X::keep(fb[n][kk]); }
-                    continue;
+                            for (int n = 0; n < NT; ++n) { X::keep(fa[m]); X::keep(fb[n][kk]); }
+                        continue;
+                    }
                 }
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int n = 0; n < NT; ++n) {
+                    const typename X::bfrag pb = X::prep(fb[n][kk]);      // (f16x3: the blended fp32 sample split into fp16 terms, once for all M-tiles)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) X::mma(acc[m][n], fa[m], fb[n][kk]);
+                    for (int m = 0; m < MT; ++m) X::mma(acc[m][n], fa[m], pb);
+                }
             }
         }
     }
@@ -226,8 +253,8 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
             for (int i = tid; i < C::BN * WV; i += C::THREADS) {
                 const int row = i / WV, q = i - row * WV;
                 const int tap = q / C::VPP, v = q - tap * C::VPP;
-                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = *reinterpret_cast<const u32x4 *>(
-                    a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+                store_w(s_w + row * C::WB + tap * CK * SS, v, *reinterpret_cast<const u32x4 *>(
+                    a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16));
             }
             __syncthreads();
 #pragma unroll 1
@@ -268,21 +295,31 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
                 if (!__any(any)) continue;          // wave-uniform: no lane of this wave has a slow sample at this tap
 #pragma unroll
                 for (int kk = 0; kk < CK / 16; ++kk) {
-                    typename X::frag fa[MT];
+                    typename X::wfrag fa[MT];
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) fa[m] = X::lds(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
+                    for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + (tap * CK + kk * 16) * SS);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int n = 0; n < NT; ++n) {
+                        const typename X::bfrag pb = X::prep_raw(fb[n][kk]);      // (corners straight from memory: the split clamps)
 #pragma unroll
-                        for (int n = 0; n < NT; ++n) X::mma(acc[m][n], fa[m], fb[n][kk]);
+                        for (int m = 0; m < MT; ++m) X::mma(acc[m][n], fa[m], pb);
+                    }
                 }
             }
         }
     }
+    if constexpr (std::is_same_v<T, x3_t>) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][n][i] *= wun;
+    }
     EpiArgs e;
     e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
     e.out_cs = a.out_cs; e.res_cs = 0; e.relu = a.relu; e.out_mode = a.out_mode;
-    tile_epilogue<T, MT, NT>(acc, e, b, oy0, ox0, cout0, wv, r, h);
+    tile_epilogue<typename StoreT<T>::type, MT, NT>(acc, e, b, oy0, ox0, cout0, wv, r, h);
 }
 
 template <typename T, int MT, int CK, int MARGIN, int NT_>
@@ -294,7 +331,7 @@ static int launch_dcn2_cfg(const Dcn2Args &a0, hipStream_t st)
     a.tiles_x = cdiv(a.W, 16);
     a.tiles_y = cdiv(a.H, 16);
     dim3 grid(a.B * a.tiles_x * a.tiles_y, cdiv(a.Cout, C::BN));
-    if (h3d_note_kernel("dcn2_kernel<%s, %d, %d, %d, %d>", sizeof(T) == 2 ? "unsigned short" : "float", MT, CK, MARGIN, NT_))
+    if (h3d_note_kernel("dcn2_kernel<%s, %d, %d, %d, %d>", h3d_tname<T>(), MT, CK, MARGIN, NT_))
         return H3D_OK;
     hipLaunchKernelGGL((dcn2_kernel<T, MT, CK, MARGIN, NT_>), grid, dim3(C::THREADS), 0, st, a);
     H3D_CHECK_LAUNCH("dcn2_kernel");
@@ -323,6 +360,7 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st)
     a.tiles_x = a.tiles_y = 0;
     a.dbg = op.reserved;
     a.mask_final = (op.reserved >> 11) & 1;
+    a.wmax = nullptr;
     if (op.dtype == H3D_BF16) {
         if (op.Cin % 32 == 0 && op.Cout <= 64) {
             if (op.Cout <= 32) return launch_dcn2_cfg<bf16_t, 1, 32, 2, 2>(a, st);
@@ -335,6 +373,15 @@ int h3d_launch_dcn2(const h3d_op &op, hipStream_t st)
     if (op.dtype == H3D_F32) {
         if (op.Cout <= 32) return launch_dcn2_cfg<float, 1, 16, 2, 1>(a, st);
         return launch_dcn2_cfg<float, 2, 16, 2, 1>(a, st);
+    }
+    if (op.dtype == H3D_F16X3 && (op.reserved & 0x100000)) {
+        // (0x100000: set by the operator entry points of csrc/dcn.hip -- a network plan's f16x3 DeformConvs are H3D_OP_DCN_FUSED[_STREAM]
+        //  with pre-split filters and h3d_op.wexp; an H3D_OP_DCN of that kind has no kernel and fails below as before)
+        // the operator's fp32 fast path on the fp16 matrix cores: fp32 tensors and the plain fp32 filter pack of H3D_F32, every product as
+        // three fp16 MFMAs on split operands (csrc/common.h ET<x3_t>).  bias[wrows] holds the bit pattern of max |filter| (see Dcn2Args)
+        a.wmax = (const unsigned *)(op.bias + op.wrows);
+        if (op.Cout <= 32) return launch_dcn2_cfg<x3_t, 1, 16, 2, 1>(a, st);
+        return launch_dcn2_cfg<x3_t, 2, 16, 2, 1>(a, st);
     }
     H3D_FAIL(H3D_ERR_DTYPE, "dcn: dtype %d", op.dtype);
 }

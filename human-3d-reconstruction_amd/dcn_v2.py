@@ -18,6 +18,11 @@ _PACKED = {}          # (weight ptr, bias ptr, shape, dtype, device) -> (packed 
 _PACKED_MAX = 64
 
 
+# fp32 tensors in the model's configuration: False (default since round 5) = three fp16 MFMAs on split operands per fp32 product
+# (H3D_F16X3: 2^-22 relative per product, fp32 accumulation, ~2x the rate), True = exact fmaf chains on the fp32 matrix instruction
+# (H3D_DCN_F32_MFMA; the environment variable H3D_DCN_OP_F32=1 selects the same for every entry point of the library)
+OP_F32_MFMA = False
+
 def _packed_weights(weight, bias, dtype):
     """The operator's filters in the kernels' layout, KEPT across calls and validated on the device at every call
     (`h3d_dcn_v2_pack_weights_cached`): the bytes of `weight` and `bias` are hashed on the current stream and the pack kernel runs
@@ -103,7 +108,7 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
             dtype = _lib.H3D_BF16 if lowp else _lib.H3D_F32
             if lowp and not out_nhwc:
                 raise RuntimeError("dcn_v2_forward: bfloat16 needs Cout % 4 == 0")
-            flags = (_lib.DCN_INPUT_NHWC if nhwc else 0) | (_lib.DCN_OUTPUT_NHWC if out_nhwc else 0)
+            flags = (_lib.DCN_INPUT_NHWC if nhwc else 0) | (_lib.DCN_OUTPUT_NHWC if out_nhwc else 0) | (_lib.DCN_F32_MFMA if OP_F32_MFMA and not lowp else 0)
             packed = _packed_weights(weight, bias, dtype)
             out = torch.empty(B, Cout, Ho, Wo, dtype=input.dtype if lowp else torch.float32, device=input.device,
                               memory_format=torch.channels_last if out_nhwc else torch.contiguous_format)

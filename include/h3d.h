@@ -101,6 +101,9 @@ int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *
  * workspace: h3d_dcn_v2_packed_workspace_bytes(B, C, H, W, flags) bytes. */
 #define H3D_DCN_INPUT_NHWC 1
 #define H3D_DCN_OUTPUT_NHWC 2
+#define H3D_DCN_F32_MFMA 4      /* H3D_F32 packs: contract on the fp32 matrix instruction (exact fmaf chains) instead of the default since round 5,
+                                   three fp16 MFMAs on split operands per fp32 product (2^-22 relative per product, fp32 accumulation: ~2x the
+                                   rate).  The same choice for every fp32 fast-path entry point: environment H3D_DCN_OP_F32=1 */
 size_t h3d_dcn_v2_packed_weight_bytes(int Cout, int C, int dtype);
 int h3d_dcn_v2_pack_weights(const float *weight, const float *bias, int Cout, int C, int dtype, void *packed, void *stream);
 /* h3d_dcn_v2_pack_weights for a pack that is KEPT across calls: validated on the device, without a host synchronisation.  Every

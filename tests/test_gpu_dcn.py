@@ -87,6 +87,42 @@ def test_operator_fast_path_matches_oracle_and_general_kernel(shape, oscale):
     assert torch.equal(out2, gen)
 
 
+@pytest.mark.parametrize("gain", [1e-6, 1.0, 3e3])
+def test_operator_fast_path_arithmetics_agree_at_any_filter_magnitude(gain):
+    # round 5: fp32 tensors in the model's configuration contract on the fp16 matrix cores -- every fp32 product as three fp16 MFMAs on split
+    # operands (dcn2_kernel<x3_t>), the filters scaled by a power of two the DEVICE derives from max |w| (pack kernels -> the word behind the
+    # bias), so that tiny filters do not fall into fp16's subnormals and large ones do not overflow.  Against the fp64 oracle and against
+    # the exact fp32-MFMA arithmetic (dcn_v2.OP_F32_MFMA / H3D_DCN_F32_MFMA), both forms of the operator (packed + cached, and _ws)
+    import ctypes
+    B, C, Co, H, W = 2, 64, 96, 24, 40
+    x = rnd("x", (B, C, H, W), -2.0, 2.0)
+    w = rnd("w", (Co, C, 3, 3)) * (1.5 / np.sqrt(C * 9)) * gain
+    b = rnd("b", (Co,)) * gain
+    off = rnd("off", (B, 18, H, W), -3.0, 3.0)
+    m = rnd("m", (B, 9, H, W), 0.0, 1.0)
+    ref = odcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
+    scale = float(ref.abs().max())
+    y3 = _fwd(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    dcn_v2.OP_F32_MFMA = True
+    try:
+        y32 = _fwd(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    finally:
+        dcn_v2.OP_F32_MFMA = False
+    e3, e32 = float((y3 - ref).abs().max()) / scale, float((y32 - ref).abs().max()) / scale
+    print("gain %g: relative error vs fp64 oracle: f16x3 %.3g, fp32 MFMA %.3g" % (gain, e3, e32))
+    assert e3 <= 3e-6 and e32 <= 3e-6, (gain, e3, e32)
+    assert not torch.equal(y3, y32)                      # (they ARE different kernels)
+    # the reference-contract form (per-call pack inside the workspace)
+    xd, wd, bd, od, md = [t.contiguous().to(DEV) for t in (x, w, b, off, m)]
+    L = _lib.lib()
+    nws = int(L.h3d_dcn_v2_workspace_bytes(B, C, H, W, Co))
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    out = torch.empty(B, Co, H, W, device=DEV)
+    _lib.check(L.h3d_dcn_v2_forward_ws(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(od), _lib.ptr(md), _lib.ptr(out), B, C, H, W, Co,
+                                       3, 3, 1, 1, 1, 1, 1, 1, 1, _lib.ptr(ws), nws, _lib.stream_ptr()), "forward_ws")
+    assert torch.equal(out.cpu(), y3)                    # same kernel, same pack, same maximum
+
+
 def test_operator_boundary_gate_and_far_offsets():
     x = torch.ones(1, 1, 4, 4)
     w = torch.zeros(1, 1, 3, 3)
