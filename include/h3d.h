@@ -82,8 +82,8 @@ int h3d_dcn_offset_mask(const float *input, const float *off_weight, const float
 /* The same operator with a caller-provided device workspace of h3d_dcn_v2_workspace_bytes(...) bytes (the reference
  * callee allocates its own scratch: `columns`, `ones`, pointer tables, dcn_v2_cuda.cu:90-103).  For the configuration the
  * model uses (model.py:355: 3x3, stride 1, pad 1, dilation 1, deformable_group 1) and C % 16 == 0 the operands are re-laid
- * into the network kernels' layout inside the workspace and the contraction runs on the LDS-apron + fp32-MFMA kernel
- * (csrc/dcn2.hip); every other configuration (or a NULL / short workspace) takes h3d_dcn_v2_forward's general kernel. */
+ * into the network kernels' layout inside the workspace and the contraction runs on the LDS-apron + MFMA kernel (csrc/dcn2.hip: since
+ * round 5 three fp16 MFMAs on split operands per fp32 product, see H3D_DCN_F32_MFMA below); every other configuration (or a NULL / short workspace) takes h3d_dcn_v2_forward's general kernel. */
 size_t h3d_dcn_v2_workspace_bytes(int B, int C, int H, int W, int Cout);
 int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *bias,
                           const float *offset, const float *mask, float *output,
@@ -93,8 +93,8 @@ int h3d_dcn_v2_forward_ws(const float *input, const float *weight, const float *
                           int deformable_group, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The operator's THROUGHPUT form: the same contraction with the per-call work of the reference contract taken out.  The filters
- * are packed once (h3d_dcn_v2_pack_weights into h3d_dcn_v2_packed_weight_bytes(...) bytes; `dtype` H3D_F32 = exact fmaf chains on
- * the fp32 matrix instruction, H3D_BF16 = fp16 filters + fp16 blend + f16 MFMA on a bf16 input); `input` is NCHW fp32 as in the
+ * are packed once (h3d_dcn_v2_pack_weights into h3d_dcn_v2_packed_weight_bytes(...) bytes; `dtype` H3D_F32 = fp32 tensors (split-operand
+ * fp16 MFMAs, or exact fmaf chains on the fp32 matrix instruction with H3D_DCN_F32_MFMA), H3D_BF16 = fp16 filters + fp16 blend + f16 MFMA on a bf16 input); `input` is NCHW fp32 as in the
  * reference or, with H3D_DCN_INPUT_NHWC, channels-last [B,H,W,C] of `dtype` (torch.channels_last: no relayout); the output is
  * NCHW fp32 or, with H3D_DCN_OUTPUT_NHWC, channels-last of `dtype`.  offset [B,18,H,W] and mask [B,9,H,W] stay the reference's
  * NCHW fp32 operands.  3x3, stride 1, pad 1, dilation 1, deformable_group 1 (model.py:355), C % 16 == 0.
