@@ -123,6 +123,30 @@ def test_operator_fast_path_arithmetics_agree_at_any_filter_magnitude(gain):
     assert torch.equal(out.cpu(), y3)                    # same kernel, same pack, same maximum
 
 
+def test_operator_fast_path_random_shapes_vs_general_kernel():
+    # 24 seeded random shapes of the model's configuration (any batch, C a multiple of 16, ANY Cout, maps from 1 x 1 to 40 x 40: partial
+    # tiles, maps smaller than the apron, a single pixel) through the LDS-apron + split-operand MFMA kernel against the general
+    # operator kernel (fp32 vector FMAs, the simple restatement of dcn_v2_im2col_cuda.cu) on the same operands
+    rng = np.random.RandomState(2026)
+    L = _lib.lib()
+    for it in range(24):
+        B, C = int(rng.randint(1, 4)), 16 * int(rng.randint(1, 6))
+        Co = int(rng.choice([1, 7, 27, 33, 64, 100, 130]))
+        H, W = int(rng.randint(1, 41)), int(rng.randint(1, 41))
+        x = rnd("x%d" % it, (B, C, H, W), -2.0, 2.0)
+        w = rnd("w%d" % it, (Co, C, 3, 3)) * (1.5 / np.sqrt(C * 9))
+        b = rnd("b%d" % it, (Co,))
+        off = rnd("o%d" % it, (B, 18, H, W), -1.0, 1.0) * float(rng.choice([0.5, 2.0, 8.0]))
+        m = rnd("m%d" % it, (B, 9, H, W), 0.0, 1.0)
+        y = _fwd(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+        xd, wd, bd, od, md = [t.contiguous().to(DEV) for t in (x, w, b, off, m)]
+        gen = torch.empty(B, Co, H, W, device=DEV)
+        _lib.check(L.h3d_dcn_v2_forward(_lib.ptr(xd), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(od), _lib.ptr(md), _lib.ptr(gen), B, C, H, W,
+                                        Co, 3, 3, 1, 1, 1, 1, 1, 1, 1, _lib.stream_ptr()), "general")
+        e = float((y - gen.cpu()).abs().max())
+        assert e <= 2e-5 * max(1.0, float(gen.abs().max())), (it, (B, C, Co, H, W), e)
+
+
 def test_operator_boundary_gate_and_far_offsets():
     x = torch.ones(1, 1, 4, 4)
     w = torch.zeros(1, 1, 3, 3)
