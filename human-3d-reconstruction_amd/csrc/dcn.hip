@@ -377,7 +377,7 @@ static int sig_begin(unsigned long long *state, const void *const *bufs, const s
 
 __global__ void dcn_wmax_reset_if_kernel(const unsigned long long *__restrict__ state, unsigned *__restrict__ wmax)
 {
-    if (state[0] != state[1]) *wmax = 0u;                  // the pack kernel behind this one rebuilds the image and its maximum
+    if (state[0] != state[1]) wmax[0] = wmax[1] = 0u;      // the pack kernel behind this one rebuilds the image and its maxima (two words: main, offset filters)
 }
 
 __global__ void dcn_w_pack_if_kernel(const float *__restrict__ w, const float *__restrict__ bias, void *__restrict__ wp_, float *__restrict__ bp,
@@ -436,6 +436,7 @@ __global__ void dcn_fused_pack_f32_if_kernel(const float *__restrict__ w, const 
                                              int Cout, int C, int rows, const unsigned long long *__restrict__ state)
 {
     if (state[0] == state[1]) return;
+    unsigned *wmax = (unsigned *)(bo + rows + 32);         // [0] max |main filter|, [1] max |offset / mask filter| (reset by dcn_wmax_reset_if_kernel)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t main_total = (size_t)rows * 9 * C, total = main_total + (size_t)128 * 9 * C;
     auto src_channel = [](int row) {                       // MFMA row of the permuted offset conv -> conv_offset_mask channel (-1: unused)
@@ -448,15 +449,23 @@ __global__ void dcn_fused_pack_f32_if_kernel(const float *__restrict__ w, const 
     };
     if (i < (size_t)rows) bo[i] = i < (size_t)Cout ? bias[i] : 0.f;
     if (i < 32) { const int ch = src_channel((int)i); bo[rows + i] = ch >= 0 ? ob[ch] : 0.f; }
-    if (i >= total) return;
-    const bool off = i >= main_total;
-    const size_t j = off ? i - main_total : i;
-    const int c = (int)(j % C);
-    const int tap = (int)((j / C) % 9);
-    const int o = (int)(j / ((size_t)9 * C));
-    if (!off) { wp[j] = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f; return; }
-    const int ch = src_channel(o);
-    wo[j] = ch >= 0 ? ow[((size_t)ch * C + c) * 9 + tap] : 0.f;
+    const bool off = i >= main_total;          // (main_total is a multiple of 64: a wave lies on one side)
+    float v = 0.f;
+    if (i < total) {
+        const size_t j = off ? i - main_total : i;
+        const int c = (int)(j % C);
+        const int tap = (int)((j / C) % 9);
+        const int o = (int)(j / ((size_t)9 * C));
+        if (!off) {
+            v = o < Cout ? w[((size_t)o * C + c) * 9 + tap] : 0.f;
+            wp[j] = v;
+        } else {
+            const int ch = src_channel(o);
+            v = ch >= 0 ? ow[((size_t)ch * C + c) * 9 + tap] : 0.f;
+            wo[j] = v;
+        }
+    }
+    dcn_wmax_accumulate(wmax + (off ? 1 : 0), v);      // (every lane of the wave takes part in the shuffles)
 }
 
 extern "C" int h3d_dcn_fused_pack_f32_cached(const float *weight, const float *bias, const float *off_weight, const float *off_bias, int Cout, int C,
@@ -472,6 +481,8 @@ extern "C" int h3d_dcn_fused_pack_f32_cached(const float *weight, const float *b
     if (rc != H3D_OK) return rc;
     const int rows = (Cout + 127) / 128 * 128;
     const size_t total = ((size_t)rows + 128) * 9 * C;
+    hipLaunchKernelGGL(dcn_wmax_reset_if_kernel, dim3(1), dim3(1), 0, st, state, (unsigned *)(bias_out + rows + 32));
+    H3D_CHECK_LAUNCH("dcn_wmax_reset_if_kernel");
     hipLaunchKernelGGL(dcn_fused_pack_f32_if_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, weight, bias, off_weight, off_bias, wp, wo,
                        bias_out, Cout, C, rows, state);
     H3D_CHECK_LAUNCH("dcn_fused_pack_f32_if_kernel");

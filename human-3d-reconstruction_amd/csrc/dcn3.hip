@@ -38,6 +38,9 @@ struct Dcn3Args {
     int dbg;   // profiling ablation (h3d_op.reserved): 1 no phase-A MFMA, 2 no gather/blend, 4 no phase-B MFMA, 8 stage once, 16 no patch fill
     int G;     // WDMA: 32-row groups of the main filter image
     float wscale, oscale;   // f16x3 plans: 2^-wexp / 2^-wexp2 of the main / offset filters (h3d_op.wexp, wexp2); 1 otherwise
+    const unsigned *wmax;   // f16x3, register-staged filters only (the stand-alone `DCN` module): the filters are PLAIN fp32 packs and [0] / [1] hold the
+                            // bit patterns of max |main filter| / max |offset filter| (csrc/dcn.hip dcn_fused_pack_f32_if_kernel): scaled by a power of
+                            // two and split while they are staged, as csrc/dcn2.hip does for the operator; nullptr = pre-split filters (network plans)
     int xcd;   // h3d_tile_id mode
     unsigned long long *stamps;   // profiling builds: in-kernel phase stamps (common.h H3D_STAMP)
 };
@@ -152,6 +155,34 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
     const char *img = a.in + (size_t)b * a.H * a.W * a.in_cs * ES;
     const int aoff = r * C::WB + 8 * h * SS;
     const int nchunks = a.Cin / CK;
+    // filter scales of this launch: the host's exponents (network plans), or derived here from the maxima the pack kernel left (a.wmax)
+    [[maybe_unused]] float wsc[2] = {1.f, 1.f}, wun = a.wscale, oun = a.oscale;      // wsc[0]: main, wsc[1]: offset filters
+    [[maybe_unused]] bool rawf = false;
+    if constexpr (std::is_same_v<T, x3_t> && !WDMA) {
+        rawf = a.wmax != nullptr;
+        if (rawf) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float m = __uint_as_float(a.wmax[q]);
+                int k = 14;
+                if (m > 0.f && m < __builtin_inff()) (void)frexpf(m, &k);
+                const int e = min(60, max(-60, 14 - k));
+                wsc[q] = ldexpf(1.f, e);
+                (q ? oun : wun) = ldexpf(1.f, -e);
+            }
+        }
+    }
+    [[maybe_unused]] auto store_w = [&](char *dst_row_tap, int v, u32x4 raw, int which) {      // one 16-byte vector of a staged filter row -> LDS
+        if constexpr (std::is_same_v<T, x3_t> && !WDMA) {
+            if (rawf) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) raw[i] = __float_as_uint(__uint_as_float(raw[i]) * wsc[which]);
+                x3_store4(dst_row_tap + (v >> 1) * 32, v & 1, raw);
+                return;
+            }
+        }
+        *reinterpret_cast<u32x4 *>(dst_row_tap + v * 16) = raw;
+    };
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const int off_bytes = nchunks * C::WGRP, main_bytes = nchunks * a.G * C::WGRP;
     // WDMA: filters of stage s -> ring slot s & 1
@@ -217,7 +248,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
                 const int q0 = i - NH;
                 const int row = q0 / WV, q = q0 - row * WV;
                 const int tap = q / C::VPP, v = q - tap * C::VPP;
-                *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = stg[j];
+                store_w(s_w + row * C::WB + tap * CK * SS, v, stg[j], s < nchunks ? 1 : 0);
             }
         }
     };
@@ -349,7 +380,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
         const float *bo = a.bias + a.wrows;
         if constexpr (std::is_same_v<T, x3_t>) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) aoffs[i] = fmaf(aoffs[i], a.oscale, bo[(i & 3) + 8 * (i >> 2) + 4 * h]);     // (exact power-of-two unscale)
+            for (int i = 0; i < 16; ++i) aoffs[i] = fmaf(aoffs[i], oun, bo[(i & 3) + 8 * (i >> 2) + 4 * h]);     // (exact power-of-two unscale)
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
@@ -785,7 +816,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
             const float *bo = a.bias + a.wrows;
             if constexpr (std::is_same_v<T, x3_t>) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) aoffs[i] = fmaf(aoffs[i], a.oscale, bo[(i & 3) + 8 * (i >> 2) + 4 * h]);
+                for (int i = 0; i < 16; ++i) aoffs[i] = fmaf(aoffs[i], oun, bo[(i & 3) + 8 * (i >> 2) + 4 * h]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) aoffs[i] += bo[(i & 3) + 8 * (i >> 2) + 4 * h];
@@ -882,8 +913,8 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
                 for (int i = tid; i < C::BN * WV; i += C::THREADS) {
                     const int row = i / WV, q = i - row * WV;
                     const int tap = q / C::VPP, v = q - tap * C::VPP;
-                    *reinterpret_cast<u32x4 *>(s_w + row * C::WB + tap * CK * SS + v * 16) = *reinterpret_cast<const u32x4 *>(
-                        a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16);
+                    store_w(s_w + row * C::WB + tap * CK * SS, v, *reinterpret_cast<const u32x4 *>(
+                        a.w + (((size_t)(cout0 + row) * 9 + tap) * a.Cin + c0) * SS + v * 16), 0);
                 }
             }
             __syncthreads();
@@ -941,7 +972,7 @@ __global__ __launch_bounds__(512, (WDMA && MT <= 2 && sizeof(T) == 2) ? 4 : 2) v
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][0][i] *= a.wscale;
+            for (int i = 0; i < 16; ++i) acc[m][0][i] *= wun;
     }
     EpiArgs e;
     e.bias = a.bias; e.res = nullptr; e.out = a.out; e.Ho = a.H; e.Wo = a.W; e.Cout = a.Cout;
@@ -1106,6 +1137,7 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
         H3D_FAIL(H3D_ERR_ARG, "dcn_fused: wexp %d / %d (H3D_F16X3 filter exponents)", op.wexp, op.wexp2);
     a.wscale = ldexpf(1.f, -op.wexp);
     a.oscale = ldexpf(1.f, -op.wexp2);
+    a.wmax = nullptr;
     if (wdma && (size_t)op.H * op.W * op.in_cs * es >= 0x7ffffff0ull) H3D_FAIL(H3D_ERR_SHAPE, "dcn_fused_stream: image of 2 GiB or more");
     if (op.dtype == H3D_BF16 && (op.reserved & 0x40000)) return launch_dcn3_lowp<bf16_t, true>(op, a, wdma, st);
     if (op.dtype == H3D_BF16) return launch_dcn3_lowp<bf16_t>(op, a, wdma, st);
@@ -1150,6 +1182,12 @@ int h3d_launch_dcn3(const h3d_op &op, hipStream_t st)
         return launch_dcn3_cfg<x3_t, 2, 16, 2, true, 256>(a, st);
     }
     if (op.dtype == H3D_F16X3) {            // the f32 plan's tiles (fp32 apron, register-staged pre-split filters) on 3 fp16 MFMAs per step
+        // 0x100000 (the stand-alone `DCN` module, h3d_amd/dcn_v2.py): plain fp32 filter packs of h3d_dcn_fused_pack_f32_cached, the two filter
+        // maxima behind the biases (bias[wrows + 32 ...]); the kernel scales and splits the filters while it stages them
+        if (op.reserved & 0x100000) {
+            if (op.wexp || op.wexp2) H3D_FAIL(H3D_ERR_ARG, "dcn_fused (f16x3, raw filters): wexp must be 0 (the scale comes from the pack's maxima)");
+            a.wmax = (const unsigned *)(op.bias + op.wrows + 32);
+        }
         if (op.reserved & 0x2000) {         // tuning override (tools/ab_flag.py): the f32 plan's margin-2 double-buffered tile
             if (op.Cout <= 32) return launch_dcn3_cfg<x3_t, 1, 16, 2>(a, st);
             return launch_dcn3_cfg<x3_t, 2, 16, 2>(a, st);

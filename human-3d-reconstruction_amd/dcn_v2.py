@@ -218,7 +218,7 @@ class DCN(DCNv2):
 
         def fresh():
             return (torch.empty(rows * 9 * C, dtype=torch.float32, device=device), torch.empty(128 * 9 * C, dtype=torch.float32, device=device),
-                    torch.empty(rows + 32, dtype=torch.float32, device=device), torch.zeros(2, dtype=torch.int64, device=device), (rows, C), stream)
+                    torch.zeros(rows + 32 + 64, dtype=torch.float32, device=device), torch.zeros(2, dtype=torch.int64, device=device), (rows, C), stream)
         ent = getattr(self, "_pack", None)
         if ent is None or ent[0].device != device or ent[4] != (rows, C):
             ent = fresh()
@@ -263,7 +263,10 @@ class DCN(DCNv2):
                 L = _lib.lib()
                 _lib.check(L.h3d_nchw_f32_to_nhwc(_lib.ptr(x), _lib.ptr(xn), _lib.H3D_F32, B, C, H, W, C, _lib.stream_ptr()), "DCN: to NHWC")
                 op = H3dOp()
-                op.kind, op.dtype, op.B, op.H, op.W, op.Ho, op.Wo = _lib.OP_DCN_FUSED, _lib.H3D_F32, B, H, W, H, W
+                # fp32 tensors, fp32 packs; since round 5 every product as three fp16 MFMAs on split operands (filters scaled and split while
+                # they are staged: reserved 0x100000), or exact fmaf chains on the fp32 matrix instruction with OP_F32_MFMA
+                op.kind, op.dtype, op.B, op.H, op.W, op.Ho, op.Wo = _lib.OP_DCN_FUSED, (_lib.H3D_F32 if OP_F32_MFMA else _lib.H3D_F16X3), B, H, W, H, W
+                op.reserved = 0 if OP_F32_MFMA else 0x100000
                 op.in_, op.in2, op.w, op.bias, op.out = xn.data_ptr(), wo.data_ptr(), wp.data_ptr(), bias.data_ptr(), out.data_ptr()
                 op.Cin, op.in_cs, op.Cout, op.out_cs, op.ksize, op.stride, op.relu = C, C, self.out_channels, self.out_channels, 3, 1, 0
                 op.out_mode, op.wrows = _lib.OUT_NCHW_F32, rows

@@ -115,7 +115,9 @@ int h3d_dcn_v2_pack_weights_cached(const float *weight, const float *bias, int C
                                    void *stream);
 /* The four parameters of the stand-alone `DCN` module (dcn_v2.py:97-116; conv_offset_mask has 27 output channels) in the fp32 layout
  * of H3D_OP_DCN_FUSED: wp [rows = Cout padded to 128][9][C], wo [128][9][C] (rows permuted as the op expects), bias_out
- * [rows | 32]; validated on the device like h3d_dcn_v2_pack_weights_cached (state: 16 zeroed bytes). */
+ * [rows | 32 | 64]: the biases, then (round 5) 64 floats of which the first two words are the bit patterns of max |weight| and
+ * max |off_weight| -- what an H3D_OP_DCN_FUSED of dtype H3D_F16X3 with reserved = 0x100000 derives its power-of-two filter scales
+ * from (fp32 packs, split while they are staged); validated on the device like h3d_dcn_v2_pack_weights_cached (state: 16 zeroed bytes). */
 int h3d_dcn_fused_pack_f32_cached(const float *weight, const float *bias, const float *off_weight, const float *off_bias, int Cout, int C,
                                   float *wp, float *wo, float *bias_out, void *state, void *stream);
 size_t h3d_dcn_v2_packed_workspace_bytes(int B, int C, int H, int W, int flags);

@@ -123,6 +123,34 @@ def test_operator_fast_path_arithmetics_agree_at_any_filter_magnitude(gain):
     assert torch.equal(out.cpu(), y3)                    # same kernel, same pack, same maximum
 
 
+@pytest.mark.parametrize("gain", [1e-5, 1.0, 1e3])
+def test_dcn_module_fused_launch_arithmetics_agree(gain):
+    # the stand-alone `DCN` module in the model's configuration: ONE fused launch (offset conv + sampling + contraction); since round 5 on the
+    # fp16 matrix cores (split operands, the filters of both convolutions scaled from the maxima the pack kernel leaves on the device),
+    # against the fp64 oracle and against the fp32-matrix-instruction arithmetic (dcn_v2.OP_F32_MFMA)
+    torch.manual_seed(7)
+    dcn = dcn_v2.DCN(64, 96, (3, 3), stride=1, padding=1, dilation=1, deformable_groups=1).to(DEV).eval()
+    with torch.no_grad():
+        dcn.weight.mul_(gain)
+        dcn.bias.copy_(torch.randn(96, device=DEV) * gain)
+        dcn.conv_offset_mask.weight.copy_(torch.randn_like(dcn.conv_offset_mask.weight) * 0.02)
+        dcn.conv_offset_mask.bias.copy_(torch.randn_like(dcn.conv_offset_mask.bias) * 0.3)
+    x = rnd("xm", (2, 64, 40, 72), -2.0, 2.0)
+    y3 = dcn(x.to(DEV)).cpu()
+    dcn_v2.OP_F32_MFMA = True
+    try:
+        y32 = dcn(x.to(DEV)).cpu()
+    finally:
+        dcn_v2.OP_F32_MFMA = False
+    ref = odcn.dcn_module_forward(x, dcn.weight.detach().cpu(), dcn.bias.detach().cpu(), dcn.conv_offset_mask.weight.detach().cpu(),
+                                  dcn.conv_offset_mask.bias.detach().cpu(), acc_dtype=torch.float64)
+    scale = float(ref.abs().max())
+    e3, e32 = float((y3 - ref).abs().max()) / scale, float((y32 - ref).abs().max()) / scale
+    print("DCN module, gain %g: relative error vs fp64 oracle: f16x3 %.3g, fp32 MFMA %.3g" % (gain, e3, e32))
+    assert e3 <= 2e-5 and e32 <= 2e-5, (gain, e3, e32)       # (offsets computed in fp32-grade arithmetic move the sampling positions by ~1e-6 px)
+    assert not torch.equal(y3, y32)
+
+
 def test_operator_fast_path_random_shapes_vs_general_kernel():
     # 24 seeded random shapes of the model's configuration (any batch, C a multiple of 16, ANY Cout, maps from 1 x 1 to 40 x 40: partial
     # tiles, maps smaller than the apron, a single pixel) through the LDS-apron + split-operand MFMA kernel against the general
