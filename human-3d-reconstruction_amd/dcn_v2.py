@@ -7,6 +7,8 @@ inference only -- an INPUT that requires grad (with autograd enabled) raises; pa
 nn.Parameter default), results are computed without a graph and returned detached."""
 import math
 
+import os
+
 import torch
 from torch import nn
 from torch.nn.modules.utils import _pair
@@ -21,7 +23,7 @@ _PACKED_MAX = 64
 # fp32 tensors in the model's configuration: False (default since round 5) = three fp16 MFMAs on split operands per fp32 product
 # (H3D_F16X3: 2^-22 relative per product, fp32 accumulation, ~2x the rate), True = exact fmaf chains on the fp32 matrix instruction
 # (H3D_DCN_F32_MFMA; the environment variable H3D_DCN_OP_F32=1 selects the same for every entry point of the library)
-OP_F32_MFMA = False
+OP_F32_MFMA = os.environ.get("H3D_DCN_OP_F32", "") not in ("", "0")
 
 def _packed_weights(weight, bias, dtype):
     """The operator's filters in the kernels' layout, KEPT across calls and validated on the device at every call
