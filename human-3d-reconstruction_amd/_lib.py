@@ -17,7 +17,7 @@ OP_IM2COL, OP_MAXPOOL3, OP_DEPTH2SPACE = 15, 16, 17
 HEADS_MAX = 16
 OUT_NHWC, OUT_NCHW_F32, OUT_NHWC_F32, OUT_NHWC_F16 = 0, 1, 2, 3
 DCN_INPUT_NHWC, DCN_OUTPUT_NHWC, DCN_F32_MFMA = 1, 2, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_vp, c_i, c_fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p
 

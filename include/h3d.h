@@ -43,7 +43,9 @@ extern "C" {
 const char *h3d_last_error(void);
 /* ABI version of this header; the loader checks it. */
 int h3d_abi_version(void);
-#define H3D_ABI_VERSION 2
+#define H3D_ABI_VERSION 3      /* 2: h3d_op.wexp / wexp2 (120-byte descriptor); 3: fp32 DeformConv packs carry their filter maxima (the sizes
+                                  h3d_dcn_v2_packed_weight_bytes / _workspace_bytes return grew by 256 B; bias_out of h3d_dcn_fused_pack_f32_cached
+                                  is [rows | 32 | 64] floats) */
 /* How this library was built: H3D_BUILD_EXTRA = `make EXTRA=1` (the superseded kernel generations kept as A/B references are in:
  * H3D_OP_DCN_V1, H3D_OP_DCN_FUSED_F16, H3D_OP_UPDCN_F16, the 0x4000 DeformConv variant, h3d_smpl_verts2 -- without it they return
  * H3D_ERR_UNSUPPORTED); H3D_BUILD_ABLATE = `make ABLATE=1` (profiling switches and in-kernel stamps compiled in). */
