@@ -203,6 +203,55 @@ __global__ __launch_bounds__(512 / NT_) void dcn2_kernel(Dcn2Args a)
         __syncthreads();
         if (c0 + CK < a.Cin) load_stage(c0 + CK);
 
+#ifndef DCN2_X3_PIPE
+#define DCN2_X3_PIPE 1
+#endif
+        if constexpr (DCN2_X3_PIPE && std::is_same_v<T, x3_t> && CK == 16 && NT == 1) {
+            // f16x3: tap t+1 is blended and split BETWEEN the MFMAs of tap t (a wave issues in order; second operand register set), tap
+            // t+2's corners requested as soon as t+1 is blended -- csrc/dcn3.hip's phase B schedule, see there
+            typename X::frag v[4];
+            typename X::bfrag pb[2];
+            auto gather = [&](int tap) {
+                const char *p00 = s_h + boff[0][tap];
+                v[0] = X::lds(p00);
+                v[1] = X::lds(p00 + C::SBH);
+                v[2] = X::lds(p00 + C::RBH);
+                v[3] = X::lds(p00 + C::RBH + C::SBH);
+            };
+            gather(0);
+            {
+                const typename X::frag fb0 = X::blend(v, geo[0][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                gather(1);
+                pb[0] = X::prep(fb0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                typename X::wfrag fa[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = X::lds_w(s_w + aoff + m * 32 * C::WB + tap * CK * SS);
+                if (tap + 1 < 9) {
+                    const typename X::frag fbn = X::blend(v, geo[0][tap + 1]);
+                    if (tap + 2 < 9) gather(tap + 2);
+                    pb[(tap + 1) & 1] = X::prep(fbn);
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) X::mma(acc[m][0], fa[m], pb[tap & 1]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
+                if (tap + 1 < 9) {
+#pragma unroll
+                    for (int i = 0; i < 3 * MT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i == 3 * MT - 1) __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x002, 36 / (3 * MT - 1) + 1, 0);
+                        if (i == (MT > 1 ? 2 : 1) && tap + 2 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             typename X::frag fb[NT][CK / 16];
