@@ -151,6 +151,26 @@ def test_dcn_module_fused_launch_arithmetics_agree(gain):
     assert not torch.equal(y3, y32)
 
 
+def test_operator_cached_pack_follows_in_place_filter_edits_of_any_magnitude():
+    # the kept pack (h3d_dcn_v2_pack_weights_cached) validates itself on the device; its filter maximum -- what the split-operand kernel
+    # scales by -- must be rebuilt with it: shrink the SAME weight tensor by 1e-6 in place (a stale maximum would leave every filter in
+    # fp16's subnormal range: 1e-3 relative), then grow it by 1e9 (a stale maximum would overflow fp16: inf / NaN)
+    B, C, Co, H, W = 1, 32, 48, 20, 24
+    x = rnd("x", (B, C, H, W), -2.0, 2.0).to(DEV)
+    w = (rnd("w", (Co, C, 3, 3)) * 0.1).to(DEV)
+    b = torch.zeros(Co, device=DEV)
+    off = rnd("off", (B, 18, H, W), -2.0, 2.0).to(DEV)
+    m = rnd("m", (B, 9, H, W), 0.0, 1.0).to(DEV)
+    for factor in (1.0, 1e-6, 1e9):
+        w.mul_(factor)                                   # in place: same data_ptr, no torch version bump through .data
+        with torch.no_grad():
+            y = dcn_v2.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1).cpu()
+        ref = odcn.dcn_v2_forward(x.cpu(), w.cpu(), b.cpu(), off.cpu(), m.cpu(), 3, 3, 1, 1, 1, 1, 1, 1, 1, acc_dtype=torch.float64)
+        assert bool(torch.isfinite(y).all()), factor
+        e = float((y - ref).abs().max()) / float(ref.abs().max())
+        assert e <= 3e-6, (factor, e)
+
+
 def test_operator_fast_path_random_shapes_vs_general_kernel():
     # 24 seeded random shapes of the model's configuration (any batch, C a multiple of 16, ANY Cout, maps from 1 x 1 to 40 x 40: partial
     # tiles, maps smaller than the apron, a single pixel) through the LDS-apron + split-operand MFMA kernel against the general
