@@ -52,6 +52,8 @@ PEAK_HBM_GBS = 8000.0
 PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # this round's counter passes; a kernel that is not in it reports traffic: null
 PMC_SQ_FILE = "r05_pmc_sq_summary.json"     # ... SQ counters per kernel (mfma_util, gpu_cycles, ...)
 KERNEL_STATS_FILE = "r05_v1_kernel_stats.csv"   # ... rocprofv3 --kernel-trace --stats summary of `bench.py --pipeline 1`
+# the same three files of the f16x3 plan (`--dtype f16x3`; tools/profile_round5.sh, profile_x3_pmc.sh, profile_x3_traffic.sh)
+PROFILE_FILES_X3 = ("r05_f16x3_pmc_traffic.json", "r05_f16x3_pmc_sq_summary.json", "r05_f16x3_kernel_stats.csv")
 
 
 class ClockSampler:
@@ -838,6 +840,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="launcher + collective plumbing only, gloo on CPU (tests)")
     args = ap.parse_args()
+    if args.dtype == "f16x3":          # the roofline record reads the f16x3 plan's own committed profile
+        global PMC_TRAFFIC_FILE, PMC_SQ_FILE, KERNEL_STATS_FILE
+        PMC_TRAFFIC_FILE, PMC_SQ_FILE, KERNEL_STATS_FILE = PROFILE_FILES_X3
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
